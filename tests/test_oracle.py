@@ -1,0 +1,156 @@
+"""CPU tests of the oracle itself (no GPU): exact integer invariants, degenerate
+inputs (section 4.5) and the independent PyTorch-autograd check of the analytic backward (section 4.2)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gs_oracle, torch_ref
+from segs_slam_amd import scenes
+
+
+def _run(scene, backward=True):
+    return gs_oracle.run_scene(scene, backward=backward)
+
+
+def check_binning_invariants(P, W, H, radii, means2D, depths, tiles_touched, offsets, keys, point_list, ranges, R, sort_bits):
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    assert (offsets[-1] if P else 0) == R
+    assert np.array_equal(np.cumsum(tiles_touched.astype(np.uint64)).astype(np.uint32), offsets)
+    assert np.array_equal(tiles_touched > 0, radii > 0)
+    # keys sorted on the low `sort_bits` bits
+    mask = np.uint64((1 << sort_bits) - 1)
+    mk = keys & mask
+    assert np.all(mk[1:] >= mk[:-1])
+    tile = (keys >> np.uint64(32)).astype(np.int64)
+    assert np.all(tile < gx * gy)
+    # depth bits of the key are the Gaussian's depth; stable order: ties in (tile, depth) keep index order
+    dbits = depths.view(np.uint32)[point_list]
+    assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), dbits)
+    same = mk[1:] == mk[:-1]
+    assert np.all(point_list[1:][same] > point_list[:-1][same])
+    # ranges partition [0, R): each tile's [start,end) holds exactly its keys
+    starts, ends = ranges[:, 0].astype(np.int64), ranges[:, 1].astype(np.int64)
+    counts = np.bincount(tile, minlength=gx * gy)
+    assert np.array_equal(ends - starts, counts)
+    nz = counts > 0
+    assert np.array_equal(starts[nz], (np.cumsum(counts) - counts)[nz])
+    assert np.all(starts[~nz] == 0) and np.all(ends[~nz] == 0)
+    # every (tile, idx) pair appears exactly once and iff the rect covers the tile
+    r = radii.astype(np.float32)
+    f32 = np.float32
+    rminx = np.clip(((means2D[:, 0] - r) / f32(16)).astype(np.int32), 0, gx)
+    rminy = np.clip(((means2D[:, 1] - r) / f32(16)).astype(np.int32), 0, gy)
+    rmaxx = np.clip(((means2D[:, 0] + r + f32(15)) / f32(16)).astype(np.int32), 0, gx)
+    rmaxy = np.clip(((means2D[:, 1] + r + f32(15)) / f32(16)).astype(np.int32), 0, gy)
+    vis = radii > 0
+    assert np.array_equal(((rmaxx - rminx) * (rmaxy - rminy))[vis].astype(np.uint32), tiles_touched[vis])
+    tx, ty = tile % gx, tile // gx
+    pl = point_list.astype(np.int64)
+    assert np.all((tx >= rminx[pl]) & (tx < rmaxx[pl]) & (ty >= rminy[pl]) & (ty < rmaxy[pl]))
+    pair = tile * max(P, 1) + pl
+    assert np.unique(pair).size == pair.size
+
+
+@pytest.mark.parametrize("P,W,H", [(1000, 64, 64), (17, 33, 17), (5000, 200, 120)])
+def test_binning_invariants(P, W, H):
+    sc = scenes.make_scene(P, W, H, 0.9 * W, 0.9 * W, seed=99 + P)
+    o, _ = _run(sc, backward=False)
+    check_binning_invariants(P, W, H, o.get("radii"), o.get("means2D"), o.get("depths"), o.get("tiles_touched"),
+                             o.get("point_offsets"), o.get("keys"), o.get("point_list"), o.get("ranges"), o.R, o.sort_bits)
+    assert o.sort_bits == 32 + int(((W + 15) // 16 * ((H + 15) // 16))).bit_length()
+
+
+def test_get_higher_msb_examples():
+    # 3225 -> 12, 8160 -> 13, 1200 -> 11 (rasterizer_impl.cu:35-50)
+    for (W, H, bits) in [(1200, 680, 12), (1920, 1080, 13), (640, 480, 11)]:
+        sc = scenes.make_scene(8, W, H, 500.0, 500.0, seed=5)
+        o, _ = _run(sc, backward=False)
+        assert o.sort_bits == 32 + bits
+
+
+def test_degenerate_inputs():
+    # P = 0 (src/rasterize_points.cu:81,159)
+    sc = scenes.make_scene(0, 32, 32, 30.0, 30.0, bg=(0.5, 0.25, 0.125))
+    o, g = _run(sc)
+    assert o.R == 0
+    img = o.get("out_color")
+    assert np.allclose(img[0], 0.5) and np.allclose(img[1], 0.25) and np.allclose(img[2], 0.125)
+    # all culled: every Gaussian behind the near threshold -> R = 0 (rasterizer_impl.cu:313)
+    sc = scenes.make_scene(64, 40, 24, 30.0, 30.0, seed=3)
+    sc.means3D[:, 2] = 0.1
+    o, g = _run(sc)
+    assert o.R == 0 and np.all(o.get("radii") == 0)
+    assert all(np.all(v == 0) for v in g.values())
+    # opacity so small that alpha < 1/255 everywhere: image = background, n_contrib = 0
+    sc = scenes.make_scene(200, 48, 48, 40.0, 40.0, seed=4, bg=(0.3, 0.3, 0.3))
+    sc.opacity[:] = 0.003
+    o, g = _run(sc)
+    assert o.R > 0 and np.all(o.get("n_contrib") == 0) and np.allclose(o.get("out_color"), 0.3)
+    assert np.all(g["dL_dopacity"] == 0)
+    # a Gaussian whose radius spans the whole (non-multiple-of-16) image
+    sc = scenes.make_scene(1, 50, 35, 40.0, 40.0, seed=6)
+    sc.means3D[:] = [0, 0, 1.0]
+    sc.scales[:] = 2.0
+    o, _ = _run(sc, backward=False)
+    assert o.get("tiles_touched")[0] == 4 * 3 and o.R == 12
+
+
+def _torch_grads(sc, o):
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), requires_grad=True)  # noqa: E731
+    m, s, r, op, col = t(sc.means3D), t(sc.scales), t(sc.rotations), t(sc.opacity), t(sc.colors)
+    cam = sc.camera
+    img, p_proj = torch_ref.render(m, s, r, op, col, torch.tensor(sc.bg, dtype=torch.float64),
+                                   torch.tensor(cam.world_view_transform), torch.tensor(cam.full_proj_transform),
+                                   cam.tanfovx, cam.tanfovy, cam.height, cam.width,
+                                   torch.tensor(o.get("radii")), torch.tensor(o.get("means2D")), sc.scale_modifier)
+    loss = (img * torch.tensor(sc.dL_dout_color, dtype=torch.float64)).sum()
+    loss.backward()
+    return img.detach().numpy(), dict(dL_dmean3D=m.grad, dL_dscale=s.grad, dL_drot=r.grad, dL_dopacity=op.grad,
+                                      dL_dcolor=col.grad, dL_dmean2D=p_proj.grad)
+
+
+@pytest.mark.parametrize("seed,bg", [(11, (0.0, 0.0, 0.0)), (12, (0.2, 0.5, 0.9))])
+def test_backward_matches_autograd(seed, bg):
+    """Oracle K10 image and K11-K13 gradients vs an independent float64 autograd formulation."""
+    sc = scenes.make_scene(120, 48, 32, 40.0, 40.0, seed=seed, bg=bg)
+    sc.scales *= 4.0  # bigger splats so many pixels blend several Gaussians
+    sc.dL_dout_color[:] = (scenes.uniform01(sc.dL_dout_color.size, 77, seed).reshape(sc.dL_dout_color.shape) * 2 - 1)
+    o, g = _run(sc)
+    assert not o.unstable_pixels(1e-4).any(), "pick another seed: a threshold decision is float32/float64 sensitive"
+    img, tg = _torch_grads(sc, o)
+    assert np.abs(img - o.get("out_color")).max() < 2e-5
+    for k in ("dL_dmean3D", "dL_dscale", "dL_drot", "dL_dopacity", "dL_dcolor"):
+        ref = tg[k].numpy()
+        err = np.abs(g[k] - ref).max()
+        scale = np.abs(ref).max() + 1e-30
+        assert err / scale < 2e-4, (k, err, scale)
+    ref = tg["dL_dmean2D"].numpy()[:, :2]
+    assert np.abs(g["dL_dmean2D"][:, :2] - ref).max() / (np.abs(ref).max() + 1e-30) < 2e-4
+
+
+def test_backward_finite_difference_scalar():
+    """A handful of scalars by central finite differences on the oracle's own forward."""
+    sc = scenes.make_scene(60, 32, 32, 30.0, 30.0, seed=21, bg=(0.1, 0.1, 0.1))
+    sc.scales *= 5.0
+    sc.dL_dout_color[:] = (scenes.uniform01(sc.dL_dout_color.size, 78, 21).reshape(sc.dL_dout_color.shape) * 2 - 1)
+    o, g = _run(sc)
+    vis = np.flatnonzero(o.get("radii") > 0)
+
+    def loss(scene):
+        oo, _ = _run(scene, backward=False)
+        return float((oo.get("out_color").astype(np.float64) * scene.dL_dout_color).sum())
+
+    import copy
+    checked = 0
+    for gi in vis[:6]:
+        for name, key, col in (("opacity", "dL_dopacity", 0), ("colors", "dL_dcolor", 1), ("means3D", "dL_dmean3D", 0)):
+            eps = 2e-3
+            a, b = copy.deepcopy(sc), copy.deepcopy(sc)
+            getattr(a, name)[gi, col] += eps
+            getattr(b, name)[gi, col] -= eps
+            fd = (loss(a) - loss(b)) / (2 * eps)
+            an = float(g[key][gi, col])
+            if abs(fd) > 1e-3:
+                assert abs(fd - an) / abs(fd) < 0.05, (name, gi, fd, an)
+                checked += 1
+    assert checked >= 3
