@@ -1,0 +1,124 @@
+/* segs_raster.h -- C ABI of the MI355X-native Gaussian-splatting rasterizer (libsegs_raster.so).
+ *
+ * Drop-in boundary for the hot path of leaner-forever/SEGS-SLAM.  The reference exposes this layer as
+ * C++ static methods over raw pointers plus std::function allocator callbacks
+ * (cuda_rasterizer/rasterizer.h:24-125, class CudaRasterizer::Rasterizer); a C-ABI replacement must be
+ * bindable without C++ types, so each entry point below is that method with
+ *   - std::function<char*(size_t)>  ->  a plain C function pointer + void* context,
+ *   - an explicit stream (the reference uses the legacy default stream),
+ *   - an int status return (0 = ok, <0 = bad argument, >0 = hipError_t) instead of exceptions.
+ * All pointers are DEVICE pointers unless stated otherwise; matrices are the reference's transposed
+ * 4x4 float tensors (src/gaussian_keyframe.cpp:151-184).  No torch types appear in any signature.
+ *
+ * The three scratch buffers (geometry / binning / image) are opaque: obtained through the allocator
+ * callbacks in forward, handed back verbatim to backward, exactly as in the reference
+ * (src/rasterize_points.cu:28-34,71-78,176-178).  Their internal layout is private (csrc/gs_layout.h).
+ */
+#ifndef SEGS_RASTER_H_
+#define SEGS_RASTER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGS_OK 0
+#define SEGS_ERR_INVALID_ARGUMENT (-1)
+#define SEGS_ERR_UNSUPPORTED (-2)
+#define SEGS_ERR_ALLOC (-3)
+
+/* Replaces std::function<char*(size_t)> (cuda_rasterizer/rasterizer.h:37-39): must return a device
+ * buffer of at least `bytes` bytes that stays valid until the matching backward has run. */
+typedef char* (*segs_alloc_fn)(void* ctx, size_t bytes);
+
+/* Human-readable text for the last non-zero status returned on this thread. */
+const char* segs_last_error(void);
+
+/* Scratch sizes (reference: CudaRasterizer::required<GeometryState|ImageState|BinningState>,
+ * cuda_rasterizer/rasterizer_impl.h:66-72).  For callers that pre-allocate instead of using callbacks. */
+size_t segs_geometry_bytes(int P);
+size_t segs_image_bytes(int width, int height);
+size_t segs_binning_bytes(int num_rendered);
+
+/* CudaRasterizer::Rasterizer::forward (cuda_rasterizer/rasterizer.h:36-59, rasterizer_impl.cu:198-336).
+ * Exactly one of (shs | colors_precomp) and one of (scales+rotations | cov3D_precomp) is non-null, as
+ * GaussianRasterizer::forward enforces (src/gaussian_rasterizer.cpp:175-181).  `radii` (P ints) may be
+ * null.  On success *num_rendered receives R (this call synchronises `stream` once to size the binning
+ * buffer, like the reference's cudaMemcpy at rasterizer_impl.cu:281).  P == 0 is legal (R = 0). */
+int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx,
+                           segs_alloc_fn binning_alloc, void* binning_ctx,
+                           segs_alloc_fn image_alloc, void* image_ctx,
+                           int P, int D, int M,
+                           const float* background, int width, int height,
+                           const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, float scale_modifier,
+                           const float* rotations, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                           float tan_fovx, float tan_fovy, int prefiltered,
+                           float* out_color, int* radii, void* stream, int* num_rendered);
+
+/* CudaRasterizer::Rasterizer::backward (cuda_rasterizer/rasterizer.h:80-108, rasterizer_impl.cu:397-490).
+ * Every output row is written by this call (the caller does not have to zero them, unlike the reference's
+ * torch::zeros at src/rasterize_points.cu:149-157).  dL_dconic is (P,2,2); dL_dmean2D is (P,3). */
+int segs_rasterize_backward(int P, int D, int M, int R,
+                            const float* background, int width, int height,
+                            const float* means3D, const float* shs, const float* colors_precomp,
+                            const float* scales, float scale_modifier, const float* rotations,
+                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                            const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                            char* geom_buffer, char* binning_buffer, char* image_buffer,
+                            const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                            float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                            float* dL_dscale, float* dL_drot, void* stream);
+
+/* CudaRasterizer::Rasterizer::visible_filter (cuda_rasterizer/rasterizer.h:62-77, rasterizer_impl.cu:339-393):
+ * radii only.  The reference also allocates geometry and image scratch it never reads; not needed here. */
+int segs_visible_filter(int P, int M, int width, int height, const float* means3D, const float* scales,
+                        float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, float tan_fovx, float tan_fovy,
+                        int prefiltered, int* radii, void* stream);
+
+/* CudaRasterizer::Rasterizer::markVisible (cuda_rasterizer/rasterizer.h:29-34, rasterizer_impl.cu:141-153).
+ * `present` is P bytes (bool). */
+int segs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                      uint8_t* present, void* stream);
+
+/* CudaRasterizer::Rasterizer::project2_image (cuda_rasterizer/rasterizer.h:110-133, rasterizer_impl.cu:494-585):
+ * preprocess only; copies the per-Gaussian pixel centres (P,2) and colours (P,3) out. */
+int segs_project2_image(int P, int D, int M, int width, int height, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales,
+                        float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                        float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* points_image,
+                        int* radii, void* stream);
+
+/* ---- Parity-test support: expand the private scratch into the reference's state arrays
+ * (GeometryState / BinningState / ImageState, cuda_rasterizer/rasterizer_impl.h:30-66). Any output may be null. */
+int segs_debug_unpack_geometry(const char* geom_buffer, int P, const int* radii, float* means2D /*P,2*/,
+                               float* conic_opacity /*P,4*/, float* depths /*P*/, uint32_t* tiles_touched /*P*/,
+                               uint32_t* point_offsets /*P*/, float* rgb /*P,3*/, void* stream);
+int segs_debug_unpack_binning(const char* binning_buffer, int R, int width, int height,
+                              uint64_t* keys_sorted /*R*/, uint32_t* point_list /*R*/, void* stream);
+int segs_debug_unpack_image(const char* image_buffer, int width, int height, uint32_t* ranges /*tiles,2*/,
+                            float* final_T /*H*W*/, uint32_t* n_contrib /*H*W*/, void* stream);
+
+/* Backward of the per-Gaussian stage alone (K12+K13) from caller-supplied dL_dmean2D (P,3) and dL_dconic
+ * (P,2,2): lets a test check it bit-exactly against the oracle. */
+int segs_debug_preprocess_backward(int P, int width, int height, const float* means3D, const int* radii,
+                                   const float* scales, float scale_modifier, const float* rotations,
+                                   const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                   float tan_fovx, float tan_fovy, const float* dL_dmean2D, const float* dL_dconic,
+                                   float* dL_dmean3D, float* dL_dcov3D, float* dL_dscale, float* dL_drot, void* stream);
+
+/* Stand-alone stable radix sort of (u64 key, u32 value) pairs on key bits [0, end_bit) -- the semantics of
+ * cub::DeviceRadixSort::SortPairs as called at rasterizer_impl.cu:303-308.  `temp` must hold
+ * segs_binning_bytes(n) bytes; results land in keys_out / vals_out. */
+int segs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+                    int n, int end_bit, char* temp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGS_RASTER_H_ */

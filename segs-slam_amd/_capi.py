@@ -1,0 +1,78 @@
+"""ctypes binding of libsegs_raster.so (include/segs_raster.h).
+
+The HIP library is the product: there is NO CPU fallback.  If the shared object is missing or a symbol
+is absent, importing/using this module raises immediately (RuntimeError), so a test can never pass on a
+silent fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsegs_raster.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+# name -> (restype, argtypes); every symbol include/segs_raster.h declares
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SYMBOLS = {
+    "segs_last_error": (C.c_char_p, []),
+    "segs_geometry_bytes": (_sz, [_i]),
+    "segs_image_bytes": (_sz, [_i, _i]),
+    "segs_binning_bytes": (_sz, [_i]),
+    "segs_rasterize_forward": (_i, [ALLOC_FN, _vp, ALLOC_FN, _vp, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp,
+                                     _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, C.POINTER(_i)]),
+    "segs_rasterize_backward": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "segs_visible_filter": (_i, [_i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),
+    "segs_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "segs_project2_image": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i,
+                                  _vp, _vp, _vp, _vp]),
+    "segs_debug_unpack_geometry": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "segs_debug_unpack_binning": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "segs_debug_unpack_image": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "segs_debug_preprocess_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
+                                             _vp, _vp, _vp, _vp]),
+    "segs_sort_pairs": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else [])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension must be built (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C segs-slam_amd/csrc). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError as e:  # pragma: no cover
+                raise RuntimeError(f"libsegs_raster.so does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class SegsError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().segs_last_error()
+        raise SegsError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")

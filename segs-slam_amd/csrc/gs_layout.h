@@ -1,0 +1,105 @@
+// gs_layout.h -- HBM layout of the rasterizer's scratch state (host + device).
+//
+// The three scratch buffers are opaque bytes to the caller, exactly as in the reference, where
+// their carve-up is "an internal contract between forward and backward only"
+// (cuda_rasterizer/rasterizer_impl.h:22-73, rasterizer_impl.cu:155-194).  Ours is laid out for
+// MI355X: one 64-byte (= one cache line) record per Gaussian holding everything the tile kernels
+// consume, so that a per-tile gather is exactly one line per instance and can be fetched by scalar
+// (SMEM) loads into SGPRs; compact 16-byte bin records for the instance emitter; 64-byte gradient
+// accumulation rows so that one packed float-atomic wave instruction touches a single line.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace segs {
+
+constexpr int TILE_X = 16;  // cuda_rasterizer/config.h:16
+constexpr int TILE_Y = 16;  // cuda_rasterizer/config.h:17
+constexpr int NUM_CHANNELS = 3;  // cuda_rasterizer/config.h:15
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// Per-Gaussian render record, 16 dwords = 64 B, 64-B aligned.
+//  [0] x  [1] y            pixel-space mean           (reference: GeometryState::means2D)
+//  [2] A2 [3] B2 [4] C2    conic pre-scaled for exp2: A2=-0.5*log2e*A, B2=-log2e*B, C2=-0.5*log2e*C
+//  [5] opacity             (reference: conic_opacity.w)
+//  [6..8] r g b            colour (colors_precomp, or SH->RGB result)
+//  [9..11] A B C           conic as the reference stores it (conic_opacity.xyz)
+//  [12] depth              view-space z (GeometryState::depths)
+//  [13..15] reserved
+constexpr int REC_DWORDS = 16;
+enum RecField { REC_X = 0, REC_Y, REC_A2, REC_B2, REC_C2, REC_O, REC_R, REC_G, REC_B, REC_CA, REC_CB, REC_CC, REC_DEPTH };
+
+// Per-Gaussian bin record (uint4): depth bits, rect_min (x | y<<16), rect_max (x | y<<16), tiles_touched.
+struct BinInfo { uint32_t depth_bits, rect_min, rect_max, tiles_touched; };
+
+// Gradient accumulation row, 16 dwords (64 B): [0,1] dL/dmean2D.xy  [2,3,4] dL/dconic (xx,xy,yy)
+// [5] dL/dopacity  [6,7,8] dL/dcolor.
+constexpr int GACC_DWORDS = 16;
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }
+
+struct GeomLayout {
+  size_t rec, bin, offsets, radii_internal, block_sums, clamped, num_rendered, gacc, total;
+  int P, nblocks;
+};
+// Mirrors GeometryState::fromChunk (rasterizer_impl.cu:155-170) in role, not in layout.
+inline GeomLayout geom_layout(int P) {
+  GeomLayout g{};
+  g.P = P;
+  g.nblocks = (P + 255) / 256;
+  size_t o = 0;
+  g.rec = o;            o = align_up(o + (size_t)P * REC_DWORDS * 4);
+  g.bin = o;            o = align_up(o + (size_t)P * sizeof(BinInfo));
+  g.offsets = o;        o = align_up(o + (size_t)P * 4);
+  g.radii_internal = o; o = align_up(o + (size_t)P * 4);
+  g.block_sums = o;     o = align_up(o + (size_t)(g.nblocks + 1) * 4);
+  g.clamped = o;        o = align_up(o + (size_t)P * 4);  // SH path: 3 clamp flags packed in one word
+  g.num_rendered = o;   o = align_up(o + 64);
+  g.gacc = o;           o = align_up(o + (size_t)P * GACC_DWORDS * 4);
+  g.total = o + ALIGN;  // slack so the base pointer can be aligned up
+  return g;
+}
+
+struct ImageLayout {
+  size_t ranges, final_T, n_contrib, total;
+};
+// Mirrors ImageState::fromChunk (rasterizer_impl.cu:172-179); ranges sized per TILE, not per pixel.
+inline ImageLayout image_layout(int W, int H) {
+  ImageLayout l{};
+  const size_t tiles = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+  size_t o = 0;
+  l.ranges = o;    o = align_up(o + tiles * 8);
+  l.final_T = o;   o = align_up(o + (size_t)W * H * 4);
+  l.n_contrib = o; o = align_up(o + (size_t)W * H * 4);
+  l.total = o + ALIGN;
+  return l;
+}
+
+constexpr int SORT_ITEMS_PER_THREAD = 16;
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_TILE = SORT_ITEMS_PER_THREAD * SORT_THREADS;  // 4096 items per workgroup
+
+struct BinningLayout {
+  size_t keys[2], vals[2], block_hist, digit_totals, total;
+  int R, nblocks;
+};
+// Mirrors BinningState::fromChunk (rasterizer_impl.cu:181-194): ping-pong key/value arrays + sort temp.
+inline BinningLayout binning_layout(int R) {
+  BinningLayout b{};
+  b.R = R;
+  b.nblocks = (R + SORT_TILE - 1) / SORT_TILE;
+  size_t o = 0;
+  for (int i = 0; i < 2; i++) { b.keys[i] = o; o = align_up(o + (size_t)R * 8); }
+  for (int i = 0; i < 2; i++) { b.vals[i] = o; o = align_up(o + (size_t)R * 4); }
+  b.block_hist = o;   o = align_up(o + (size_t)256 * (b.nblocks > 0 ? b.nblocks : 1) * 4);
+  b.digit_totals = o; o = align_up(o + 256 * 4);
+  b.total = o + ALIGN;
+  return b;
+}
+
+inline char* align_ptr(char* p) { return (char*)(((uintptr_t)p + ALIGN - 1) / ALIGN * ALIGN); }
+inline const char* align_ptr(const char* p) { return (const char*)(((uintptr_t)p + ALIGN - 1) / ALIGN * ALIGN); }
+
+}  // namespace segs

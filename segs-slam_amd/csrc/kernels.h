@@ -1,0 +1,61 @@
+// kernels.h -- declarations of the device kernels (defined in preprocess.hip, binning.hip, render.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "gs_layout.h"
+
+namespace segs {
+
+// ---- preprocess.hip
+__global__ void preprocess_fwd_kernel(
+    int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
+    const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ colors,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+    int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy,
+    int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums);
+
+__global__ void visible_filter_kernel(
+    int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, int W, int H,
+    float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy, int* __restrict__ radii);
+
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ viewmatrix,
+                                    uint8_t* __restrict__ present);
+
+__global__ void preprocess_bwd_kernel(
+    int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ scales,
+    const float* __restrict__ rotations, float mod, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ view, const float* __restrict__ proj, float h_x, float h_y, float tan_fovx, float tan_fovy,
+    const float* __restrict__ gacc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot);
+
+// ---- binning.hip
+__global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total);
+__global__ void duplicate_with_keys_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ block_offsets,
+                                           uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
+                                           uint32_t* __restrict__ vals, uint32_t gx);
+__global__ void radix_count_kernel(const uint64_t* __restrict__ keys, int n, int shift, uint32_t* __restrict__ block_hist, int nblocks);
+__global__ void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_totals);
+__global__ void radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
+                                     const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_totals, int nblocks);
+__global__ void identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges);
+
+// ---- render.hip
+__global__ void render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
+                                  const float* __restrict__ rec, const float* __restrict__ bg,
+                                  float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color);
+__global__ void render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
+                                  const float* __restrict__ rec, const float* __restrict__ bg,
+                                  const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                  const float* __restrict__ dL_dpix, float* __restrict__ gacc);
+
+// ---- debug / test support (binning.hip)
+__global__ void unpack_geometry_kernel(int P, const float* __restrict__ rec, const BinInfo* __restrict__ bin,
+                                       const int* __restrict__ radii, float* __restrict__ means2D,
+                                       float* __restrict__ conic_opacity, float* __restrict__ depths,
+                                       uint32_t* __restrict__ tiles_touched, float* __restrict__ rgb);
+
+}  // namespace segs

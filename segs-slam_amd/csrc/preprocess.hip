@@ -1,0 +1,398 @@
+// preprocess.hip -- per-Gaussian kernels of the rasterizer (gfx950 / MI355X).
+//
+//   preprocess_fwd_kernel   K1  reference: preprocessCUDA          cuda_rasterizer/forward.cu:155-256
+//   visible_filter_kernel   K2  reference: filter_preprocessCUDA   cuda_rasterizer/forward.cu:259-334
+//   mark_visible_kernel     K4  reference: checkFrustum            cuda_rasterizer/rasterizer_impl.cu:54-66
+//   preprocess_bwd_kernel   K12+K13 fused; reference: computeCov2DCUDA backward.cu:144-274,
+//                           preprocessCUDA backward.cu:346-396, computeCov3D backward.cu:278-341
+//
+// All are HBM-bound streaming kernels (one Gaussian per lane, 256-thread workgroups):
+//  * the (P,3) AoS inputs are fetched as three fully coalesced dword sweeps per workgroup and
+//    transposed through LDS (stride-3 LDS reads are conflict free), rotations as 16 B/lane;
+//  * everything the tile kernels need is emitted as ONE 64-byte record per Gaussian (gs_layout.h);
+//  * the per-workgroup sum of tiles_touched is produced here so the prefix sum needs no extra pass
+//    over the per-Gaussian data;
+//  * the backward fuses the reference's two kernels and its 108 B/Gaussian of zero-fills (K14): every
+//    output row is written exactly once (zeros for culled Gaussians), cov3D is recomputed instead of
+//    being stored and re-read.
+//
+// Arithmetic: this translation unit is built with -ffp-contract=off and evaluates every expression
+// in the reference's order with one binary32 rounding per operation, so that radii, rects, depths
+// (hence tile/sort keys) are bit-identical to the CPU oracle.  glm semantics: mat3 is column-major,
+// m[c][r] = column c, row r.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "gs_layout.h"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace segs {
+
+struct mat3 { float m[3][3]; };
+
+__device__ __forceinline__ mat3 mk(float a, float b, float c, float d, float e, float f, float g, float h, float i) {
+  mat3 r; r.m[0][0] = a; r.m[0][1] = b; r.m[0][2] = c; r.m[1][0] = d; r.m[1][1] = e; r.m[1][2] = f; r.m[2][0] = g; r.m[2][1] = h; r.m[2][2] = i; return r;
+}
+__device__ __forceinline__ mat3 mul(const mat3& A, const mat3& B) {
+  mat3 R;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+  return R;
+}
+__device__ __forceinline__ mat3 transpose(const mat3& A) {
+  mat3 R;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) R.m[c][r] = A.m[r][c];
+  return R;
+}
+__device__ __forceinline__ mat3 smul(float s, const mat3& A) {
+  mat3 R;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) R.m[c][r] = s * A.m[c][r];
+  return R;
+}
+
+// auxiliary.h:41-45 -- double-literal arithmetic, narrowed on return.
+__device__ __forceinline__ float ndc2Pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+// auxiliary.h:47-57 -- (int) truncation first, then clamp to the tile grid.
+__device__ __forceinline__ void getRect(float px, float py, int max_radius, uint32_t& minx, uint32_t& miny,
+                                        uint32_t& maxx, uint32_t& maxy, uint32_t gx, uint32_t gy) {
+  minx = min(gx, (uint32_t)max(0, (int)((px - max_radius) / TILE_X)));
+  miny = min(gy, (uint32_t)max(0, (int)((py - max_radius) / TILE_Y)));
+  maxx = min(gx, (uint32_t)max(0, (int)((px + max_radius + TILE_X - 1) / TILE_X)));
+  maxy = min(gy, (uint32_t)max(0, (int)((py + max_radius + TILE_Y - 1) / TILE_Y)));
+}
+
+// auxiliary.h:59-78
+__device__ __forceinline__ float3 transformPoint4x3(float3 p, const float* M) {
+  return make_float3(M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12],
+                     M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13],
+                     M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14]);
+}
+__device__ __forceinline__ float4 transformPoint4x4(float3 p, const float* M) {
+  return make_float4(M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12],
+                     M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13],
+                     M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14],
+                     M[3] * p.x + M[7] * p.y + M[11] * p.z + M[15]);
+}
+
+__device__ __forceinline__ mat3 quat_to_R(float4 rot) {  // forward.cu:127-139 (un-normalised, F5b)
+  const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+  return mk(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+            2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+            2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+}
+
+// forward.cu:118-152
+__device__ __forceinline__ void computeCov3D(float3 scale, float mod, float4 rot, float* cov3D) {
+  mat3 S = mk(1, 0, 0, 0, 1, 0, 0, 0, 1);
+  S.m[0][0] = mod * scale.x; S.m[1][1] = mod * scale.y; S.m[2][2] = mod * scale.z;
+  mat3 R = quat_to_R(rot);
+  mat3 M = mul(S, R);
+  mat3 Sigma = mul(transpose(M), M);
+  cov3D[0] = Sigma.m[0][0]; cov3D[1] = Sigma.m[0][1]; cov3D[2] = Sigma.m[0][2];
+  cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
+}
+
+struct Cov2DTerms { mat3 T, W, Vrk; float3 t; float txtz, tytz; };
+
+// forward.cu:74-113 (also the recompute at backward.cu:160-199); returns (a, b, c) with the 0.3 dilation.
+__device__ __forceinline__ float3 computeCov2D(float3 mean, float focal_x, float focal_y, float tan_fovx, float tan_fovy,
+                                               const float* cov3D, const float* view, Cov2DTerms* out) {
+  float3 t = transformPoint4x3(mean, view);
+  const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+  const float txtz = t.x / t.z, tytz = t.y / t.z;
+  t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+  t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+  mat3 J = mk(focal_x / t.z, 0.0f, -(focal_x * t.x) / (t.z * t.z),
+              0.0f, focal_y / t.z, -(focal_y * t.y) / (t.z * t.z),
+              0, 0, 0);
+  mat3 W = mk(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+  mat3 T = mul(W, J);
+  mat3 Vrk = mk(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+  mat3 cov = mul(mul(transpose(T), transpose(Vrk)), T);
+  cov.m[0][0] += 0.3f; cov.m[1][1] += 0.3f;
+  if (out) { out->T = T; out->W = W; out->Vrk = Vrk; out->t = t; out->txtz = txtz; out->tytz = tytz; }
+  return make_float3(cov.m[0][0], cov.m[0][1], cov.m[1][1]);
+}
+
+// Workgroup-coalesced fetch of row `tid` of a (P,3) float array: three dword sweeps + LDS transpose.
+__device__ __forceinline__ float3 load_row3(const float* __restrict__ a, int P, float* lds /*768 floats*/) {
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * 768;
+  const size_t lim = (size_t)P * 3;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const size_t i = base + k * 256 + tid;
+    lds[k * 256 + tid] = i < lim ? a[i] : 0.f;
+  }
+  __syncthreads();
+  float3 v = make_float3(lds[3 * tid], lds[3 * tid + 1], lds[3 * tid + 2]);
+  __syncthreads();
+  return v;
+}
+
+struct Projected {
+  int radius;          // 0 = rejected
+  float depth, px, py; // view z, pixel centre
+  float3 conic;
+  uint32_t minx, miny, maxx, maxy;
+};
+
+// Shared geometry of K1/K2 (forward.cu:185-236 and :282-330).
+__device__ __forceinline__ Projected project_gaussian(float3 p, float3 scale, float mod, float4 rot, const float* cov3D_precomp_row,
+                                                     const float* view, const float* proj, int W, int H, float tan_fovx,
+                                                     float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy) {
+  Projected o; o.radius = 0;
+  float3 p_view = transformPoint4x3(p, view);
+  if (p_view.z <= 0.2f) return o;  // auxiliary.h:155-156 (x/y frustum test removed in this fork)
+  float4 p_hom = transformPoint4x4(p, proj);
+  float p_w = 1.0f / (p_hom.w + 0.0000001f);
+  float3 p_proj = make_float3(p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w);
+  float cov3D[6];
+  if (cov3D_precomp_row) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) cov3D[k] = cov3D_precomp_row[k];
+  } else {
+    computeCov3D(scale, mod, rot, cov3D);
+  }
+  float3 cov = computeCov2D(p, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view, nullptr);
+  float det = (cov.x * cov.z - cov.y * cov.y);
+  if (det == 0.0f) return o;
+  float det_inv = 1.f / det;
+  o.conic = make_float3(cov.z * det_inv, -cov.y * det_inv, cov.x * det_inv);
+  float mid = 0.5f * (cov.x + cov.z);
+  float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+  float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+  float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+  o.px = ndc2Pix(p_proj.x, W); o.py = ndc2Pix(p_proj.y, H);
+  getRect(o.px, o.py, (int)my_radius, o.minx, o.miny, o.maxx, o.maxy, gx, gy);
+  if ((o.maxx - o.minx) * (o.maxy - o.miny) == 0) return o;
+  o.depth = p_view.z;
+  o.radius = (int)my_radius;
+  return o;
+}
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(
+    int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
+    const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ colors,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+    int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy,
+    int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums) {
+  __shared__ float lds[768];
+  __shared__ uint32_t wave_sums[4];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float3 p = load_row3(means3D, P, lds);
+  float3 sc = make_float3(0, 0, 0);
+  float4 rot = make_float4(0, 0, 0, 0);
+  if (scales) {
+    sc = load_row3(scales, P, lds);
+    if (idx < P) rot = reinterpret_cast<const float4*>(rotations)[idx];
+  }
+  const float3 col = load_row3(colors, P, lds);
+
+  uint32_t touched = 0;
+  if (idx < P) {
+    Projected g = project_gaussian(p, sc, mod, rot, cov3D_precomp ? cov3D_precomp + (size_t)6 * idx : nullptr,
+                                   viewmatrix, projmatrix, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy);
+    BinInfo b{0u, 0u, 0u, 0u};
+    if (g.radius > 0) {
+      touched = (g.maxy - g.miny) * (g.maxx - g.minx);
+      b.depth_bits = __float_as_uint(g.depth);
+      b.rect_min = g.minx | (g.miny << 16);
+      b.rect_max = g.maxx | (g.maxy << 16);
+      b.tiles_touched = touched;
+      float4* r4 = reinterpret_cast<float4*>(rec + (size_t)idx * REC_DWORDS);
+      // A2/B2/C2: conic pre-scaled so the tile kernels evaluate alpha = o * exp2(A2 dx^2 + B2 dx dy + C2 dy^2)
+      r4[0] = make_float4(g.px, g.py, (-0.5f * LOG2E) * g.conic.x, (-LOG2E) * g.conic.y);
+      r4[1] = make_float4((-0.5f * LOG2E) * g.conic.z, opacities[idx], col.x, col.y);
+      r4[2] = make_float4(col.z, g.conic.x, g.conic.y, g.conic.z);
+      r4[3] = make_float4(g.depth, 0.f, 0.f, 0.f);
+    }
+    radii[idx] = g.radius;
+    reinterpret_cast<uint4*>(bin)[idx] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
+  }
+  // workgroup sum of tiles_touched -> block_sums[blockIdx] (feeds the prefix sum, K5)
+  uint32_t s = touched;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+}
+
+__global__ void __launch_bounds__(256) visible_filter_kernel(
+    int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, int W, int H,
+    float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy, int* __restrict__ radii) {
+  __shared__ float lds[768];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float3 p = load_row3(means3D, P, lds);
+  float3 sc = make_float3(0, 0, 0);
+  float4 rot = make_float4(0, 0, 0, 0);
+  if (scales) {
+    sc = load_row3(scales, P, lds);
+    if (idx < P) rot = reinterpret_cast<const float4*>(rotations)[idx];
+  }
+  if (idx >= P) return;
+  Projected g = project_gaussian(p, sc, mod, rot, cov3D_precomp ? cov3D_precomp + (size_t)6 * idx : nullptr,
+                                 viewmatrix, projmatrix, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy);
+  radii[idx] = g.radius;
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                           const float* __restrict__ viewmatrix, uint8_t* __restrict__ present) {
+  __shared__ float lds[768];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float3 p = load_row3(means3D, P, lds);
+  if (idx >= P) return;
+  float3 p_view = transformPoint4x3(p, viewmatrix);
+  present[idx] = (p_view.z <= 0.2f) ? 0 : 1;
+}
+
+// Fused K12 + K13.  gacc rows hold the tile kernel's per-Gaussian sums (gs_layout.h); if gacc is null the
+// caller supplied dL_dmean2D / dL_dconic directly (test hook for the bit-exactness check).
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(
+    int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ scales,
+    const float* __restrict__ rotations, float mod, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ view, const float* __restrict__ proj, float h_x, float h_y, float tan_fovx, float tan_fovy,
+    const float* __restrict__ gacc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+  __shared__ float lds[768];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float3 mean = load_row3(means3D, P, lds);
+  float3 scale = make_float3(0, 0, 0);
+  if (scales) scale = load_row3(scales, P, lds);
+  if (idx >= P) return;
+
+  float g2x, g2y, gcx, gcy, gcw;
+  if (gacc) {
+    const float4* a = reinterpret_cast<const float4*>(gacc + (size_t)idx * GACC_DWORDS);
+    const float4 a0 = a[0], a1 = a[1];
+    const float a8 = gacc[(size_t)idx * GACC_DWORDS + 8];
+    g2x = a0.x; g2y = a0.y; gcx = a0.z; gcy = a0.w; gcw = a1.x;
+    const bool vis = radii[idx] > 0;  // rows of culled Gaussians are never touched by the tile kernel (all zero)
+    dL_dmean2D[3 * (size_t)idx + 0] = g2x; dL_dmean2D[3 * (size_t)idx + 1] = g2y; dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+    reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcw);
+    dL_dopacity[idx] = a1.y;
+    dL_dcolor[3 * (size_t)idx + 0] = a1.z; dL_dcolor[3 * (size_t)idx + 1] = a1.w; dL_dcolor[3 * (size_t)idx + 2] = a8;
+    (void)vis;
+  } else {
+    g2x = dL_dmean2D[3 * (size_t)idx + 0]; g2y = dL_dmean2D[3 * (size_t)idx + 1];
+    gcx = dL_dconic[4 * (size_t)idx + 0]; gcy = dL_dconic[4 * (size_t)idx + 1]; gcw = dL_dconic[4 * (size_t)idx + 3];
+  }
+
+  float out_mean[3] = {0, 0, 0}, out_cov[6] = {0, 0, 0, 0, 0, 0}, out_scale[3] = {0, 0, 0}, out_rot[4] = {0, 0, 0, 0};
+  if (radii[idx] > 0) {
+    float4 rot = make_float4(0, 0, 0, 0);
+    float cov3D[6];
+    if (cov3D_precomp) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) cov3D[k] = cov3D_precomp[(size_t)6 * idx + k];
+    } else {
+      rot = reinterpret_cast<const float4*>(rotations)[idx];
+      computeCov3D(scale, mod, rot, cov3D);
+    }
+    // ---- K12: backward.cu:160-273
+    const float3 dL_dconic3 = make_float3(gcx, gcy, gcw);
+    Cov2DTerms q;
+    float3 abc = computeCov2D(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view, &q);
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    const float x_grad_mul = q.txtz < -limx || q.txtz > limx ? 0 : 1;
+    const float y_grad_mul = q.tytz < -limy || q.tytz > limy ? 0 : 1;
+    const mat3& T = q.T; const mat3& Wm = q.W; const mat3& Vrk = q.Vrk; const float3 t = q.t;
+    float a = abc.x, b = abc.y, c = abc.z;
+    float denom = a * c - b * b;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    if (denom2inv != 0) {
+      dL_da = denom2inv * (-c * c * dL_dconic3.x + 2 * b * c * dL_dconic3.y + (denom - a * c) * dL_dconic3.z);
+      dL_dc = denom2inv * (-a * a * dL_dconic3.z + 2 * a * b * dL_dconic3.y + (denom - a * c) * dL_dconic3.x);
+      dL_db = denom2inv * 2 * (b * c * dL_dconic3.x - (denom + 2 * b * b) * dL_dconic3.y + a * b * dL_dconic3.z);
+      out_cov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
+      out_cov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
+      out_cov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
+      out_cov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][1] * dL_dc;
+      out_cov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][2] * dL_dc;
+      out_cov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2 * T.m[1][1] * T.m[1][2] * dL_dc;
+    }
+    float dL_dT00 = 2 * (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_da +
+                    (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_db;
+    float dL_dT01 = 2 * (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_da +
+                    (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_db;
+    float dL_dT02 = 2 * (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_da +
+                    (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_db;
+    float dL_dT10 = 2 * (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc +
+                    (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_db;
+    float dL_dT11 = 2 * (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc +
+                    (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_db;
+    float dL_dT12 = 2 * (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc +
+                    (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_db;
+    float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
+    float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
+    float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
+    float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
+    float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+    // transformVec4x3Transpose (auxiliary.h:90-98)
+    float k12x = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz;
+    float k12y = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz;
+    float k12z = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
+    // ---- K13: backward.cu:370-387
+    float4 m_hom = transformPoint4x4(mean, proj);
+    float m_w = 1.0f / (m_hom.w + 0.0000001f);
+    float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+    float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+    float dmx = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+    float dmy = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+    float dmz = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+    out_mean[0] = k12x + dmx; out_mean[1] = k12y + dmy; out_mean[2] = k12z + dmz;  // "dL_dmeans[idx] += dL_dmean" (:387)
+    // ---- computeCov3D backward: backward.cu:278-341 (no quaternion-normalisation Jacobian, F5b)
+    if (scales) {
+      const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
+      mat3 Rm = quat_to_R(rot);
+      mat3 S = mk(1, 0, 0, 0, 1, 0, 0, 0, 1);
+      const float3 s = make_float3(mod * scale.x, mod * scale.y, mod * scale.z);
+      S.m[0][0] = s.x; S.m[1][1] = s.y; S.m[2][2] = s.z;
+      mat3 M = mul(S, Rm);
+      const float* g = out_cov;
+      mat3 dL_dSigma = mk(g[0], 0.5f * g[1], 0.5f * g[2], 0.5f * g[1], g[3], 0.5f * g[4], 0.5f * g[2], 0.5f * g[4], g[5]);
+      mat3 dL_dM = mul(smul(2.0f, M), dL_dSigma);
+      mat3 Rt = transpose(Rm);
+      mat3 dL_dMt = transpose(dL_dM);
+      out_scale[0] = Rt.m[0][0] * dL_dMt.m[0][0] + Rt.m[0][1] * dL_dMt.m[0][1] + Rt.m[0][2] * dL_dMt.m[0][2];
+      out_scale[1] = Rt.m[1][0] * dL_dMt.m[1][0] + Rt.m[1][1] * dL_dMt.m[1][1] + Rt.m[1][2] * dL_dMt.m[1][2];
+      out_scale[2] = Rt.m[2][0] * dL_dMt.m[2][0] + Rt.m[2][1] * dL_dMt.m[2][1] + Rt.m[2][2] * dL_dMt.m[2][2];
+#pragma unroll
+      for (int k = 0; k < 3; k++) { dL_dMt.m[0][k] *= s.x; dL_dMt.m[1][k] *= s.y; dL_dMt.m[2][k] *= s.z; }
+      out_rot[0] = 2 * z * (dL_dMt.m[0][1] - dL_dMt.m[1][0]) + 2 * y * (dL_dMt.m[2][0] - dL_dMt.m[0][2]) + 2 * x * (dL_dMt.m[1][2] - dL_dMt.m[2][1]);
+      out_rot[1] = 2 * y * (dL_dMt.m[1][0] + dL_dMt.m[0][1]) + 2 * z * (dL_dMt.m[2][0] + dL_dMt.m[0][2]) + 2 * r * (dL_dMt.m[1][2] - dL_dMt.m[2][1]) - 4 * x * (dL_dMt.m[2][2] + dL_dMt.m[1][1]);
+      out_rot[2] = 2 * x * (dL_dMt.m[1][0] + dL_dMt.m[0][1]) + 2 * r * (dL_dMt.m[2][0] - dL_dMt.m[0][2]) + 2 * z * (dL_dMt.m[1][2] + dL_dMt.m[2][1]) - 4 * y * (dL_dMt.m[2][2] + dL_dMt.m[0][0]);
+      out_rot[3] = 2 * r * (dL_dMt.m[0][1] - dL_dMt.m[1][0]) + 2 * x * (dL_dMt.m[2][0] + dL_dMt.m[0][2]) + 2 * y * (dL_dMt.m[1][2] + dL_dMt.m[2][1]) - 4 * z * (dL_dMt.m[1][1] + dL_dMt.m[0][0]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) dL_dmean3D[3 * (size_t)idx + k] = out_mean[k];
+#pragma unroll
+  for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = out_cov[k];
+  if (dL_dscale) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) dL_dscale[3 * (size_t)idx + k] = out_scale[k];
+  }
+  if (dL_drot) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(out_rot[0], out_rot[1], out_rot[2], out_rot[3]);
+}
+
+}  // namespace segs

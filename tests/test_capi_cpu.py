@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol
+that include/segs_raster.h declares (no compute calls without a GPU), and the host mirror fails loudly
+instead of falling back to a CPU path."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "segs_raster.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(segs_[a-z0-9_]+)\s*\(", text)) - {"segs_alloc_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    from segs_slam_amd import _capi
+    _capi.build()
+    lib = _capi.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), name
+        assert name in _capi.SYMBOLS, f"{name} has no ctypes prototype"
+    assert sorted(_capi.SYMBOLS) == declared
+
+
+def test_scratch_size_queries_are_monotone_and_aligned():
+    from segs_slam_amd import _capi
+    lib = _capi.lib()
+    prev = 0
+    for P in (0, 1, 255, 256, 257, 50_000, 3_000_000):
+        b = lib.segs_geometry_bytes(P)
+        assert b >= prev and b % 256 == 0
+        prev = b
+    assert lib.segs_image_bytes(1920, 1080) > 2 * 4 * 1920 * 1080
+    assert lib.segs_binning_bytes(10_000_000) > 10_000_000 * 24
+
+
+def test_no_cpu_fallback():
+    from segs_slam_amd import rasterize_points as rp
+    e = torch.empty(0)
+    with pytest.raises(RuntimeError, match="GPU"):
+        rp.RasterizeGaussiansCUDA(torch.zeros(3), torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 1), torch.zeros(4, 3),
+                                  torch.zeros(4, 4), 1.0, e, torch.eye(4), torch.eye(4), 1.0, 1.0, 16, 16, e, 0, torch.zeros(3), False)
+    with pytest.raises(RuntimeError):
+        rp.RasterizeGaussiansCUDA(e, torch.zeros(4, 2), e, e, e, e, 1.0, e, e, e, 1.0, 1.0, 8, 8, e, 0, e, False)
+
+
+def test_camera_tensors_match_reference_logger_dump():
+    """Known-answer data: keyframes printed by GaussianKeyframe::logger (src/gaussian_keyframe.cpp:293-302) that the
+    reference ships in check_colmap.md; extracted to tests/golden/check_colmap_keyframes.json by
+    tests/golden/extract_check_colmap.py.  Pins the layout/convention of view / proj / full_proj / campos."""
+    import json
+    import numpy as np
+    from segs_slam_amd import scenes
+    data = json.load(open(os.path.join(ROOT, "tests", "golden", "check_colmap_keyframes.json")))
+    assert len(data) >= 5
+    for kf in data:
+        wvt = np.array(kf["world_view_transform"], dtype=np.float32)
+        proj = scenes.projection_matrix(0.01, 100.0, kf["FoVx"], kf["FoVy"]).T
+        assert np.allclose(proj, np.array(kf["projection_matrix"]), atol=6e-5 * max(1.0, np.abs(proj).max()))
+        full = wvt @ proj
+        assert np.allclose(full, np.array(kf["full_proj_transform"]), atol=2e-3)
+        center = np.linalg.inv(wvt)[3, :3]
+        assert np.allclose(center, np.array(kf["camera_center"]), atol=2e-3)

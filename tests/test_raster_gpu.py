@@ -1,0 +1,267 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI via the
+reference-shaped wrappers, against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): bit-exact on every integer / index product of binning (radii,
+tiles_touched, point_offsets, sort keys, point_list, ranges) and on the per-Gaussian floats that feed
+them; <= 1e-4 relative on rendered RGB and gradients.
+
+Tolerances, stated once:
+  * per-Gaussian forward floats (means2D, depth, conic): exact (same expression order, no contraction).
+  * image / final_T: |gpu - ref| <= 1e-4 * |ref| + 2e-6 on pixels whose compositing decisions are not
+    within 1e-5 (relative) of a threshold (power>0, alpha<1/255, T<1e-4) -- v_exp_f32 and glibc expf differ
+    in the last bits, so a decision that close to its threshold may legitimately flip; such pixels are
+    reported by the oracle (gso_unstable_pixels) and must be < 1 % of the image.
+  * gradients: dL_dout_color is zeroed on those pixels for BOTH sides, then
+    |gpu - ref| <= 1e-4 * |ref| + 1e-5 * max|ref| per tensor (float atomics sum in arbitrary order; the
+    oracle sums in double).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gs_oracle
+from segs_slam_amd import scenes
+from tests.test_oracle import check_binning_invariants
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, dtype)
+
+
+def gpu_forward(sc):
+    from segs_slam_amd import rasterize_points as rp
+    cam = sc.camera
+    e = torch.empty(0, device=DEV)
+    args = dict(bg=_t(sc.bg), means3D=_t(sc.means3D), colors=_t(sc.colors), opacity=_t(sc.opacity), scales=_t(sc.scales),
+                rotations=_t(sc.rotations), view=_t(cam.world_view_transform), proj=_t(cam.full_proj_transform),
+                campos=_t(cam.camera_center))
+    R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(
+        args["bg"], args["means3D"], args["colors"], args["opacity"], args["scales"], args["rotations"], sc.scale_modifier,
+        e, args["view"], args["proj"], cam.tanfovx, cam.tanfovy, cam.height, cam.width, e, 0, args["campos"], False)
+    return args, (R, color, radii, geom, binning, img)
+
+
+def gpu_backward(sc, args, fwd, dL):
+    from segs_slam_amd import rasterize_points as rp
+    cam = sc.camera
+    e = torch.empty(0, device=DEV)
+    R, color, radii, geom, binning, img = fwd
+    out = rp.RasterizeGaussiansBackwardCUDA(args["bg"], args["means3D"], radii, args["colors"], args["scales"],
+                                            args["rotations"], sc.scale_modifier, e, args["view"], args["proj"],
+                                            cam.tanfovx, cam.tanfovy, _t(dL), e, 0, args["campos"], geom, R, binning, img)
+    names = ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot")
+    return {k: v.cpu().numpy() for k, v in zip(names, out)}
+
+
+def gpu_state(sc, fwd):
+    from segs_slam_amd import rasterize_points as rp
+    R, color, radii, geom, binning, img = fwd
+    st = rp.debug_state(sc.P, sc.camera.width, sc.camera.height, R, radii, geom, binning, img)
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in st.items()}
+    out["tiles_touched"] = out["tiles_touched"].view(np.uint32)
+    out["point_offsets"] = out["point_offsets"].view(np.uint32)
+    out["keys"] = out["keys"].view(np.uint64)
+    out["point_list"] = out["point_list"].view(np.uint32)
+    out["ranges"] = out["ranges"].view(np.uint32)
+    out["n_contrib"] = out["n_contrib"].view(np.uint32)
+    out["radii"] = radii.cpu().numpy()
+    out["out_color"] = color.cpu().numpy()
+    return out
+
+
+def assert_forward_parity(sc, o, g, R):
+    assert R == o.R
+    for k in ("radii", "tiles_touched", "point_offsets", "keys", "point_list", "ranges"):
+        assert np.array_equal(g[k], o.get(k)), k
+    for k in ("means2D", "depths", "conic_opacity"):
+        assert np.array_equal(g[k].view(np.uint32), o.get(k).view(np.uint32)), k
+    unstable = o.unstable_pixels(1e-5)
+    assert unstable.mean() < 0.01
+    ok = ~unstable
+    assert np.array_equal(g["n_contrib"][ok], o.get("n_contrib")[ok])
+    for name, a, b in (("final_T", g["final_T"], o.get("final_T")),):
+        assert np.all(np.abs(a - b)[ok] <= 1e-4 * np.abs(b)[ok] + 2e-6), name
+    a, b = g["out_color"], o.get("out_color")
+    err = np.abs(a - b)[:, ok]
+    assert np.all(err <= 1e-4 * np.abs(b)[:, ok] + 2e-6), float(err.max())
+    return unstable
+
+
+def assert_grad_close(name, a, b):
+    tol = 1e-4 * np.abs(b) + 1e-5 * (np.abs(b).max() + 1e-30)
+    bad = np.abs(a - b) > tol
+    assert not bad.any(), (name, int(bad.sum()), float(np.abs(a - b).max()), float(np.abs(b).max()))
+
+
+def run_parity(sc, backward=True):
+    o, _ = gs_oracle.run_scene(sc, backward=False)
+    args, fwd = gpu_forward(sc)
+    g = gpu_state(sc, fwd)
+    unstable = assert_forward_parity(sc, o, g, fwd[0])
+    if sc.P:
+        check_binning_invariants(sc.P, sc.camera.width, sc.camera.height, g["radii"], g["means2D"], g["depths"],
+                                 g["tiles_touched"], g["point_offsets"], g["keys"], g["point_list"], g["ranges"], fwd[0],
+                                 o.sort_bits)
+    if backward:
+        dL = sc.dL_dout_color.copy()
+        dL[:, unstable] = 0.0
+        ref = o.backward(dL)
+        got = gpu_backward(sc, args, fwd, dL)
+        for k in ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot"):
+            assert_grad_close(k, got[k].reshape(ref[k].shape), ref[k])
+    return o, g
+
+
+@pytest.mark.parametrize("P,W,H,bg", [(1000, 64, 64, (0.1, 0.2, 0.3)), (17, 33, 17, (0, 0, 0)), (5000, 200, 120, (1, 1, 1)),
+                                      (1, 16, 16, (0, 0, 0))])
+def test_small_scenes(P, W, H, bg):
+    sc = scenes.make_scene(P, W, H, 0.9 * W, 0.9 * W, seed=4000 + P, bg=bg)
+    sc.scales *= 3.0
+    sc.dL_dout_color[:] = (scenes.uniform01(sc.dL_dout_color.size, 55, P).reshape(sc.dL_dout_color.shape) * 2 - 1)
+    run_parity(sc)
+
+
+def test_config1_50k_640x480():
+    """BASELINE.json configs[0]: 50k Gaussians, 640x480 (forward + backward here)."""
+    sc = scenes.make_config_scene("c1")
+    o, g = run_parity(sc)
+    assert 100_000 < o.R < 250_000
+
+
+def test_degenerate_inputs():
+    from segs_slam_amd import rasterize_points as rp
+    e = torch.empty(0, device=DEV)
+    # P = 0: the tensor-level entry short-circuits like the reference (zero image, R = 0)
+    sc = scenes.make_scene(0, 32, 32, 30.0, 30.0, bg=(0.5, 0.25, 0.125))
+    args, fwd = gpu_forward(sc)
+    assert fwd[0] == 0 and float(fwd[1].abs().max()) == 0.0
+    grads = gpu_backward(sc, args, fwd, sc.dL_dout_color)
+    assert all(v.size == 0 or np.all(v == 0) for v in grads.values())
+    # all culled -> R = 0, image = background
+    sc = scenes.make_scene(64, 40, 24, 30.0, 30.0, seed=3, bg=(0.5, 0.25, 0.125))
+    sc.means3D[:, 2] = 0.1
+    o, g = run_parity(sc)
+    assert o.R == 0 and np.allclose(g["out_color"][0], 0.5)
+    # alpha < 1/255 everywhere
+    sc = scenes.make_scene(200, 48, 48, 40.0, 40.0, seed=4, bg=(0.3, 0.3, 0.3))
+    sc.opacity[:] = 0.003
+    o, g = run_parity(sc)
+    assert np.all(g["n_contrib"] == 0)
+    # one Gaussian spanning the whole non-multiple-of-16 image
+    sc = scenes.make_scene(1, 50, 35, 40.0, 40.0, seed=6)
+    sc.means3D[:] = [0, 0, 1.0]
+    sc.scales[:] = 2.0
+    o, g = run_parity(sc)
+    assert o.R == 12
+    # bad rank -> RuntimeError like AT_ERROR (rasterize_points.cu:57-59)
+    with pytest.raises(RuntimeError):
+        rp.RasterizeGaussiansCUDA(e, torch.zeros(4, 2, device=DEV), e, e, e, e, 1.0, e, e, e, 1.0, 1.0, 8, 8, e, 0, e, False)
+
+
+def test_preprocess_backward_bit_exact():
+    """K12+K13 alone, fed the oracle's dL_dmean2D / dL_dconic: results must be bit-identical."""
+    import ctypes as C
+    from segs_slam_amd import _capi
+    sc = scenes.make_scene(4000, 128, 96, 100.0, 100.0, seed=77, bg=(0.2, 0.2, 0.2))
+    sc.scales *= 3.0
+    o, ref = gs_oracle.run_scene(sc)
+    cam = sc.camera
+    P = sc.P
+    m3, sca, rot = _t(sc.means3D), _t(sc.scales), _t(sc.rotations)
+    view, proj = _t(cam.world_view_transform), _t(cam.full_proj_transform)
+    radii = _t(o.get("radii"), torch.int32)
+    d2, dc = _t(ref["dL_dmean2D"]), _t(ref["dL_dconic"])
+    outs = [torch.empty((P, n), device=DEV) for n in (3, 6, 3, 4)]
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st = _capi.lib().segs_debug_preprocess_backward(P, cam.width, cam.height, p(m3), p(radii), p(sca), 1.0, p(rot), None,
+                                                    p(view), p(proj), cam.tanfovx, cam.tanfovy, p(d2), p(dc),
+                                                    *[p(t) for t in outs], C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _capi.check(st, "segs_debug_preprocess_backward")
+    torch.cuda.synchronize()
+    ref2 = o.backward(sc.dL_dout_color, ref["dL_dmean2D"], ref["dL_dconic"])
+    for t, k in zip(outs, ("dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot")):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), ref2[k].view(np.uint32)), k
+
+
+@pytest.mark.parametrize("n,end_bit", [(1, 44), (63, 40), (4096, 44), (4097, 45), (100_000, 44), (1_000_003, 48), (5000, 7)])
+def test_sort_pairs(n, end_bit):
+    """Stable LSD radix sort on key bits [0,end_bit) == numpy stable argsort of the masked keys."""
+    import ctypes as C
+    from segs_slam_amd import _capi
+    rng = np.random.default_rng(n)
+    # skewed keys: few distinct tile ids / exponent bytes, many ties
+    keys = (rng.integers(0, 3000, n, dtype=np.uint64) << np.uint64(32)) | \
+           (rng.integers(0x3E000000, 0x40C00000, n, dtype=np.uint64) & np.uint64(0xFFFFF000))
+    vals = np.arange(n, dtype=np.uint32)
+    mask = np.uint64((1 << end_bit) - 1)
+    order = np.argsort(keys & mask, kind="stable")
+    k_in, v_in = _t(keys.view(np.int64), torch.int64), _t(vals.view(np.int32), torch.int32)
+    k_out, v_out = torch.empty_like(k_in), torch.empty_like(v_in)
+    l = _capi.lib()
+    temp = torch.empty(l.segs_binning_bytes(n), dtype=torch.uint8, device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _capi.check(l.segs_sort_pairs(p(k_in), p(v_in), p(k_out), p(v_out), n, end_bit, p(temp),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "segs_sort_pairs")
+    torch.cuda.synchronize()
+    assert np.array_equal(v_out.cpu().numpy().view(np.uint32), vals[order])
+    assert np.array_equal(k_out.cpu().numpy().view(np.uint64), keys[order])
+
+
+def test_visible_filter_and_mark_visible():
+    from segs_slam_amd import rasterize_points as rp
+    sc = scenes.make_scene(30_000, 320, 240, 250.0, 260.0, seed=31)
+    cam = sc.camera
+    e = torch.empty(0, device=DEV)
+    radii = rp.RasterizeGaussiansfilterCUDA(_t(sc.means3D), _t(sc.scales), _t(sc.rotations), 1.0, e,
+                                            _t(cam.world_view_transform), _t(cam.full_proj_transform), cam.tanfovx,
+                                            cam.tanfovy, cam.height, cam.width, False, False)
+    ref = gs_oracle.visible_filter(sc.means3D, sc.scales, sc.rotations, 1.0, cam.world_view_transform,
+                                   cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.height, cam.width)
+    assert np.array_equal(radii.cpu().numpy(), ref)
+    pres = rp.markVisible(_t(sc.means3D), _t(cam.world_view_transform), _t(cam.full_proj_transform))
+    assert np.array_equal(pres.cpu().numpy(), gs_oracle.mark_visible(sc.means3D, cam.world_view_transform, cam.full_proj_transform))
+    # strided scales view (exp(_scaling)[:, :3] of an (A,6) tensor, src/gaussian_renderer.cpp:166-170) is accepted
+    wide = torch.cat([_t(sc.scales), _t(sc.scales) * 2], dim=1)
+    radii2 = rp.RasterizeGaussiansfilterCUDA(_t(sc.means3D), wide[:, :3], _t(sc.rotations), 1.0, e,
+                                             _t(cam.world_view_transform), _t(cam.full_proj_transform), cam.tanfovx,
+                                             cam.tanfovy, cam.height, cam.width, False, False)
+    assert torch.equal(radii, radii2)
+
+
+def test_autograd_module_matches_oracle():
+    """GaussianRasterizer module (include/gaussian_rasterizer.h) end to end through autograd."""
+    from segs_slam_amd.gaussian_rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    sc = scenes.make_scene(3000, 96, 80, 80.0, 80.0, seed=91, bg=(0.1, 0.0, 0.2))
+    sc.scales *= 3.0
+    cam = sc.camera
+    o, _ = gs_oracle.run_scene(sc, backward=False)
+    unstable = o.unstable_pixels(1e-5)
+    dL = (scenes.uniform01(sc.dL_dout_color.size, 56, 91).reshape(sc.dL_dout_color.shape) * 2 - 1).astype(np.float32)
+    dL[:, unstable] = 0
+    ref = o.backward(dL)
+    bg = _t(sc.bg)
+    view, proj, campos = _t(cam.world_view_transform), _t(cam.full_proj_transform), _t(cam.camera_center)
+    rs = GaussianRasterizationSettings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, bg, 1.0, view, proj, 0, campos, False)
+    rast = GaussianRasterizer(rs)
+    leaf = lambda a: _t(a).requires_grad_(True)  # noqa: E731
+    m3, op, sca, rot = leaf(sc.means3D), leaf(sc.opacity), leaf(sc.scales), leaf(sc.rotations)
+    # colours arrive as a strided view of a wider tensor (src/gaussian_renderer.cpp:319-324)
+    wide = torch.cat([_t(sc.colors), torch.zeros(sc.P, 19, device=DEV)], dim=1).requires_grad_(True)
+    col = wide[:, :3]
+    means2D = torch.zeros_like(m3, requires_grad=True)
+    img, radii = rast(m3, means2D, op, False, True, True, True, False, colors_precomp=col, scales=sca, rotations=rot)
+    (img * _t(dL)).sum().backward()
+    assert np.array_equal(radii.cpu().numpy(), o.get("radii"))
+    assert_grad_close("means3D", m3.grad.cpu().numpy(), ref["dL_dmean3D"])
+    assert_grad_close("means2D", means2D.grad.cpu().numpy(), ref["dL_dmean2D"])
+    assert_grad_close("opacity", op.grad.cpu().numpy(), ref["dL_dopacity"])
+    assert_grad_close("scales", sca.grad.cpu().numpy(), ref["dL_dscale"])
+    assert_grad_close("rotations", rot.grad.cpu().numpy(), ref["dL_drot"])
+    assert_grad_close("colors", wide.grad[:, :3].cpu().numpy(), ref["dL_dcolor"])
+    with pytest.raises(RuntimeError):
+        rast(m3, means2D, op, True, True, True, True, False, colors_precomp=col, scales=sca, rotations=rot)
