@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- mapper train-iteration throughput of the rasterizer hot path on MI355X.
+
+One "step" = one pass of the hot path over one keyframe of synthetic input, inputs resident in HBM:
+  forward raster (preprocess, scan, duplicate, radix sort, ranges, render)  ->  backward raster
+  (tile backward, fused per-Gaussian backward) with a fixed dL/dimage  [-> RCCL all-reduce of the
+  Gaussian-parameter gradients when N > 1: keyframe-parallel training, one keyframe per GPU].
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run)
+prints ONE JSON line on rank 0.  `value` = keyframe-iterations per second over all N GPUs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def algorithmic_bytes(P, P_vis, R, W, H, passes):
+    """algorithmic bytes per kernel of one fwd+bwd raster."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    return {
+        "preprocess_fwd_kernel": 104 * P_vis + 8 * (P - P_vis),
+        "scan_block_sums_kernel": 8 * P,
+        "duplicate_with_keys_kernel": 20 * P + 12 * R,
+        "radix_sort(all passes)": (8 + 24 * passes) * R,
+        "identify_tile_ranges_kernel": 8 * R + 8 * T,
+        "render_fwd_kernel": 40 * R + 20 * W * H,
+        "render_bwd_kernel": 40 * R + 20 * W * H + 36 * R,
+        "preprocess_bwd_kernel": (92 + 132 + 108) * P,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c2_1080p", help="scene config name (segs_slam_amd.scenes.CONFIGS)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from segs_slam_amd import scenes
+    from segs_slam_amd.raster_engine import KernelProfile, RasterEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP extension has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- workload: same Gaussians on every rank, one keyframe (camera pose) per rank
+    sc = scenes.make_config_scene(args.workload, keyframe=rank)
+    cam = sc.camera
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    bg, m3, col, op, sca, rot = t(sc.bg), t(sc.means3D), t(sc.colors), t(sc.opacity), t(sc.scales), t(sc.rotations)
+    view, proj, campos = t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center)
+    dL = t(sc.dL_dout_color)
+    eng = RasterEngine(sc.P, cam.width, cam.height, dev)
+
+    def step():
+        eng.forward(bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy)
+        eng.backward(dL)
+        if world > 1:
+            dist.all_reduce(eng.grads_flat)  # sum of per-keyframe parameter gradients over xGMI (RCCL)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup; the per-kernel breakdown (all kernels, HIP events) is taken on the warmup steps
+    with KernelProfile() as prof_all:
+        for _ in range(max(args.warmup, 1)):
+            step()
+        torch.cuda.synchronize()
+    breakdown = prof_all.result
+    sort_names = ("radix_count_kernel", "radix_scan_kernel", "radix_scatter_kernel")
+    per_step = {k: v["total_ms"] / max(args.warmup, 1) for k, v in breakdown.items()}
+    dominant = max((k for k in per_step if k != "memset"), key=lambda k: per_step[k])
+
+    # ---- timed region: exactly K steps, barrier + sync on both sides; the dominant kernel is timed live
+    # with HIP events on its launch stream inside this region
+    fence()
+    with KernelProfile([dominant]) as prof_dom:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        R = eng.R
+        P_vis = int((eng.radii > 0).sum().item())
+        gx, gy = (cam.width + 15) // 16, (cam.height + 15) // 16
+        bit = max(1, int(gx * gy).bit_length())
+        passes = (32 + bit + 7) // 8
+        ab = algorithmic_bytes(sc.P, P_vis, R, cam.width, cam.height, passes)
+        dom = prof_dom.result[dominant]
+        dom_bytes = ab[dominant] if dominant in ab else ab["radix_sort(all passes)"] / (3 * passes)
+        achieved = dom_bytes / (dom["avg_ms"] * 1e-3) / 1e9
+        total_bytes = sum(ab.values())
+        ms_per_step = elapsed / args.steps * 1e3
+        raster_ms = sum(v for k, v in per_step.items())
+        out = {
+            "metric": "mapper train-iters/sec (fwd+bwd raster)",
+            "value": world * args.steps / elapsed,
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {sc.P} Gaussians, {cam.width}x{cam.height}, 1 keyframe per GPU, "
+                                   "fwd+bwd raster" + (", RCCL all-reduce of parameter grads" if world > 1 else ""),
+                       "P": sc.P, "P_visible": P_vis, "num_rendered": R, "width": cam.width, "height": cam.height,
+                       "sort_passes": passes, "parallelism": f"keyframe-dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+                         "note": "tile kernels are VALU-bound, not HBM-bound (SURVEY 8d); see DESIGN.md"},
+            "raster": {"algorithmic_bytes": total_bytes, "kernel_ms_sum": raster_ms,
+                       "achieved_GBps": total_bytes / (raster_ms * 1e-3) / 1e9,
+                       "kernel_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+                       "radix_sort_ms": round(sum(per_step.get(k, 0.0) for k in sort_names), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc)
+        if args.breakdown:
+            for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]):
+                print(f"  {k:32s} {v:8.4f} ms/step", file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc):
+    """The CPU oracle (a port of the reference algorithm; the reference has no CPU raster path)
+    timed on this host: ONE fwd+bwd iteration of the same workload (bounded sample)."""
+    from oracle import gs_oracle
+    cam = sc.camera
+    o = gs_oracle.Oracle()
+    t0 = time.perf_counter()
+    o.forward(sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, sc.scale_modifier, sc.rotations,
+              cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.height, cam.width)
+    t1 = time.perf_counter()
+    o.backward(sc.dL_dout_color)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "iters/s", "cores": int(gs_oracle.lib().gso_threads()), "kind": "port",
+            "sample": f"1 fwd+bwd iteration of the same scene (fwd {t1 - t0:.2f} s, bwd {t2 - t1:.2f} s), OpenMP oracle",
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

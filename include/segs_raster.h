@@ -118,6 +118,16 @@ int segs_debug_preprocess_backward(int P, int width, int height, const float* me
 int segs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                     int n, int end_bit, char* temp, void* stream);
 
+/* ---- Measurement support (bench.py): per-kernel timing with HIP events recorded on the launch stream.
+ * kernel_mask bit i selects kernel id i (ids 0..segs_profile_kernel_count()-1, names via
+ * segs_profile_kernel_name).  segs_profile_end() synchronises the recorded events and accumulates;
+ * segs_profile_query() then returns total milliseconds and launch count per kernel id. */
+int segs_profile_begin(unsigned kernel_mask);
+int segs_profile_end(void);
+int segs_profile_kernel_count(void);
+const char* segs_profile_kernel_name(int id);
+int segs_profile_query(int id, double* total_ms, long* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,11 @@ SYMBOLS = {
     "segs_debug_preprocess_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                                              _vp, _vp, _vp, _vp]),
     "segs_sort_pairs": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "segs_profile_begin": (_i, [C.c_uint]),
+    "segs_profile_end": (_i, []),
+    "segs_profile_kernel_count": (_i, []),
+    "segs_profile_kernel_name": (C.c_char_p, [_i]),
+    "segs_profile_query": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
 }
 
 _lib = None

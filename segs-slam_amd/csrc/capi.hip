@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 #include "../../include/segs_raster.h"
 #include "gs_layout.h"
 #include "kernels.h"
@@ -37,6 +38,37 @@ int hip_fail(hipError_t e, const char* where) {
     if (_e != hipSuccess) return hip_fail(_e, name);    \
   } while (0)
 
+// ---- measurement support: per-kernel HIP-event timing on the launch stream (segs_profile_*) ----
+enum KernelId { K_PREPROCESS_FWD = 0, K_SCAN, K_DUPLICATE, K_RADIX_COUNT, K_RADIX_SCAN, K_RADIX_SCATTER, K_RANGES,
+                K_RENDER_FWD, K_RENDER_BWD, K_PREPROCESS_BWD, K_MEMSET, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"preprocess_fwd_kernel", "scan_block_sums_kernel", "duplicate_with_keys_kernel",
+                                           "radix_count_kernel", "radix_scan_kernel", "radix_scatter_kernel",
+                                           "identify_tile_ranges_kernel", "render_fwd_kernel", "render_bwd_kernel",
+                                           "preprocess_bwd_kernel", "memset"};
+struct Profiler {
+  unsigned mask = 0;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  struct Span { int id; size_t e0, e1; };
+  std::vector<Span> spans;
+  double total_ms[K_COUNT] = {0};
+  long count[K_COUNT] = {0};
+  hipEvent_t get() {
+    if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+    return pool[used++];
+  }
+} g_prof;
+struct ProfScope {
+  int id; hipStream_t st; size_t e0 = 0; bool on;
+  ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on((g_prof.mask >> id_) & 1u) {
+    if (on) { e0 = g_prof.used; hipEvent_t e = g_prof.get(); if (e) (void)hipEventRecord(e, st); else on = false; }
+  }
+  ~ProfScope() {
+    if (on) { size_t e1 = g_prof.used; hipEvent_t e = g_prof.get(); if (e) { (void)hipEventRecord(e, st); g_prof.spans.push_back({id, e0, e1}); } }
+  }
+};
+#define PROF(id) ProfScope _prof_scope_##id(id, st)
+
 // rasterizer_impl.cu:35-50
 uint32_t getHigherMsb(uint32_t n) {
   uint32_t msb = sizeof(n) * 4, step = msb;
@@ -62,11 +94,17 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, hipStream_
     uint64_t* kout = (uint64_t*)(bin + L.keys[side ^ 1]);
     uint32_t* vout = (uint32_t*)(bin + L.vals[side ^ 1]);
     const int shift = 8 * p;
+    { PROF(K_RADIX_COUNT);
     radix_count_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, block_hist, L.nblocks);
+    }
     LAUNCH_TRY("radix_count_kernel");
+    { PROF(K_RADIX_SCAN);
     radix_scan_kernel<<<256, 256, 0, st>>>(block_hist, L.nblocks, digit_totals);
+    }
     LAUNCH_TRY("radix_scan_kernel");
+    { PROF(K_RADIX_SCATTER);
     radix_scatter_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, block_hist, digit_totals, L.nblocks);
+    }
     LAUNCH_TRY("radix_scatter_kernel");
     side ^= 1;
   }
@@ -92,9 +130,11 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
   const float focal_y = H / (2.0f * tan_fovy);   // rasterizer_impl.cu:221-222
   const float focal_x = W / (2.0f * tan_fovx);
   const uint32_t gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
+  { PROF(K_PREPROCESS_FWD);
   preprocess_fwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, scales, mod, rots, opac, colors, cov3D_precomp, view,
                                                      proj, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, radii,
                                                      G.rec(), G.bin(), G.block_sums());
+  }
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
 }
@@ -144,7 +184,9 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
     int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales,
                             scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, st);
     if (rc) return rc;
+    { PROF(K_SCAN);
     scan_block_sums_kernel<<<1, 1024, 0, st>>>(G.block_sums(), G.L.nblocks, G.num_rendered());
+    }
     LAUNCH_TRY("scan_block_sums_kernel");
     HIP_TRY(hipMemcpyAsync(&R, G.num_rendered(), sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -156,25 +198,33 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   char* bin = align_ptr(bin_raw);
 
   uint2* ranges = (uint2*)(img + IL.ranges);
+  { PROF(K_MEMSET);
   HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)gx * gy * sizeof(uint2), st));   // rasterizer_impl.cu:310
+  }
   if (R > 0) {
     const int bit = (int)getHigherMsb(gx * gy);
     const int end_bit = 32 + bit;
     const int passes = (end_bit + 7) / 8;
     const int side = passes & 1;
+    { PROF(K_DUPLICATE);
     duplicate_with_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), G.block_sums(), G.offsets(),
                                                             (uint64_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx);
+    }
     LAUNCH_TRY("duplicate_with_keys_kernel");
     int rc = sort_pairs(bin, BL, R, end_bit, st);
     if (rc) return rc;
+    { PROF(K_RANGES);
     identify_tile_ranges_kernel<<<(R + 255) / 256, 256, 0, st>>>(R, (const uint64_t*)(bin + BL.keys[0]), ranges);
+    }
     LAUNCH_TRY("identify_tile_ranges_kernel");
   } else if (P > 0) {
     // still materialise point_offsets (all zero) for parity with GeometryState::point_offsets
     HIP_TRY(hipMemsetAsync(G.offsets(), 0, (size_t)P * 4, st));
   }
+  { PROF(K_RENDER_FWD);
   render_fwd_kernel<<<dim3(gx, gy), 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(),
                                                   background, (float*)(img + IL.final_T), (uint32_t*)(img + IL.n_contrib), out_color);
+  }
   LAUNCH_TRY("render_fwd_kernel");
   *num_rendered = R;
   return SEGS_OK;
@@ -207,17 +257,23 @@ int segs_rasterize_backward(int P, int D, int M, int R, const float* background,
   const uint32_t gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
   const float focal_y = height / (2.0f * tan_fovy), focal_x = width / (2.0f * tan_fovx);  // rasterizer_impl.cu:436-437
 
+  { PROF(K_MEMSET);
   HIP_TRY(hipMemsetAsync(G.gacc(), 0, (size_t)P * GACC_DWORDS * 4, st));
+  }
   if (R > 0) {
+    { PROF(K_RENDER_BWD);
     render_bwd_kernel<<<dim3(gx, gy), 256, 0, st>>>((const uint2*)(img + IL.ranges), (const uint32_t*)(bin + BL.vals[0]), width,
                                                     height, G.rec(), background, (const float*)(img + IL.final_T),
                                                     (const uint32_t*)(img + IL.n_contrib), dL_dpix, G.gacc());
+    }
     LAUNCH_TRY("render_bwd_kernel");
   }
+  { PROF(K_PREPROCESS_BWD);
   preprocess_bwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, radii, cov3D_precomp ? nullptr : scales, rotations,
                                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
                                                      tan_fovx, tan_fovy, G.gacc(), dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
                                                      dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot);
+  }
   LAUNCH_TRY("preprocess_bwd_kernel");
   return SEGS_OK;
 }
@@ -358,6 +414,32 @@ int segs_project2_image(int P, int D, int M, int width, int height, const float*
   hipError_t fe = hipFreeAsync(raw, st);
   if (rc == SEGS_OK && fe != hipSuccess) return hip_fail(fe, "hipFreeAsync");
   return rc;
+}
+
+
+// ---- measurement support (bench.py): HIP events recorded on the launch stream around selected kernels.
+int segs_profile_begin(unsigned kernel_mask) {
+  g_prof.mask = kernel_mask; g_prof.used = 0; g_prof.spans.clear();
+  for (int i = 0; i < K_COUNT; i++) { g_prof.total_ms[i] = 0; g_prof.count[i] = 0; }
+  return SEGS_OK;
+}
+int segs_profile_end(void) {
+  g_prof.mask = 0;
+  for (const auto& sp : g_prof.spans) {
+    HIP_TRY(hipEventSynchronize(g_prof.pool[sp.e1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g_prof.pool[sp.e0], g_prof.pool[sp.e1]));
+    g_prof.total_ms[sp.id] += ms; g_prof.count[sp.id]++;
+  }
+  g_prof.spans.clear(); g_prof.used = 0;
+  return SEGS_OK;
+}
+int segs_profile_kernel_count(void) { return K_COUNT; }
+const char* segs_profile_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+int segs_profile_query(int id, double* total_ms, long* launches) {
+  if (id < 0 || id >= K_COUNT || !total_ms || !launches) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad profile query");
+  *total_ms = g_prof.total_ms[id]; *launches = g_prof.count[id];
+  return SEGS_OK;
 }
 
 }  // extern "C"
