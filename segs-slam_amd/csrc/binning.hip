@@ -65,7 +65,11 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int idx = blockIdx.x * 256 + tid;
   uint4 b = make_uint4(0, 0, 0, 0);
-  if (idx < P) b = reinterpret_cast<const uint4*>(bin)[idx];
+  float4 e = make_float4(0.f, 0.f, -1.f, -1.f);
+  if (idx < P) {
+    b = reinterpret_cast<const uint4*>(bin)[2 * (size_t)idx];
+    e = reinterpret_cast<const float4*>(bin)[2 * (size_t)idx + 1];
+  }
   uint32_t x = b.w;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -82,13 +86,19 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
   if (b.w == 0) return;
   uint32_t off = incl - b.w;
   const uint32_t minx = b.y & 0xFFFFu, miny = b.y >> 16, maxx = b.z & 0xFFFFu, maxy = b.z >> 16;
+  const float bx0 = e.x - e.z, bx1 = e.x + e.z, by0 = e.y - e.w, by1 = e.y + e.w;  // alpha-support box
   for (uint32_t y = miny; y < maxy; y++) {
+    // rows of 8x8 quadrants of this tile row: pixel centres y*16 .. y*16+7 and y*16+8 .. y*16+15
+    const float ty = (float)(y * TILE_Y);
+    const uint32_t rowm = ((by0 <= ty + 7.f && by1 >= ty) ? 0x3u : 0u) | ((by0 <= ty + 15.f && by1 >= ty + 8.f) ? 0xCu : 0u);
     for (uint32_t xx = minx; xx < maxx; xx++) {
+      const float tx = (float)(xx * TILE_X);
+      const uint32_t colm = ((bx0 <= tx + 7.f && bx1 >= tx) ? 0x5u : 0u) | ((bx0 <= tx + 15.f && bx1 >= tx + 8.f) ? 0xAu : 0u);
       uint64_t key = (uint64_t)(y * gx + xx);
       key <<= 32;
       key |= (uint64_t)b.x;
       keys[off] = key;
-      vals[off] = (uint32_t)idx;
+      vals[off] = (uint32_t)idx | ((rowm & colm) << ID_BITS);
       off++;
     }
   }
@@ -303,6 +313,12 @@ __global__ void __launch_bounds__(256) unpack_geometry_kernel(
     rgb[3 * (size_t)idx + 1] = vis ? r[REC_G] : 0.f;
     rgb[3 * (size_t)idx + 2] = vis ? r[REC_B] : 0.f;
   }
+}
+
+// point_list as the reference defines it: strip the quadrant mask from the sorted values.
+__global__ void __launch_bounds__(256) strip_mask_kernel(int n, const uint32_t* __restrict__ vals, uint32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = vals[i] & ID_MASK;
 }
 
 }  // namespace segs

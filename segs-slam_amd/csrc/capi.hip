@@ -160,6 +160,7 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   hipStream_t st = (hipStream_t)stream;
   if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(SEGS_ERR_INVALID_ARGUMENT, "null allocator callback");
   if (P < 0 || width <= 0 || height <= 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad P / image size");
+  if (P > MAX_GAUSSIANS) return fail(SEGS_ERR_INVALID_ARGUMENT, "P exceeds 2^28 Gaussians (sort values carry a 4-bit quadrant mask)");
   if (!background || !out_color || !viewmatrix || !projmatrix || !num_rendered) return fail(SEGS_ERR_INVALID_ARGUMENT, "null required pointer");
   if (P > 0 && (!means3D || !opacities)) return fail(SEGS_ERR_INVALID_ARGUMENT, "null means3D/opacities");
   if (P > 0 && !colors_precomp) {
@@ -329,7 +330,10 @@ int segs_debug_unpack_binning(const char* binning_buffer, int R, int width, int 
   const BinningLayout BL = binning_layout(R);
   const char* bin = align_ptr(binning_buffer);
   if (keys_sorted) HIP_TRY(hipMemcpyAsync(keys_sorted, bin + BL.keys[0], (size_t)R * 8, hipMemcpyDeviceToDevice, st));
-  if (point_list) HIP_TRY(hipMemcpyAsync(point_list, bin + BL.vals[0], (size_t)R * 4, hipMemcpyDeviceToDevice, st));
+  if (point_list) {
+    strip_mask_kernel<<<(R + 255) / 256, 256, 0, st>>>(R, (const uint32_t*)(bin + BL.vals[0]), point_list);
+    LAUNCH_TRY("strip_mask_kernel");
+  }
   return SEGS_OK;
 }
 

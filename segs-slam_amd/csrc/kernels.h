@@ -58,4 +58,6 @@ __global__ void unpack_geometry_kernel(int P, const float* __restrict__ rec, con
                                        float* __restrict__ conic_opacity, float* __restrict__ depths,
                                        uint32_t* __restrict__ tiles_touched, float* __restrict__ rgb);
 
+__global__ void strip_mask_kernel(int n, const uint32_t* __restrict__ vals, uint32_t* __restrict__ out);
+
 }  // namespace segs

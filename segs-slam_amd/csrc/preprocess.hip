@@ -145,6 +145,7 @@ struct Projected {
   int radius;          // 0 = rejected
   float depth, px, py; // view z, pixel centre
   float3 conic;
+  float cov_a, cov_c;  // diagonal of the dilated 2D covariance
   uint32_t minx, miny, maxx, maxy;
 };
 
@@ -170,6 +171,7 @@ __device__ __forceinline__ Projected project_gaussian(float3 p, float3 scale, fl
   if (det == 0.0f) return o;
   float det_inv = 1.f / det;
   o.conic = make_float3(cov.z * det_inv, -cov.y * det_inv, cov.x * det_inv);
+  o.cov_a = cov.x; o.cov_c = cov.z;
   float mid = 0.5f * (cov.x + cov.z);
   float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
   float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -204,22 +206,32 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   if (idx < P) {
     Projected g = project_gaussian(p, sc, mod, rot, cov3D_precomp ? cov3D_precomp + (size_t)6 * idx : nullptr,
                                    viewmatrix, projmatrix, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy);
-    BinInfo b{0u, 0u, 0u, 0u};
+    BinInfo b{0u, 0u, 0u, 0u, 0.f, 0.f, -1.f, -1.f};
     if (g.radius > 0) {
       touched = (g.maxy - g.miny) * (g.maxx - g.minx);
       b.depth_bits = __float_as_uint(g.depth);
       b.rect_min = g.minx | (g.miny << 16);
       b.rect_max = g.maxx | (g.maxy << 16);
       b.tiles_touched = touched;
+      // alpha >= 1/255 support box (conservatively inflated; see gs_layout.h)
+      const float op = opacities[idx];
+      const float k2 = 2.0f * __logf(255.0f * op);
+      b.x = g.px; b.y = g.py;
+      if (op * 255.0f > 1.0f) {
+        b.hx = sqrtf(k2 * g.cov_a) * 1.0001f + 0.02f;
+        b.hy = sqrtf(k2 * g.cov_c) * 1.0001f + 0.02f;
+      }
       float4* r4 = reinterpret_cast<float4*>(rec + (size_t)idx * REC_DWORDS);
       // A2/B2/C2: conic pre-scaled so the tile kernels evaluate alpha = o * exp2(A2 dx^2 + B2 dx dy + C2 dy^2)
       r4[0] = make_float4(g.px, g.py, (-0.5f * LOG2E) * g.conic.x, (-LOG2E) * g.conic.y);
-      r4[1] = make_float4((-0.5f * LOG2E) * g.conic.z, opacities[idx], col.x, col.y);
+      r4[1] = make_float4((-0.5f * LOG2E) * g.conic.z, op, col.x, col.y);
       r4[2] = make_float4(col.z, g.conic.x, g.conic.y, g.conic.z);
       r4[3] = make_float4(g.depth, 0.f, 0.f, 0.f);
     }
     radii[idx] = g.radius;
-    reinterpret_cast<uint4*>(bin)[idx] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
+    uint4* bp = reinterpret_cast<uint4*>(bin) + 2 * (size_t)idx;
+    bp[0] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
+    bp[1] = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.hx), __float_as_uint(b.hy));
   }
   // workgroup sum of tiles_touched -> block_sums[blockIdx] (feeds the prefix sum, K5)
   uint32_t s = touched;
