@@ -55,21 +55,44 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(uint32_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// K7: one lane per Gaussian.  Finishes the inclusive scan inside the workgroup (point_offsets is the
-// reference's GeometryState::point_offsets, bit-exact) and emits one (tile|depth, idx) pair per tile of
-// the rect, row-major (y outer, x inner) like the reference.
+// K7.  Finishes the inclusive scan inside the workgroup (point_offsets is the reference's
+// GeometryState::point_offsets, bit-exact) and emits one (tile|depth, idx) pair per tile of each rect,
+// row-major (y outer, x inner) like the reference.  Emission is load-balanced per wave: the wave's 64 rects
+// are expanded slot by slot (lane j handles output slot j, owner found by binary search in the wave's
+// prefix), so the 12-byte pairs leave as coalesced stores whatever the rect sizes are.
+//
+// Each emitted VALUE also carries the 4-bit mask of 8x8 quadrants of the tile in which this Gaussian can pass
+// the alpha >= 1/255 test at all: exact minimum of the quadratic form over the quadrant's pixel rectangle
+// against 2 ln(255 o) (conservatively inflated).  See gs_layout.h.
+__device__ __forceinline__ bool ellipse_hits_rect(float cx, float cy, float A, float B, float C, float k,
+                                                  float x0, float x1, float y0, float y1) {
+  const float lx0 = x0 - cx, lx1 = x1 - cx, ly0 = y0 - cy, ly1 = y1 - cy;
+  if (lx0 <= 0.f && lx1 >= 0.f && ly0 <= 0.f && ly1 >= 0.f) return true;  // centre inside the rectangle
+  const float inv_c = 1.0f / C, inv_a = 1.0f / A;
+  float best = 3.0e38f;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const float dx = e ? lx1 : lx0;
+    const float dy = fminf(ly1, fmaxf(ly0, -B * dx * inv_c));
+    best = fminf(best, A * dx * dx + 2.f * B * dx * dy + C * dy * dy);
+    const float ey = e ? ly1 : ly0;
+    const float ex = fminf(lx1, fmaxf(lx0, -B * ey * inv_a));
+    best = fminf(best, A * ex * ex + 2.f * B * ex * ey + C * ey * ey);
+  }
+  return best <= k;
+}
+
 __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
-    int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ block_offsets,
+    int P, const BinInfo* __restrict__ bin, const float* __restrict__ rec, const uint32_t* __restrict__ block_offsets,
     uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx) {
   __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t s_excl[4][64];
+  __shared__ uint4 s_bin[4][64];
+  __shared__ float s_geo[4][64][6];  // x, y, A, B, C, k
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int idx = blockIdx.x * 256 + tid;
   uint4 b = make_uint4(0, 0, 0, 0);
-  float4 e = make_float4(0.f, 0.f, -1.f, -1.f);
-  if (idx < P) {
-    b = reinterpret_cast<const uint4*>(bin)[2 * (size_t)idx];
-    e = reinterpret_cast<const float4*>(bin)[2 * (size_t)idx + 1];
-  }
+  if (idx < P) b = reinterpret_cast<const uint4*>(bin)[idx];
   uint32_t x = b.w;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -77,29 +100,53 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     if (lane >= off) x += y;
   }
   if (lane == 63) wave_tot[wv] = x;
+  s_excl[wv][lane] = x - b.w;
+  s_bin[wv][lane] = b;
+  if (b.w != 0u) {
+    const float* r = rec + (size_t)idx * REC_DWORDS;
+    const float2 xy = *reinterpret_cast<const float2*>(r);
+    const float4 q2 = reinterpret_cast<const float4*>(r)[2];  // b, A, B, C
+    const float op = r[REC_O];
+    float* g = s_geo[wv][lane];
+    g[0] = xy.x; g[1] = xy.y; g[2] = q2.y; g[3] = q2.z; g[4] = q2.w;
+    g[5] = (op * 255.0f > 1.0f) ? 2.0f * __logf(255.0f * op) * 1.0001f + 1e-3f : -1.0f;
+  }
   __syncthreads();
   uint32_t base = block_offsets[blockIdx.x];
   for (int w = 0; w < wv; w++) base += wave_tot[w];
-  const uint32_t incl = base + x;
-  if (idx >= P) return;
-  point_offsets[idx] = incl;
-  if (b.w == 0) return;
-  uint32_t off = incl - b.w;
-  const uint32_t minx = b.y & 0xFFFFu, miny = b.y >> 16, maxx = b.z & 0xFFFFu, maxy = b.z >> 16;
-  const float bx0 = e.x - e.z, bx1 = e.x + e.z, by0 = e.y - e.w, by1 = e.y + e.w;  // alpha-support box
-  for (uint32_t y = miny; y < maxy; y++) {
-    // rows of 8x8 quadrants of this tile row: pixel centres y*16 .. y*16+7 and y*16+8 .. y*16+15
-    const float ty = (float)(y * TILE_Y);
-    const uint32_t rowm = ((by0 <= ty + 7.f && by1 >= ty) ? 0x3u : 0u) | ((by0 <= ty + 15.f && by1 >= ty + 8.f) ? 0xCu : 0u);
-    for (uint32_t xx = minx; xx < maxx; xx++) {
-      const float tx = (float)(xx * TILE_X);
-      const uint32_t colm = ((bx0 <= tx + 7.f && bx1 >= tx) ? 0x5u : 0u) | ((bx0 <= tx + 15.f && bx1 >= tx + 8.f) ? 0xAu : 0u);
-      uint64_t key = (uint64_t)(y * gx + xx);
+  if (idx < P) point_offsets[idx] = base + x;
+  const uint32_t total = wave_tot[wv];
+  const uint32_t* excl = s_excl[wv];
+  for (uint32_t j0 = 0; j0 < total; j0 += 64) {
+    const uint32_t j = j0 + lane;
+    if (j < total) {
+      // owner = last g with excl[g] <= j  (always has tiles > 0)
+      int g = 0;
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) g += (excl[g + step] <= j) ? step : 0;
+      const uint4 bb = s_bin[wv][g];
+      const uint32_t t = j - excl[g];
+      const uint32_t minx = bb.y & 0xFFFFu, miny = bb.y >> 16, w = (bb.z & 0xFFFFu) - minx;
+      uint32_t q = (uint32_t)((float)t / (float)w);
+      if (q * w > t) q--;
+      if ((q + 1) * w <= t) q++;
+      const uint32_t ty = miny + q, tx = minx + (t - q * w);
+      const float* ge = s_geo[wv][g];
+      const float cx = ge[0], cy = ge[1], A = ge[2], B = ge[3], C = ge[4], k = ge[5];
+      uint32_t mask = 0u;
+      if (k > 0.f) {
+        const float fx = (float)(tx * TILE_X), fy = (float)(ty * TILE_Y);
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+          const float x0 = fx + (float)((qd & 1) * 8), y0 = fy + (float)((qd >> 1) * 8);
+          if (ellipse_hits_rect(cx, cy, A, B, C, k, x0, x0 + 7.f, y0, y0 + 7.f)) mask |= 1u << qd;
+        }
+      }
+      uint64_t key = (uint64_t)(ty * gx + tx);
       key <<= 32;
-      key |= (uint64_t)b.x;
-      keys[off] = key;
-      vals[off] = (uint32_t)idx | ((rowm & colm) << ID_BITS);
-      off++;
+      key |= (uint64_t)bb.x;
+      keys[base + j] = key;
+      vals[base + j] = (uint32_t)(blockIdx.x * 256 + wv * 64 + g) | (mask << ID_BITS);
     }
   }
 }

@@ -208,7 +208,7 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
     const int passes = (end_bit + 7) / 8;
     const int side = passes & 1;
     { PROF(K_DUPLICATE);
-    duplicate_with_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), G.block_sums(), G.offsets(),
+    duplicate_with_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), G.rec(), G.block_sums(), G.offsets(),
                                                             (uint64_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx);
     }
     LAUNCH_TRY("duplicate_with_keys_kernel");
@@ -272,7 +272,7 @@ int segs_rasterize_backward(int P, int D, int M, int R, const float* background,
   { PROF(K_PREPROCESS_BWD);
   preprocess_bwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, radii, cov3D_precomp ? nullptr : scales, rotations,
                                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
-                                                     tan_fovx, tan_fovy, G.gacc(), dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                                                     tan_fovx, tan_fovy, G.gacc(), G.rec(), (float)width, (float)height, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
                                                      dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot);
   }
   LAUNCH_TRY("preprocess_bwd_kernel");
@@ -362,7 +362,7 @@ int segs_debug_preprocess_backward(int P, int width, int height, const float* me
   const float focal_y = height / (2.0f * tan_fovy), focal_x = width / (2.0f * tan_fovx);
   preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, means3D, radii, cov3D_precomp ? nullptr : scales, rotations,
                                                          scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
-                                                         tan_fovx, tan_fovy, nullptr, const_cast<float*>(dL_dmean2D),
+                                                         tan_fovx, tan_fovy, nullptr, nullptr, (float)width, (float)height, const_cast<float*>(dL_dmean2D),
                                                          const_cast<float*>(dL_dconic), nullptr, nullptr, dL_dmean3D, dL_dcov3D,
                                                          dL_dscale, dL_drot);
   LAUNCH_TRY("preprocess_bwd_kernel");

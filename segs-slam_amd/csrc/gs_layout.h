@@ -30,13 +30,13 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr int REC_DWORDS = 16;
 enum RecField { REC_X = 0, REC_Y, REC_A2, REC_B2, REC_C2, REC_O, REC_R, REC_G, REC_B, REC_CA, REC_CB, REC_CC, REC_DEPTH };
 
-// Per-Gaussian bin record (32 B): depth bits, rect_min (x | y<<16), rect_max (x | y<<16), tiles_touched, then
-// the pixel centre and the half extents (hx, hy) of the axis-aligned box that contains every pixel where this
-// Gaussian can pass the alpha >= 1/255 test: {d : d^T Sigma^-1 d <= 2 ln(255 o)} has extents sqrt(2 ln(255 o) * Sigma_xx/yy).
-// The emitter turns it into a 4-bit "which 8x8 quadrants of this tile can be touched" mask carried in the top
-// bits of the sort VALUE, so a wave skips instances that cannot contribute to any of its 64 pixels.  Skipped
-// instances are exactly those the reference `continue`s on for every pixel of the quadrant: results are identical.
-struct BinInfo { uint32_t depth_bits, rect_min, rect_max, tiles_touched; float x, y, hx, hy; };
+// Per-Gaussian bin record (uint4): depth bits, rect_min (x | y<<16), rect_max (x | y<<16), tiles_touched.
+struct BinInfo { uint32_t depth_bits, rect_min, rect_max, tiles_touched; };
+// The instance emitter (K7) tags each (Gaussian, tile) instance with a 4-bit mask of the 8x8 quadrants of the tile
+// that contain at least one point of {d : d^T conic d <= 2 ln(255 o)}, i.e. where alpha >= 1/255 is possible at all.
+// The mask travels in the top bits of the sort VALUE; a wave (= one quadrant) skips instances whose bit is clear.
+// Skipped instances are exactly those the reference `continue`s on for every pixel of the quadrant, so images,
+// n_contrib and gradients are unchanged; point_list for parity checks is value & ID_MASK.
 constexpr uint32_t ID_BITS = 28;                    // sort value = gaussian idx | quadrant mask << 28
 constexpr uint32_t ID_MASK = (1u << ID_BITS) - 1u;
 constexpr int MAX_GAUSSIANS = 1 << ID_BITS;

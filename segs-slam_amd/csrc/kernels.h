@@ -27,13 +27,15 @@ __global__ void preprocess_bwd_kernel(
     int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ scales,
     const float* __restrict__ rotations, float mod, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ view, const float* __restrict__ proj, float h_x, float h_y, float tan_fovx, float tan_fovy,
-    const float* __restrict__ gacc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+    const float* __restrict__ gacc, const float* __restrict__ rec_in, float img_w, float img_h,
+    float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot);
 
 // ---- binning.hip
 __global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total);
-__global__ void duplicate_with_keys_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ block_offsets,
+__global__ void duplicate_with_keys_kernel(int P, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
+                                           const uint32_t* __restrict__ block_offsets,
                                            uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
                                            uint32_t* __restrict__ vals, uint32_t gx);
 __global__ void radix_count_kernel(const uint64_t* __restrict__ keys, int n, int shift, uint32_t* __restrict__ block_hist, int nblocks);

@@ -206,21 +206,14 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   if (idx < P) {
     Projected g = project_gaussian(p, sc, mod, rot, cov3D_precomp ? cov3D_precomp + (size_t)6 * idx : nullptr,
                                    viewmatrix, projmatrix, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy);
-    BinInfo b{0u, 0u, 0u, 0u, 0.f, 0.f, -1.f, -1.f};
+    BinInfo b{0u, 0u, 0u, 0u};
     if (g.radius > 0) {
       touched = (g.maxy - g.miny) * (g.maxx - g.minx);
       b.depth_bits = __float_as_uint(g.depth);
       b.rect_min = g.minx | (g.miny << 16);
       b.rect_max = g.maxx | (g.maxy << 16);
       b.tiles_touched = touched;
-      // alpha >= 1/255 support box (conservatively inflated; see gs_layout.h)
       const float op = opacities[idx];
-      const float k2 = 2.0f * __logf(255.0f * op);
-      b.x = g.px; b.y = g.py;
-      if (op * 255.0f > 1.0f) {
-        b.hx = sqrtf(k2 * g.cov_a) * 1.0001f + 0.02f;
-        b.hy = sqrtf(k2 * g.cov_c) * 1.0001f + 0.02f;
-      }
       float4* r4 = reinterpret_cast<float4*>(rec + (size_t)idx * REC_DWORDS);
       // A2/B2/C2: conic pre-scaled so the tile kernels evaluate alpha = o * exp2(A2 dx^2 + B2 dx dy + C2 dy^2)
       r4[0] = make_float4(g.px, g.py, (-0.5f * LOG2E) * g.conic.x, (-LOG2E) * g.conic.y);
@@ -229,9 +222,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       r4[3] = make_float4(g.depth, 0.f, 0.f, 0.f);
     }
     radii[idx] = g.radius;
-    uint4* bp = reinterpret_cast<uint4*>(bin) + 2 * (size_t)idx;
-    bp[0] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
-    bp[1] = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.hx), __float_as_uint(b.hy));
+    reinterpret_cast<uint4*>(bin)[idx] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
   }
   // workgroup sum of tiles_touched -> block_sums[blockIdx] (feeds the prefix sum, K5)
   uint32_t s = touched;
@@ -278,7 +269,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ scales,
     const float* __restrict__ rotations, float mod, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ view, const float* __restrict__ proj, float h_x, float h_y, float tan_fovx, float tan_fovy,
-    const float* __restrict__ gacc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+    const float* __restrict__ gacc, const float* __restrict__ rec_in, float img_w, float img_h,
+    float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
   __shared__ float lds[768];
@@ -290,16 +282,28 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
 
   float g2x, g2y, gcx, gcy, gcw;
   if (gacc) {
+    // Rows hold raw moments from the tile kernel (render.hip): Mx My Mxx Mxy | Myy S0 Sr Sg | Sb, sums over the
+    // (pixel, Gaussian) pairs of w=dL_dG*G times 1, dx, dy, ...; the reference's per-pair terms
+    // (backward.cu:541-554) are linear in them:
+    //   dL_dmean2D.x = sum dL_dG*(-G dx A - G dy B)*(W/2) = -(A Mx + B My) W/2,  .y = -(C My + B Mx) H/2
+    //   dL_dconic    = -0.5 (Mxx, Mxy, Myy);   dL_dopacity = sum G dL_dalpha = S0 / o
     const float4* a = reinterpret_cast<const float4*>(gacc + (size_t)idx * GACC_DWORDS);
     const float4 a0 = a[0], a1 = a[1];
     const float a8 = gacc[(size_t)idx * GACC_DWORDS + 8];
-    g2x = a0.x; g2y = a0.y; gcx = a0.z; gcy = a0.w; gcw = a1.x;
-    const bool vis = radii[idx] > 0;  // rows of culled Gaussians are never touched by the tile kernel (all zero)
+    float dop = 0.f;
+    g2x = 0.f; g2y = 0.f; gcx = 0.f; gcy = 0.f; gcw = 0.f;
+    if (radii[idx] > 0) {
+      const float4 q2 = reinterpret_cast<const float4*>(rec_in + (size_t)idx * REC_DWORDS)[2];  // b, A, B, C
+      const float op = rec_in[(size_t)idx * REC_DWORDS + REC_O];
+      g2x = -(q2.y * a0.x + q2.z * a0.y) * (0.5f * img_w);
+      g2y = -(q2.w * a0.y + q2.z * a0.x) * (0.5f * img_h);
+      gcx = -0.5f * a0.z; gcy = -0.5f * a0.w; gcw = -0.5f * a1.x;
+      dop = a1.y != 0.f ? a1.y / op : 0.f;
+    }
     dL_dmean2D[3 * (size_t)idx + 0] = g2x; dL_dmean2D[3 * (size_t)idx + 1] = g2y; dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
     reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcw);
-    dL_dopacity[idx] = a1.y;
+    dL_dopacity[idx] = dop;
     dL_dcolor[3 * (size_t)idx + 0] = a1.z; dL_dcolor[3 * (size_t)idx + 1] = a1.w; dL_dcolor[3 * (size_t)idx + 2] = a8;
-    (void)vis;
   } else {
     g2x = dL_dmean2D[3 * (size_t)idx + 0]; g2y = dL_dmean2D[3 * (size_t)idx + 1];
     gcx = dL_dconic[4 * (size_t)idx + 0]; gcy = dL_dconic[4 * (size_t)idx + 1]; gcw = dL_dconic[4 * (size_t)idx + 3];

@@ -71,10 +71,37 @@ __device__ __forceinline__ float rl(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// Compiler-only fence: LDS operations of one wave execute in order in hardware; this keeps the compiler from
+// reordering this lane's LDS stores and the (other lanes' data) loads that follow.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
+
+// Wave-level compaction of the list entries this wave (quadrant) must evaluate: lanes 0..n-1 receive, in list
+// order, the entry value and its index inside the 64-entry chunk.  ds_permute moves data between lanes through
+// the LDS crossbar without touching LDS memory.
+struct Compacted { uint32_t val; uint32_t pos; int n; };
+template <bool REVERSE>
+__device__ __forceinline__ Compacted compact_chunk(uint32_t v, uint32_t qbit, int lane) {
+  const bool rel = (v & qbit) != 0u;
+  const uint64_t m = __ballot(rel);
+  const int n = __popcll(m);
+  const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  // forward: k-th relevant entry from the front goes to lane k; reverse: k-th from the back goes to lane k
+  const int rank = REVERSE ? (n - 1 - below) : below;
+  const int dest = rel ? rank : n + (lane - below);  // a permutation of 0..63
+  Compacted c;
+  c.val = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)v);
+  c.pos = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, lane);
+  c.n = n;
+  return c;
+}
+
+constexpr int FWD_REC = 12;  // floats per staged record: x y a2 b2 | c2 o r g | b pos - -
+
 __global__ void __launch_bounds__(256) render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
     const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color) {
+  __shared__ float4 s_rec[4][64][FWD_REC / 4];
   const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -85,78 +112,90 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(
   const uint32_t qbit = 1u << (ID_BITS + wv);
 
   const uint2 range = ranges[tile];
-  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-  uint32_t last_contributor = 0;
-  bool done = !inside;
+  // Per-pixel state.  A pixel that has terminated ("dead") keeps T = 0 and thr = -1, which makes every later
+  // Gaussian a no-op for it without any per-lane branch: w = alpha*T = 0 and the stop test T' < thr is false.
+  float T = inside ? 1.0f : 0.f, thr = inside ? 0.0001f : -1.f;
+  float Tfin = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  uint32_t last = 0u, lastfin = 0u;
 
-  // Software pipeline over 64-entry chunks of the tile list: while chunk c is evaluated, the records of
-  // chunk c+1 and the list entries of chunk c+2 are in flight (vector loads, counted vmcnt waits).
-  // Lane l fetches the record of list entry (base + l) only if this wave's quadrant bit is set in it;
-  // the evaluation loop then broadcasts one lane's record at a time into SGPRs (v_readlane).
-  LaneRec cur, nxt;
-  uint32_t v_cur = 0u, v_nxt = 0u, v_nn = 0u;
+  // Software pipeline over 64-entry chunks of the tile list: while chunk c is evaluated, the records of chunk
+  // c+1 (gathered one per lane, compacted order) and the list entries of chunk c+2 are in flight.
+  uint32_t v_nxt, v_nn = 0u;
+  Compacted cc;
+  float4 r0, r1; float rb;
   {
     const uint32_t i0 = range.x + lane, i1 = range.x + 64 + lane;
-    v_cur = i0 < range.y ? point_list[i0] : 0u;
+    const uint32_t v0 = i0 < range.y ? point_list[i0] : 0u;
     v_nxt = i1 < range.y ? point_list[i1] : 0u;
-    cur = load_lane_rec_fwd(rec, v_cur, qbit);
+    cc = compact_chunk<false>(v0, qbit, lane);
+    r0 = make_float4(0.f, 0.f, 0.f, 0.f); r1 = r0; rb = 0.f;
+    if (lane < cc.n) {
+      const float4* p = reinterpret_cast<const float4*>(rec + (size_t)(cc.val & ID_MASK) * REC_DWORDS);
+      r0 = p[0]; r1 = p[1]; rb = reinterpret_cast<const float*>(p)[8];
+    }
   }
-  for (uint32_t base = range.x; base < range.y; base += 64) {
-    if (__ballot(!done) == 0ull) break;  // whole 8x8 block finished (forward.cu:386-389, per wave)
-    nxt = load_lane_rec_fwd(rec, v_nxt, qbit);
+  bool alive = true;  // wave-uniform: some pixel of this 8x8 block still accumulates
+  for (uint32_t base = range.x; base < range.y && alive; base += 64) {
+    // stage chunk c's records for broadcast reads
+    const int n = cc.n;
+    if (lane < n) {
+      s_rec[wv][lane][0] = r0;
+      s_rec[wv][lane][1] = r1;
+      s_rec[wv][lane][2] = make_float4(rb, __uint_as_float(base - range.x + cc.pos + 1u), 0.f, 0.f);
+    }
+    wave_lds_fence();
+    // put chunk c+1's records and chunk c+2's list entries in flight
     {
       const uint32_t i2 = base + 128 + lane;
       v_nn = i2 < range.y ? point_list[i2] : 0u;
-    }
-    uint64_t m = __ballot((v_cur & qbit) != 0u);
-    while (m != 0ull) {
-      const int j = __builtin_ctzll(m);
-      m &= m - 1ull;
-      const float gx = rl(cur.q0.x, j), gy = rl(cur.q0.y, j), a2 = rl(cur.q0.z, j), b2 = rl(cur.q0.w, j);
-      const float c2 = rl(cur.q1.x, j), go = rl(cur.q1.y, j), cr = rl(cur.q1.z, j), cg = rl(cur.q1.w, j), cb = rl(cur.q2.x, j);
-      const float dx = gx - pxf, dy = gy - pyf;
-      const float power2 = dx * (a2 * dx + b2 * dy) + (c2 * dy) * dy;  // log2e * power
-      const float alpha = fminf(0.99f, go * fast_exp2(power2));
-      const bool ok = !done && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
-      if (__ballot(ok) != 0ull) {
-        const float test_T = T * (1.f - alpha);
-        const bool stop = ok && test_T < 0.0001f;
-        const bool upd = ok && !stop;
-        const float w = upd ? alpha * T : 0.f;
-        C0 += cr * w; C1 += cg * w; C2 += cb * w;
-        T = upd ? test_T : T;
-        last_contributor = upd ? (base - range.x + (uint32_t)j + 1u) : last_contributor;
-        done = done || stop;
-        if (__ballot(!done) == 0ull) break;
+      cc = compact_chunk<false>(v_nxt, qbit, lane);
+      if (lane < cc.n) {
+        const float4* p = reinterpret_cast<const float4*>(rec + (size_t)(cc.val & ID_MASK) * REC_DWORDS);
+        r0 = p[0]; r1 = p[1]; rb = reinterpret_cast<const float*>(p)[8];
       }
+      v_nxt = v_nn;
     }
-    cur = nxt; v_cur = v_nxt; v_nxt = v_nn;
+    for (int k = 0; k < n; k++) {
+      const float4 q0 = s_rec[wv][k][0], q1 = s_rec[wv][k][1];
+      const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[wv][k][2]);
+      const float dx = q0.x - pxf, dy = q0.y - pyf;
+      const float power2 = dx * (q0.z * dx + q0.w * dy) + (q1.x * dy) * dy;  // log2e * power
+      const float alpha = fminf(0.99f, q1.y * fast_exp2(power2));
+      const bool ok = power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+      const float ae = ok ? alpha : 0.f;
+      float w = ae * T;
+      float test_T = T - w;
+      const bool stop = test_T < thr;  // forward.cu:420-425; never true for dead pixels (thr = -1)
+      bool upd = ok;
+      if (__ballot(stop) != 0ull) {    // rare: some pixel saturates at this Gaussian
+        Tfin = stop ? T : Tfin;
+        lastfin = stop ? last : lastfin;
+        thr = stop ? -1.f : thr;
+        w = stop ? 0.f : w;
+        test_T = stop ? 0.f : test_T;
+        upd = ok && !stop;
+        alive = __ballot(thr > 0.f) != 0ull;
+      }
+      T = test_T;
+      C0 += q1.z * w; C1 += q1.w * w; C2 += q2.x * w;
+      last = upd ? __float_as_uint(q2.y) : last;
+      if (!alive) break;
+    }
   }
   if (inside) {
+    const bool dead = thr < 0.f;
     const size_t pix_id = (size_t)W * py + px;
     const size_t HW = (size_t)H * W;
-    final_T[pix_id] = T;
-    n_contrib[pix_id] = last_contributor;
-    out_color[pix_id] = C0 + T * bg[0];
-    out_color[HW + pix_id] = C1 + T * bg[1];
-    out_color[2 * HW + pix_id] = C2 + T * bg[2];
+    const float Tout = dead ? Tfin : T;
+    final_T[pix_id] = Tout;
+    n_contrib[pix_id] = dead ? lastfin : last;
+    out_color[pix_id] = C0 + Tout * bg[0];
+    out_color[HW + pix_id] = C1 + Tout * bg[1];
+    out_color[2 * HW + pix_id] = C2 + Tout * bg[2];
   }
 }
 
 // ---- cross-lane helpers -----------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
-  return v + __int_as_float(moved);
-}
-// every lane of each 16-lane row ends with the sum over its row
-__device__ __forceinline__ float row16_sum(float v) {
-  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);  // row_half_mirror
-  v = dpp_add<0x140>(v);  // row_mirror
-  return v;
-}
 // lanes 0-31 <- a[l] + a[l+32], lanes 32-63 <- b[l-32] + b[l]
 __device__ __forceinline__ float fold32(float a, float b) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -167,65 +206,45 @@ __device__ __forceinline__ float fold16(float x, float y) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// Sum each of a,b,c,d over the 64 lanes; result rows hold: row0 = sum(a), row1 = sum(c), row2 = sum(b), row3 = sum(d).
-__device__ __forceinline__ float reduce4(float a, float b, float c, float d) {
-  return row16_sum(fold16(fold32(a, b), fold32(c, d)));
+// a,b,c,d each hold, in lane (row, s), a partial for slot s.  Result rows: row0 = sum_rows(a), row1 = sum_rows(c),
+// row2 = sum_rows(b), row3 = sum_rows(d), per slot s.
+__device__ __forceinline__ float fold_rows4(float a, float b, float c, float d) {
+  return fold16(fold32(a, b), fold32(c, d));
 }
 
-struct PixelState {
-  float T, acc0, acc1, acc2, lc0, lc1, lc2, last_alpha;
+// Backward tile kernel.  Two roles alternate inside each wave, 16 list entries ("slots") at a time:
+//  (1) pixel role (lane = pixel of the 8x8 quadrant): walk the 16 Gaussians back to front, update the pixel's
+//      transmittance / behind-colour state and produce just TWO numbers per (pixel, Gaussian):
+//         w  = dL/dG * G          (everything geometric is linear in it)
+//         aT = alpha * T          (weight of dL/dcolour)
+//      which go to LDS as two 16x64 tiles;
+//  (2) Gaussian role (lane = (slot, 16-pixel part)): read the tiles transposed and accumulate the nine sums
+//      S0=Sum w, S1x=Sum w px, S1y=Sum w py, Sxx, Sxy, Syy (px,py = pixel coords local to the quadrant) and
+//      Sum aT*dL/dpixel[rgb] with plain FMAs -- no cross-lane reduction per pair.  Four row partials per slot are
+//      folded with permlane swaps, shifted from quadrant-local to Gaussian-relative moments, and leave as one
+//      float-atomic wave instruction per 4 Gaussians (36 contiguous bytes per Gaussian).
+// The accumulated row holds raw moments (Mx, My, Mxx, Mxy, Myy, S0, Sr, Sg, Sb); preprocess_bwd_kernel turns
+// them into the reference's dL/dmean2D, dL/dconic, dL/dopacity (backward.cu:541-554) with the per-Gaussian conic.
+constexpr int BW_SLOTS = 16;
+constexpr int BW_STRIDE = 65;  // padded row of the transposed tiles: conflict-free in both roles
+struct BwdLds {                  // 10112 B per wave -> 4 workgroups (16 waves) per CU
+  float4 rec[BW_SLOTS][3];      // staged records of the current batch: [0] x y a2 b2  [1] c2 o r g  [2] b pos id -
+  float wt[BW_SLOTS][BW_STRIDE];
+  float at[BW_SLOTS][BW_STRIDE];  // its first 16x12 floats are reused as the moment exchange area `mom`
+  float4 dp[64];                // dL/dpixel (r,g,b) of the quadrant's pixels
 };
-
-// One (pixel, Gaussian) backward step (backward.cu:489-555).  Writes the 9 per-lane partials (zeros for lanes
-// that skip) into v[0..8].
-__device__ __forceinline__ void bwd_pair(const RecS& g, uint32_t pos, uint32_t last_contributor, float pxf, float pyf,
-                                         float dp0, float dp1, float dp2, float T_final, float bg_dot_dpixel,
-                                         float ddelx_dx, float ddely_dy, PixelState& s, float* v) {
-  const float dx = g.x - pxf, dy = g.y - pyf;
-  const float power2 = dx * (g.a2 * dx + g.b2 * dy) + (g.c2 * dy) * dy;
-  const float Graw = fast_exp2(power2);
-  const float alpha = fminf(0.99f, g.o * Graw);
-  const bool ok = pos < last_contributor && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
-  const float G = ok ? Graw : 0.f;  // lanes that skip contribute exact zeros (Graw may be inf)
-  const float one_m_alpha_inv = fast_rcp(1.f - alpha);
-  const float Tn = s.T * one_m_alpha_inv;
-  s.T = ok ? Tn : s.T;
-  const float dchannel_dcolor = ok ? alpha * s.T : 0.f;
-  // accum_rec / last_color recursion (backward.cu:513-523)
-  const float a0 = s.last_alpha * s.lc0 + (1.f - s.last_alpha) * s.acc0;
-  const float a1 = s.last_alpha * s.lc1 + (1.f - s.last_alpha) * s.acc1;
-  const float a2 = s.last_alpha * s.lc2 + (1.f - s.last_alpha) * s.acc2;
-  s.acc0 = ok ? a0 : s.acc0; s.acc1 = ok ? a1 : s.acc1; s.acc2 = ok ? a2 : s.acc2;
-  s.lc0 = ok ? g.r : s.lc0; s.lc1 = ok ? g.g : s.lc1; s.lc2 = ok ? g.b : s.lc2;
-  float dL_dalpha = (g.r - a0) * dp0 + (g.g - a1) * dp1 + (g.b - a2) * dp2;
-  dL_dalpha *= s.T;
-  s.last_alpha = ok ? alpha : s.last_alpha;
-  dL_dalpha += (-T_final * one_m_alpha_inv) * bg_dot_dpixel;
-  dL_dalpha = ok ? dL_dalpha : 0.f;
-  const float dL_dG = g.o * dL_dalpha;
-  const float gdx = G * dx, gdy = G * dy;
-  const float dG_ddelx = -gdx * g.ca - gdy * g.cb;
-  const float dG_ddely = -gdy * g.cc - gdx * g.cb;
-  v[0] = dL_dG * dG_ddelx * ddelx_dx;
-  v[1] = dL_dG * dG_ddely * ddely_dy;
-  v[2] = -0.5f * gdx * dx * dL_dG;
-  v[3] = -0.5f * gdx * dy * dL_dG;
-  v[4] = -0.5f * gdy * dy * dL_dG;
-  v[5] = G * dL_dalpha;
-  v[6] = dchannel_dcolor * dp0;
-  v[7] = dchannel_dcolor * dp1;
-  v[8] = dchannel_dcolor * dp2;
-}
 
 __global__ void __launch_bounds__(256) render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
     const float* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ gacc) {
+  __shared__ BwdLds lds_all[4];
   const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t px = blockIdx.x * TILE_X + (wv & 1) * 8 + (lane & 7);
-  const uint32_t py = blockIdx.y * TILE_Y + (wv >> 1) * 8 + (lane >> 3);
+  BwdLds& L = lds_all[wv];
+  const uint32_t qx0 = blockIdx.x * TILE_X + (wv & 1) * 8, qy0 = blockIdx.y * TILE_Y + (wv >> 1) * 8;
+  const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const bool inside = px < (uint32_t)W && py < (uint32_t)H;
   const float pxf = (float)px, pyf = (float)py;
   const size_t pix_id = (size_t)W * py + px;
@@ -238,71 +257,131 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
   float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
   if (inside) { dp0 = dL_dpix[pix_id]; dp1 = dL_dpix[HW + pix_id]; dp2 = dL_dpix[2 * HW + pix_id]; }
   const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
-  const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-  PixelState s{T_final, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // Start at the deepest contributor of this 8x8 block: everything behind it is skipped by every pixel
-  // (backward.cu:487-488).
+  // Start at the deepest contributor of this 8x8 block (backward.cu:487-488).
   uint32_t wave_last = last_contributor;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, off, 64));
   wave_last = __builtin_amdgcn_readfirstlane(wave_last);
   if (wave_last == 0u) return;
 
-  const int row = lane >> 4, col = lane & 15;
+  L.dp[lane] = make_float4(dp0, dp1, dp2, 0.f);
+  float T = T_final, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;  // acc = colour accumulated BEHIND the current Gaussian
+
+  // Gaussian-role constants
+  const int gs = lane & 15, part = lane >> 4;
+  const float pyl0 = (float)(part * 2), pyl1 = pyl0 + 1.0f;
+  const float qx0f = (float)qx0, qy0f = (float)qy0;
+
   const int32_t cfirst = (int32_t)((wave_last - 1u) & ~63u);
-  uint32_t v_cur, v_nxt = 0u;
+  uint32_t v_nxt = 0u;
+  Compacted cc;
+  float4 r0, r1; float rb;
   {
     const uint32_t p0 = (uint32_t)cfirst + lane;
-    v_cur = p0 < wave_last ? point_list[range.x + p0] : 0u;
+    const uint32_t v0 = p0 < wave_last ? point_list[range.x + p0] : 0u;
     if (cfirst >= 64) v_nxt = point_list[range.x + (uint32_t)(cfirst - 64) + lane];
+    cc = compact_chunk<true>(v0, qbit, lane);
+    r0 = make_float4(0.f, 0.f, 0.f, 0.f); r1 = r0; rb = 0.f;
+    if (lane < cc.n) {
+      const float4* p = reinterpret_cast<const float4*>(rec + (size_t)(cc.val & ID_MASK) * REC_DWORDS);
+      r0 = p[0]; r1 = p[1]; rb = reinterpret_cast<const float*>(p)[8];
+    }
   }
-  LaneRec cur = load_lane_rec_bwd(rec, v_cur, qbit);
   for (int32_t cbase = cfirst; cbase >= 0; cbase -= 64) {
-    // records of the next (shallower) chunk and the list entries of the one after it go in flight now
-    const LaneRec nxt = load_lane_rec_bwd(rec, v_nxt, qbit);
-    uint32_t v_nn = 0u;
-    if (cbase >= 128) v_nn = point_list[range.x + (uint32_t)(cbase - 128) + lane];
-    const uint32_t v = v_cur;
-    uint64_t m = __ballot((v & qbit) != 0u);
-    while (m != 0ull) {
-      // up to four list entries, back to front
-      uint32_t ids[4]; uint32_t pos[4]; bool have[4]; int jj[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        have[k] = m != 0ull;
-        const int j = have[k] ? 63 - __builtin_clzll(m) : 0;
-        if (have[k]) m &= ~(1ull << j);
-        jj[k] = j;
-        ids[k] = readlane_u32(v, j) & ID_MASK;
-        pos[k] = (uint32_t)cbase + (uint32_t)j;
+    const int n = cc.n;
+    // current chunk's records stay in registers (one per lane, compacted order); the next chunk's go in flight
+    const float4 c0 = r0, c1 = r1;
+    const float4 c2 = make_float4(rb, __uint_as_float((uint32_t)cbase + cc.pos), __uint_as_float(cc.val & ID_MASK), 0.f);
+    {
+      uint32_t v_nn = 0u;
+      if (cbase >= 128) v_nn = point_list[range.x + (uint32_t)(cbase - 128) + lane];
+      cc = compact_chunk<true>(v_nxt, qbit, lane);
+      if (lane < cc.n) {
+        const float4* p = reinterpret_cast<const float4*>(rec + (size_t)(cc.val & ID_MASK) * REC_DWORDS);
+        r0 = p[0]; r1 = p[1]; rb = reinterpret_cast<const float*>(p)[8];
       }
-      float vq[4][9];
+      v_nxt = v_nn;
+    }
+    float (*mom)[12] = reinterpret_cast<float (*)[12]>(&L.at[0][0]);
+    for (int b0 = 0; b0 < n; b0 += BW_SLOTS) {
+      const int nb = min(BW_SLOTS, n - b0);
+      if (lane >= b0 && lane < b0 + nb) {
+        L.rec[lane - b0][0] = c0; L.rec[lane - b0][1] = c1; L.rec[lane - b0][2] = c2;
+      }
+      wave_lds_fence();
+      // ---------------- (1) pixel role
+      for (int sl = 0; sl < nb; sl++) {
+        const float4 q0 = L.rec[sl][0], q1 = L.rec[sl][1];
+        const float2 q2 = *reinterpret_cast<const float2*>(&L.rec[sl][2]);
+        const float dx = q0.x - pxf, dy = q0.y - pyf;
+        const float power2 = dx * (q0.z * dx + q0.w * dy) + (q1.x * dy) * dy;
+        const float ar = q1.y * fast_exp2(power2);  // o * G
+        const float alpha = fminf(0.99f, ar);
+        const bool ok = __float_as_uint(q2.y) < last_contributor && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
+        const float ae = ok ? alpha : 0.f;   // skipped pairs: alpha = 0 makes every update below a no-op
+        const float aw = ok ? ar : 0.f;      // o * G (the clamp at 0.99 is not differentiated, backward.cu:497)
+        const float rinv = fast_rcp(1.f - ae);
+        T = T * rinv;                        // T / (1 - alpha)
+        const float d0 = q1.z - acc0, d1 = q1.w - acc1, d2 = q2.x - acc2;
+        float dL_dalpha = (d0 * dp0 + d1 * dp1 + d2 * dp2) * T;
+        dL_dalpha += (-T_final * rinv) * bg_dot_dpixel;
+        acc0 += ae * d0; acc1 += ae * d1; acc2 += ae * d2;  // alpha*c + (1-alpha)*acc  (backward.cu:513-516)
+        L.wt[sl][lane] = aw * dL_dalpha;     // = dL_dG * G
+        L.at[sl][lane] = ae * T;             // = dchannel_dcolor
+      }
+      wave_lds_fence();
+      // ---------------- (2) Gaussian role: lane = (part, gs): slot gs, pixels part*16 .. part*16+15
+      float S0 = 0.f, S1x = 0.f, S1y = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (have[k]) {  // wave-uniform
-          RecS g;
-          g.x = rl(cur.q0.x, jj[k]); g.y = rl(cur.q0.y, jj[k]); g.a2 = rl(cur.q0.z, jj[k]); g.b2 = rl(cur.q0.w, jj[k]);
-          g.c2 = rl(cur.q1.x, jj[k]); g.o = rl(cur.q1.y, jj[k]); g.r = rl(cur.q1.z, jj[k]); g.g = rl(cur.q1.w, jj[k]);
-          g.b = rl(cur.q2.x, jj[k]); g.ca = rl(cur.q2.y, jj[k]); g.cb = rl(cur.q2.z, jj[k]); g.cc = rl(cur.q2.w, jj[k]);
-          bwd_pair(g, pos[k], last_contributor, pxf, pyf, dp0, dp1, dp2, T_final, bg_dot_dpixel, ddelx_dx, ddely_dy, s, vq[k]);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 9; q++) vq[k][q] = 0.f;
+      for (int i = 0; i < 16; i++) {
+        const int p = part * 16 + i;
+        const float w = L.wt[gs][p], a = L.at[gs][p];
+        const float4 d = L.dp[p];
+        const float pxl = (float)(i & 7);
+        const float pyl = (i >> 3) ? pyl1 : pyl0;
+        const float wx = w * pxl, wy = w * pyl;
+        S0 += w; S1x += wx; S1y += wy;
+        Sxx += wx * pxl; Sxy += wx * pyl; Syy += wy * pyl;
+        Sr += a * d.x; Sg += a * d.y; Sb += a * d.z;
+      }
+      const float g1 = fold_rows4(S0, S1y, S1x, Sxx);   // rows: S0, S1x, S1y, Sxx
+      const float g2 = fold_rows4(Sxy, Sr, Syy, Sg);    // rows: Sxy, Syy, Sr, Sg
+      const float g3 = fold_rows4(Sb, Sb, Sb, Sb);      // every row: Sb total
+      mom[gs][part] = g1;
+      mom[gs][4 + part] = g2;
+      if (part == 0) mom[gs][8] = g3;
+      wave_lds_fence();
+      {
+        // every lane of column gs shifts slot gs from quadrant-local moments to Gaussian-relative ones
+        const float4 m0 = *reinterpret_cast<const float4*>(&mom[gs][0]);  // S0 S1x S1y Sxx
+        const float4 m1 = *reinterpret_cast<const float4*>(&mom[gs][4]);  // Sxy Syy Sr Sg
+        const float m8 = mom[gs][8];
+        const float2 gxy = *reinterpret_cast<const float2*>(&L.rec[gs][0]);
+        const float gxr = gxy.x - qx0f, gyr = gxy.y - qy0f;   // dx = gxr - pxl, dy = gyr - pyl
+        const float Mx = gxr * m0.x - m0.y, My = gyr * m0.x - m0.z;
+        const float Mxx = gxr * (gxr * m0.x - 2.f * m0.y) + m0.w;
+        const float Mxy = gxr * (gyr * m0.x - m0.z) - gyr * m0.y + m1.x;
+        const float Myy = gyr * (gyr * m0.x - 2.f * m0.z) + m1.y;
+        wave_lds_fence();
+        if (part == 0) {
+          *reinterpret_cast<float4*>(&mom[gs][0]) = make_float4(Mx, My, Mxx, Mxy);
+          *reinterpret_cast<float4*>(&mom[gs][4]) = make_float4(Myy, m0.x, m1.z, m1.w);
+          mom[gs][8] = m8;
         }
       }
-      // rows after reduce4: row0 <- k=0, row1 <- k=2, row2 <- k=1, row3 <- k=3
-      float mine = 0.f;
+      wave_lds_fence();
+      // one atomic wave instruction per 4 slots: lane (row, col<9) adds element col of slot 4j + row
 #pragma unroll
-      for (int q = 0; q < 9; q++) {
-        const float z = reduce4(vq[0][q], vq[1][q], vq[2][q], vq[3][q]);
-        mine = (col == q) ? z : mine;
+      for (int j = 0; j < 4; j++) {
+        const int slot = 4 * j + part;
+        if (slot < nb && gs < 9) {
+          const uint32_t id = __float_as_uint(reinterpret_cast<const float*>(&L.rec[slot][2])[2]);
+          atomicAdd(gacc + (size_t)id * GACC_DWORDS + gs, mom[slot][gs]);
+        }
       }
-      const uint32_t my_id = row == 0 ? ids[0] : row == 1 ? ids[2] : row == 2 ? ids[1] : ids[3];
-      const bool my_have = row == 0 ? have[0] : row == 1 ? have[2] : row == 2 ? have[1] : have[3];
-      if (my_have && col < 9) atomicAdd(gacc + (size_t)my_id * GACC_DWORDS + col, mine);
+      wave_lds_fence();
     }
-    cur = nxt; v_cur = v_nxt; v_nxt = v_nn;
   }
 }
 
