@@ -26,15 +26,19 @@ namespace segs {
 // K5: exclusive scan of the per-workgroup tiles_touched sums written by preprocess_fwd_kernel.
 // One 1024-thread workgroup; in-place; total (= num_rendered R) to *total.
 __global__ void __launch_bounds__(1024) scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks,
+                                                               const uint32_t* __restrict__ depth_range,
                                                                uint32_t* __restrict__ total) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
+  __shared__ uint32_t s_dmax, s_dnmin;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) carry_s = 0;
+  if (tid == 0) { carry_s = 0; s_dmax = 0; s_dnmin = 0; }
   __syncthreads();
+  uint32_t dmax = 0, dnmin = 0;
   for (int base = 0; base < nblocks; base += 1024) {
     const int i = base + tid;
     const uint32_t v = i < nblocks ? block_sums[i] : 0u;
+    if (i < nblocks) { dmax = max(dmax, depth_range[i]); dnmin = max(dnmin, depth_range[nblocks + i]); }
     uint32_t x = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -51,7 +55,14 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(uint32_t* __restr
     if (tid == 1023) carry_s = carry + wbase + x;
     __syncthreads();
   }
-  if (tid == 0) *total = carry_s;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    dmax = max(dmax, (uint32_t)__shfl_down((int)dmax, off, 64));
+    dnmin = max(dnmin, (uint32_t)__shfl_down((int)dnmin, off, 64));
+  }
+  if (lane == 0) { atomicMax(&s_dmax, dmax); atomicMax(&s_dnmin, dnmin); }
+  __syncthreads();
+  if (tid == 0) { total[0] = carry_s; total[1] = s_dnmin; total[2] = s_dmax; }  // R, max(~depth), max(depth)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -152,8 +163,15 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// K8 helpers.  digit of a key for this pass.
-__device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift) { return (uint32_t)(key >> shift) & 0xFFu; }
+// K8 helpers.  The sort runs on a compacted image of the key, k' = (tile << dbits) | (depth_bits - dmin), where
+// [dmin, dmin + 2^dbits) covers every depth present (depth bits of positive floats are monotone, so the order,
+// ties included, is exactly that of the reference's 32+bit-bit key); the stored keys stay untouched.  A Replica-like
+// depth range (0.2 m .. 6 m) needs 26 of the 32 depth bits, i.e. 5 byte passes instead of 6 at 1080p.
+struct KeyMap { uint32_t dmin; int dbits; };
+__device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, KeyMap km) {
+  const uint64_t kc = ((key >> 32) << km.dbits) | (uint64_t)((uint32_t)key - km.dmin);
+  return (uint32_t)(kc >> shift) & 0xFFu;
+}
 
 // Per-lane mask of the lanes (among `valid`) holding the same 8-bit digit: 8 ballots.
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint64_t valid) {
@@ -172,18 +190,26 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {  // number of set bits o
 
 // Count matrix: block_hist[d * nblocks + b] = number of keys of workgroup b's 4096-key tile with digit d.
 __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const uint64_t* __restrict__ keys, int n, int shift,
+                                                                    uint32_t dmin, int dbits,
                                                                     uint32_t* __restrict__ block_hist, int nblocks) {
+  const KeyMap km{dmin, dbits};
   __shared__ uint32_t cnt[4][256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int i = tid; i < 4 * 256; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const size_t wave_base = (size_t)blockIdx.x * SORT_TILE + (size_t)wv * (SORT_TILE / 4);
   volatile uint32_t* my = cnt[wv];
-#pragma unroll 4
+  uint64_t kreg[SORT_ITEMS_PER_THREAD];
+#pragma unroll
+  for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {  // all loads in flight before the first use
+    const size_t i = wave_base + (size_t)r * 64 + lane;
+    kreg[r] = i < (size_t)n ? keys[i] : 0ull;
+  }
+#pragma unroll
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     const size_t i = wave_base + (size_t)r * 64 + lane;
     const bool valid = i < (size_t)n;
-    const uint32_t d = valid ? digit_of(keys[i], shift) : 0u;
+    const uint32_t d = valid ? digit_of(kreg[r], shift, km) : 0u;
     const uint64_t vmask = __ballot(valid);
     const uint64_t peers = match_digit(d, vmask);
     if (valid && mbcnt(peers) == 0) my[d] = my[d] + (uint32_t)__popcll(peers);  // one leader lane per digit
@@ -226,8 +252,9 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ 
 // Stable scatter of one 4096-key tile.
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, int n, int shift, const uint32_t* __restrict__ block_hist,
+    uint32_t* __restrict__ vals_out, int n, int shift, uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist,
     const uint32_t* __restrict__ digit_totals, int nblocks) {
+  const KeyMap km{dmin, dbits};
   __shared__ uint64_t s_keys[SORT_TILE];
   __shared__ uint32_t s_vals[SORT_TILE];
   __shared__ uint32_t cnt[4][256];       // per-wave running digit counters, then per-wave bases
@@ -257,7 +284,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     const size_t i = wave_base + (size_t)r * 64 + lane;
     const bool valid = i < (size_t)n;
-    const uint32_t d = valid ? digit_of(key[r], shift) : 0u;
+    const uint32_t d = valid ? digit_of(key[r], shift, km) : 0u;
     const uint64_t vmask = __ballot(valid);
     const uint64_t peers = match_digit(d, vmask);
     const uint32_t below = mbcnt(peers);
@@ -315,7 +342,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const int lp = r * SORT_THREADS + tid;
     if (lp < nvalid) {
       const uint64_t k = s_keys[lp];
-      const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of(k, shift)]);
+      const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of(k, shift, km)]);
       keys_out[gp] = k;
       vals_out[gp] = s_vals[lp];
     }

@@ -82,7 +82,7 @@ uint32_t getHigherMsb(uint32_t n) {
 
 // K8: stable LSD radix sort, 8 bits per pass over key bits [0,end_bit).  Input is expected in side
 // `passes & 1` of the ping-pong pair so that the result lands in side 0.
-int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, hipStream_t st) {
+int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t dmin, int dbits, hipStream_t st) {
   if (n <= 0) return SEGS_OK;
   const int passes = (end_bit + 7) / 8;
   int side = passes & 1;
@@ -95,7 +95,7 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, hipStream_
     uint32_t* vout = (uint32_t*)(bin + L.vals[side ^ 1]);
     const int shift = 8 * p;
     { PROF(K_RADIX_COUNT);
-    radix_count_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, block_hist, L.nblocks);
+    radix_count_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, block_hist, L.nblocks);
     }
     LAUNCH_TRY("radix_count_kernel");
     { PROF(K_RADIX_SCAN);
@@ -103,7 +103,7 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, hipStream_
     }
     LAUNCH_TRY("radix_scan_kernel");
     { PROF(K_RADIX_SCATTER);
-    radix_scatter_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, block_hist, digit_totals, L.nblocks);
+    radix_scatter_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, block_hist, digit_totals, L.nblocks);
     }
     LAUNCH_TRY("radix_scatter_kernel");
     side ^= 1;
@@ -133,7 +133,7 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
   { PROF(K_PREPROCESS_FWD);
   preprocess_fwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, scales, mod, rots, opac, colors, cov3D_precomp, view,
                                                      proj, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, radii,
-                                                     G.rec(), G.bin(), G.block_sums());
+                                                     G.rec(), G.bin(), G.block_sums(), G.block_sums() + (G.L.nblocks + 1));
   }
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
@@ -181,16 +181,18 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   if (!radii) radii = G.radii_internal();
 
   int R = 0;
+  uint32_t hdr[3] = {0u, 0u, 0u};  // num_rendered, max(~depth_bits), max(depth_bits)
   if (P > 0) {
     int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales,
                             scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, st);
     if (rc) return rc;
     { PROF(K_SCAN);
-    scan_block_sums_kernel<<<1, 1024, 0, st>>>(G.block_sums(), G.L.nblocks, G.num_rendered());
+    scan_block_sums_kernel<<<1, 1024, 0, st>>>(G.block_sums(), G.L.nblocks, G.block_sums() + (G.L.nblocks + 1), G.num_rendered());
     }
     LAUNCH_TRY("scan_block_sums_kernel");
-    HIP_TRY(hipMemcpyAsync(&R, G.num_rendered(), sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hdr, G.num_rendered(), sizeof(hdr), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    R = (int)hdr[0];
     if (R < 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "num_rendered overflows int32");
   }
   const BinningLayout BL = binning_layout(R);
@@ -203,8 +205,13 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)gx * gy * sizeof(uint2), st));   // rasterizer_impl.cu:310
   }
   if (R > 0) {
+    // The reference sorts key bits [0, 32+bit) (rasterizer_impl.cu:300-308); the same order is obtained from the
+    // compacted key (tile << dbits) | (depth_bits - dmin), see binning.hip.
     const int bit = (int)getHigherMsb(gx * gy);
-    const int end_bit = 32 + bit;
+    const uint32_t dmin = ~hdr[1], dspan = hdr[2] - dmin;
+    int dbits = 1;
+    while (dbits < 32 && (dspan >> dbits) != 0u) dbits++;
+    const int end_bit = dbits + bit;
     const int passes = (end_bit + 7) / 8;
     const int side = passes & 1;
     { PROF(K_DUPLICATE);
@@ -212,7 +219,7 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
                                                             (uint64_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx);
     }
     LAUNCH_TRY("duplicate_with_keys_kernel");
-    int rc = sort_pairs(bin, BL, R, end_bit, st);
+    int rc = sort_pairs(bin, BL, R, end_bit, dmin, dbits, st);
     if (rc) return rc;
     { PROF(K_RANGES);
     identify_tile_ranges_kernel<<<(R + 255) / 256, 256, 0, st>>>(R, (const uint64_t*)(bin + BL.keys[0]), ranges);
@@ -381,7 +388,7 @@ int segs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* 
   const int side = passes & 1;
   HIP_TRY(hipMemcpyAsync(bin + BL.keys[side], keys_in, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemcpyAsync(bin + BL.vals[side], vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-  int rc = sort_pairs(bin, BL, n, end_bit, st);
+  int rc = sort_pairs(bin, BL, n, end_bit, 0u, 32, st);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(keys_out, bin + BL.keys[0], (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemcpyAsync(vals_out, bin + BL.vals[0], (size_t)n * 4, hipMemcpyDeviceToDevice, st));

@@ -62,7 +62,7 @@ inline GeomLayout geom_layout(int P) {
   g.bin = o;            o = align_up(o + (size_t)P * sizeof(BinInfo));
   g.offsets = o;        o = align_up(o + (size_t)P * 4);
   g.radii_internal = o; o = align_up(o + (size_t)P * 4);
-  g.block_sums = o;     o = align_up(o + (size_t)(g.nblocks + 1) * 4);
+  g.block_sums = o;     o = align_up(o + (size_t)(g.nblocks + 1) * 4 * 3);  // tiles sums | max(depth bits) | max(~depth bits)
   g.clamped = o;        o = align_up(o + (size_t)P * 4);  // SH path: 3 clamp flags packed in one word
   g.num_rendered = o;   o = align_up(o + 64);
   g.gacc = o;           o = align_up(o + (size_t)P * GACC_DWORDS * 4);
@@ -85,9 +85,9 @@ inline ImageLayout image_layout(int W, int H) {
   return l;
 }
 
-constexpr int SORT_ITEMS_PER_THREAD = 16;
+constexpr int SORT_ITEMS_PER_THREAD = 8;
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_TILE = SORT_ITEMS_PER_THREAD * SORT_THREADS;  // 4096 items per workgroup
+constexpr int SORT_TILE = SORT_ITEMS_PER_THREAD * SORT_THREADS;  // 2048 items per workgroup
 
 struct BinningLayout {
   size_t keys[2], vals[2], block_hist, digit_totals, total;

@@ -12,7 +12,8 @@ __global__ void preprocess_fwd_kernel(
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ colors,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy,
-    int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums);
+    int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
+    uint32_t* __restrict__ depth_range);
 
 __global__ void visible_filter_kernel(
     int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
@@ -33,16 +34,18 @@ __global__ void preprocess_bwd_kernel(
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot);
 
 // ---- binning.hip
-__global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, uint32_t* __restrict__ total);
+__global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, const uint32_t* __restrict__ depth_range,
+                                       uint32_t* __restrict__ total);
 __global__ void duplicate_with_keys_kernel(int P, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
                                            const uint32_t* __restrict__ block_offsets,
                                            uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
                                            uint32_t* __restrict__ vals, uint32_t gx);
-__global__ void radix_count_kernel(const uint64_t* __restrict__ keys, int n, int shift, uint32_t* __restrict__ block_hist, int nblocks);
+__global__ void radix_count_kernel(const uint64_t* __restrict__ keys, int n, int shift, uint32_t dmin, int dbits,
+                                   uint32_t* __restrict__ block_hist, int nblocks);
 __global__ void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_totals);
 __global__ void radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                      uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
-                                     const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_totals, int nblocks);
+                                     uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_totals, int nblocks);
 __global__ void identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges);
 
 // ---- render.hip

@@ -189,9 +189,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ colors,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy,
-    int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums) {
+    int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
+    uint32_t* __restrict__ depth_range /* per workgroup: [b] = max(depth_bits), [nblocks + b] = max(~depth_bits), visible only */) {
   __shared__ float lds[768];
-  __shared__ uint32_t wave_sums[4];
+  __shared__ uint32_t wave_sums[4], wave_dmax[4], wave_dnmin[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const float3 p = load_row3(means3D, P, lds);
   float3 sc = make_float3(0, 0, 0);
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   }
   const float3 col = load_row3(colors, P, lds);
 
-  uint32_t touched = 0;
+  uint32_t touched = 0, dbits_mine = 0;
   if (idx < P) {
     Projected g = project_gaussian(p, sc, mod, rot, cov3D_precomp ? cov3D_precomp + (size_t)6 * idx : nullptr,
                                    viewmatrix, projmatrix, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy);
@@ -210,6 +211,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     if (g.radius > 0) {
       touched = (g.maxy - g.miny) * (g.maxx - g.minx);
       b.depth_bits = __float_as_uint(g.depth);
+      dbits_mine = b.depth_bits;
       b.rect_min = g.minx | (g.miny << 16);
       b.rect_max = g.maxx | (g.maxy << 16);
       b.tiles_touched = touched;
@@ -224,13 +226,24 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     radii[idx] = g.radius;
     reinterpret_cast<uint4*>(bin)[idx] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
   }
-  // workgroup sum of tiles_touched -> block_sums[blockIdx] (feeds the prefix sum, K5)
+  // workgroup sum of tiles_touched -> block_sums[blockIdx] (feeds the prefix sum, K5); depth range for the sort
   uint32_t s = touched;
+  uint32_t dmax = touched ? dbits_mine : 0u, dnmin = touched ? ~dbits_mine : 0u;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = s;
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    dmax = max(dmax, (uint32_t)__shfl_down((int)dmax, off, 64));
+    dnmin = max(dnmin, (uint32_t)__shfl_down((int)dnmin, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    wave_sums[threadIdx.x >> 6] = s; wave_dmax[threadIdx.x >> 6] = dmax; wave_dnmin[threadIdx.x >> 6] = dnmin;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+  if (threadIdx.x == 0) {
+    block_sums[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    depth_range[blockIdx.x] = max(max(wave_dmax[0], wave_dmax[1]), max(wave_dmax[2], wave_dmax[3]));
+    depth_range[gridDim.x + blockIdx.x] = max(max(wave_dnmin[0], wave_dnmin[1]), max(wave_dnmin[2], wave_dnmin[3]));
+  }
 }
 
 __global__ void __launch_bounds__(256) visible_filter_kernel(
