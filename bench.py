@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2_1080p", help="scene config name (segs_slam_amd.scenes.CONFIGS)")
+    ap.add_argument("--mode", default="raster", choices=["raster", "trainer"],
+                    help="raster: fwd+bwd raster (+all-reduce); trainer: + L1/SSIM loss (torch ops) and fused Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     args = ap.parse_args()
@@ -76,7 +78,18 @@ def main():
     dL = t(sc.dL_dout_color)
     eng = RasterEngine(sc.P, cam.width, cam.height, dev)
 
+    if args.mode == "trainer":
+        from segs_slam_amd.gaussian_trainer import TrainerStep, keyframe_tensors
+        tstep = TrainerStep.on_gpu(sc, dev)
+        eng = tstep.engine
+        kfs = [keyframe_tensors(cam, dev)]
+        gts = [torch.rand(3, cam.height, cam.width, device=dev)]
+        tstep.keyframe_for = lambda step, n: 0
+
     def step():
+        if args.mode == "trainer":
+            tstep.training_once(kfs, gts)
+            return
         eng.forward(bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy)
         eng.backward(dL)
         if world > 1:
@@ -138,7 +151,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {sc.P} Gaussians, {cam.width}x{cam.height}, 1 keyframe per GPU, "
-                                   "fwd+bwd raster" + (", RCCL all-reduce of parameter grads" if world > 1 else ""),
+                                   "fwd+bwd raster" + (", RCCL all-reduce of parameter grads" if world > 1 else "")
+                                   + (" + L1/SSIM loss + fused Adam" if args.mode == "trainer" else ""),
                        "P": sc.P, "P_visible": P_vis, "num_rendered": R, "width": cam.width, "height": cam.height,
                        "sort_passes": passes, "parallelism": f"keyframe-dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

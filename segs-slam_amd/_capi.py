@@ -16,6 +16,11 @@ LIB_PATH = os.path.join(CSRC, "libsegs_raster.so")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
+
+class AdamSegment(C.Structure):
+    """segs_adam_segment (include/segs_train.h)."""
+    _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("lr", C.c_float)]
+
 # name -> (restype, argtypes); every symbol include/segs_raster.h declares
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -37,6 +42,7 @@ SYMBOLS = {
     "segs_debug_preprocess_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                                              _vp, _vp, _vp, _vp]),
     "segs_sort_pairs": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "segs_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, C.c_int64, _f, _i, _vp]),
     "segs_profile_begin": (_i, [C.c_uint]),
     "segs_profile_end": (_i, []),
     "segs_profile_kernel_count": (_i, []),

@@ -11,9 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "segs_raster.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(segs_[a-z0-9_]+)\s*\(", text)) - {"segs_alloc_fn"})
+    names = set()
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(segs_[a-z0-9_]+)\s*\(", text))
+    return sorted(names - {"segs_alloc_fn"})
 
 
 def test_library_exports_every_declared_symbol():

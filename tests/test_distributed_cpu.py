@@ -1,0 +1,145 @@
+"""world_size-2 gloo tests (CPU) of the keyframe-parallel trainer step.
+
+The HIP engine cannot run here, so the per-rank render+backward is supplied by the CPU oracle (test-only wiring;
+the package never imports oracle/).  Checked: (1) the all-reduced bucket equals the sum of the two single-keyframe
+oracle gradients; (2) both ranks end the step with bit-identical parameters; (3) the 2-rank step equals a 1-process
+step fed the summed gradient (parity at gradient level, not trajectory level)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_backend(scene_np, grads_flat, P):
+    from oracle import gs_oracle
+    from segs_slam_amd.raster_engine import split_flat
+
+    def render_backward(params, keyframe, dL_fn):
+        cam = keyframe
+        o = gs_oracle.Oracle()
+        o.forward(scene_np.bg, params["means3D"].numpy(), params["colors"].numpy(), params["opacity"].numpy(),
+                  params["scales"].numpy(), 1.0, params["rotations"].numpy(), cam.world_view_transform,
+                  cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.height, cam.width)
+        image = torch.from_numpy(o.get("out_color"))
+        loss, dL = dL_fn(image)
+        g = o.backward(dL.numpy())
+        views = split_flat(grads_flat, P)
+        for name, key in (("means3D", "dL_dmean3D"), ("scales", "dL_dscale"), ("rotations", "dL_drot"),
+                          ("opacity", "dL_dopacity"), ("colors", "dL_dcolor")):
+            views[name].copy_(torch.from_numpy(g[key]))
+        return loss
+    return render_backward
+
+
+def _make(P=400, W=48, H=32):
+    from segs_slam_amd import scenes
+    sc = scenes.make_scene(P, W, H, 40.0, 40.0, seed=77, bg=(0.1, 0.1, 0.1))
+    sc.scales *= 4.0
+    cams = [scenes.make_scene(P, W, H, 40.0, 40.0, seed=77, keyframe=k).camera for k in range(2)]
+    gts = [torch.from_numpy(scenes.uniform01(3 * H * W, 60 + k, 5).reshape(3, H, W).copy()) for k in range(2)]
+    return sc, cams, gts
+
+
+def _params(sc):
+    from segs_slam_amd.raster_engine import FLOATS_PER_GAUSSIAN, split_flat
+    flat = torch.zeros(FLOATS_PER_GAUSSIAN * sc.P)
+    v = split_flat(flat, sc.P)
+    for name, arr in (("means3D", sc.means3D), ("scales", sc.scales), ("rotations", sc.rotations), ("opacity", sc.opacity),
+                      ("colors", sc.colors)):
+        v[name].copy_(torch.from_numpy(arr))
+    return flat
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from segs_slam_amd.gaussian_trainer import OptimizationParams, TorchAdam, TrainerStep
+    sc, cams, gts = _make()
+    flat = _params(sc)
+    grads = torch.zeros_like(flat)
+    opt = OptimizationParams()
+    step = TrainerStep(flat, sc.P, _oracle_backend(sc, grads, sc.P), TorchAdam(flat.numel(), "cpu", opt), opt, grads)
+    assert step.world == world and step.keyframe_for(0, 2) == rank
+    # capture the reduced gradient before Adam clears it
+    reduced = {}
+    orig = step.optimizer.step
+
+    def spy(p, g, lrs, P, scale):
+        reduced["g"] = g.clone()
+        reduced["scale"] = scale
+        return orig(p, g, lrs, P, scale)
+    step.optimizer.step = spy
+    loss = step.training_once(cams, gts)
+    np.save(os.path.join(out_dir, f"params_{rank}.npy"), flat.numpy())
+    np.save(os.path.join(out_dir, f"reduced_{rank}.npy"), reduced["g"].numpy())
+    assert reduced["scale"] == 0.5 and np.isfinite(float(loss))
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_summed_gradients(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "params_0.npy"), np.load(tmp_path / "params_1.npy")
+    assert np.array_equal(p0, p1), "replicas diverged"
+    r0, r1 = np.load(tmp_path / "reduced_0.npy"), np.load(tmp_path / "reduced_1.npy")
+    assert np.array_equal(r0, r1)
+
+    # single-process reference: sum of the two single-keyframe oracle gradients, then one Adam step at scale 1/2
+    from segs_slam_amd.gaussian_trainer import OptimizationParams, TorchAdam, TrainerStep
+    sc, cams, gts = _make()
+    total = None
+    for k in range(2):
+        flat = _params(sc)
+        grads = torch.zeros_like(flat)
+        opt = OptimizationParams()
+        st = TrainerStep(flat, sc.P, _oracle_backend(sc, grads, sc.P), TorchAdam(flat.numel(), "cpu", opt), opt, grads)
+        st.render_backward(st.params, cams[k], lambda im: st.loss_and_grad(im, gts[k]))
+        total = grads.clone() if total is None else total + grads
+    assert np.allclose(r0, total.numpy(), rtol=1e-6, atol=1e-12)
+    assert np.abs(total.numpy()).max() > 0
+    flat = _params(sc)
+    opt = OptimizationParams()
+    adam = TorchAdam(flat.numel(), "cpu", opt)
+    st = TrainerStep(flat, sc.P, None, adam, opt, torch.zeros_like(flat))
+    adam.step(flat, torch.from_numpy(r0.copy()), st.learning_rates(1), sc.P, 0.5)
+    assert np.array_equal(flat.numpy(), p0)
+
+
+def test_expon_lr_and_schedule():
+    from segs_slam_amd.gaussian_trainer import expon_lr
+    assert abs(expon_lr(0, 1.6e-4, 1.6e-6, 30000) - 1.6e-4) < 1e-12
+    assert abs(expon_lr(30000, 1.6e-4, 1.6e-6, 30000) - 1.6e-6) < 1e-12
+    assert abs(expon_lr(15000, 1.6e-4, 1.6e-6, 30000) - 1.6e-5) < 1e-10
+    assert expon_lr(5, 0.0, 0.0, 100) == 0.0
+
+
+def test_ssim_matches_reference_formula_on_cpu():
+    """loss_utils.ssim against a direct numpy evaluation of loss_utils.h:77-109 (zero padding 5, integer-x window)."""
+    from segs_slam_amd import loss_utils
+    rng = np.random.default_rng(3)
+    a, b = rng.random((3, 20, 24), dtype=np.float32), rng.random((3, 20, 24), dtype=np.float32)
+    g = np.array([np.exp(-float((x - 5) ** 2) / (2 * 1.5 * 1.5)) for x in range(11)], dtype=np.float64)
+    g /= g.sum()
+    w2 = np.outer(g, g)
+
+    def conv(img):
+        pad = np.pad(img.astype(np.float64), ((0, 0), (5, 5), (5, 5)))
+        out = np.zeros_like(img, dtype=np.float64)
+        for dy in range(11):
+            for dx in range(11):
+                out += w2[dy, dx] * pad[:, dy:dy + img.shape[1], dx:dx + img.shape[2]]
+        return out
+    mu1, mu2 = conv(a), conv(b)
+    s1, s2, s12 = conv(a * a) - mu1 ** 2, conv(b * b) - mu2 ** 2, conv(a * b) - mu1 * mu2
+    ref = (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 ** 2 + mu2 ** 2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+    got = float(loss_utils.ssim(torch.from_numpy(a), torch.from_numpy(b)))
+    assert abs(got - ref) < 2e-5
