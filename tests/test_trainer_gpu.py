@@ -12,9 +12,9 @@ DEV = "cuda:0"
 def adam_reference(p, g, m, v, lr, b1, b2, eps, step, gscale):
     """float32 restatement of LibTorch 2.0.1's C++ Adam step, one rounding per operation."""
     f = np.float32
-    bc1 = 1.0 - b1 ** step
-    bc2 = 1.0 - b2 ** step
-    step_size = f(lr / bc1)
+    bc1 = 1.0 - float(f(b1)) ** step  # betas cross the C ABI as float32; corrections are formed in double
+    bc2 = 1.0 - float(f(b2)) ** step
+    step_size = f(float(f(lr)) / bc1)  # the C ABI takes lr as float32
     sqrt_bc2 = f(np.sqrt(bc2))
     gr = g * f(gscale)
     m = m * f(b1) + gr * (f(1.0) - f(b1))
