@@ -161,3 +161,46 @@ def run_scene(scene, backward: bool = True):
               cam.height, cam.width)
     grads = o.backward(scene.dL_dout_color) if backward else None
     return o, grads
+
+
+# ---- point-set helpers (oracle/aux_oracle.cpp) ------------------------------------------------------------
+def _u8(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def knn_mean_dist2(points) -> np.ndarray:
+    """distCUDA2 (third_party/simple-knn/spatial.cu:15-26): exact mean of the 3 smallest squared distances (O(P^2))."""
+    p = _f32(points)
+    out = np.zeros(p.shape[0], dtype=np.float32)
+    lib().gso_knn_mean_dist2(C.c_int(p.shape[0]), _p(p), _p(out))
+    return out
+
+
+def transform_points(points, M) -> np.ndarray:
+    p, m = _f32(points), _f32(M)
+    out = np.zeros_like(p)
+    lib().gso_transform_points(C.c_int(p.shape[0]), _p(p), _p(m), _p(out))
+    return out
+
+
+def scale_and_transform_points(points, rots, M, mask, scale):
+    p, r, m, k = _f32(points), _f32(rots), _f32(M), _u8(mask)
+    out_p, out_r = np.zeros_like(p), np.zeros_like(r)
+    lib().gso_scale_and_transform_points(C.c_int(p.shape[0]), C.c_float(scale), _p(p), _p(r), _p(m), _p(k, np.uint8),
+                                         _p(out_p), _p(out_r))
+    return out_p, out_r
+
+
+def reproject_depths_pinhole(depths, mask, intr, width) -> np.ndarray:
+    d, k = _f32(depths), _u8(mask)
+    out = np.zeros((d.shape[0], 3), dtype=np.float32)
+    lib().gso_reproject_depths_pinhole(C.c_int(d.shape[0]), C.c_int(width), *[C.c_float(x) for x in intr], _p(d), _p(k, np.uint8), _p(out))
+    return out
+
+
+def search_neighborhood_depth(pixels, has3D, p3d, colors, max_pixel_dist, intr, width):
+    px, h, p, c = _f32(pixels), _u8(has3D), _f32(p3d), _f32(colors)
+    out_p, out_c = np.zeros_like(p), np.zeros_like(p)
+    lib().gso_search_neighborhood_depth(C.c_int(px.shape[0]), C.c_int(width), *[C.c_float(x) for x in intr], C.c_float(max_pixel_dist),
+                                        _p(px), _p(h, np.uint8), _p(p), _p(c), _p(out_p), _p(out_c))
+    return out_p, out_c

@@ -42,6 +42,12 @@ SYMBOLS = {
     "segs_debug_preprocess_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,
                                              _vp, _vp, _vp, _vp]),
     "segs_sort_pairs": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "segs_knn_temp_bytes": (_sz, [_i]),
+    "segs_knn_mean_dist2": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "segs_transform_points": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "segs_scale_and_transform_points": (_i, [_i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "segs_reproject_depths_pinhole": (_i, [_i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "segs_search_neighborhood_depth": (_i, [_i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "segs_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, C.c_int64, _f, _i, _vp]),
     "segs_profile_begin": (_i, [C.c_uint]),
     "segs_profile_end": (_i, []),
