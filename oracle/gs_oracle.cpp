@@ -149,11 +149,121 @@ static uint32_t getHigherMsb(uint32_t n) {
   return msb;
 }
 
+
+// ---- spherical harmonics (cuda_rasterizer/auxiliary.h:22-40 constants; glm::vec3 semantics: componentwise,
+// scalar*vec, dot = x*x' + y*y' + z*z' summed left to right, length = sqrt(dot(v,v))) ----
+const float SH_C0 = 0.28209479177387814f;
+const float SH_C1 = 0.4886025119029199f;
+const float SH_C2[] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f };
+const float SH_C3[] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                        -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+struct v3 { float x, y, z; };
+static inline v3 operator+(v3 a, v3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+static inline v3 operator-(v3 a, v3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+static inline v3 operator*(float s, v3 a) { return { s * a.x, s * a.y, s * a.z }; }
+static inline v3 operator*(v3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+static inline v3 operator/(v3 a, float s) { return { a.x / s, a.y / s, a.z / s }; }
+static inline float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float length(v3 a) { return std::sqrt(dot(a, a)); }
+
+// forward.cu:20-71
+static inline v3 computeColorFromSH(int idx, int deg, int max_coeffs, const float* means, const float* campos_, const float* shs,
+                                    uint8_t* clamped) {
+  v3 pos = { means[3 * idx], means[3 * idx + 1], means[3 * idx + 2] };
+  v3 campos = { campos_[0], campos_[1], campos_[2] };
+  v3 dir = pos - campos;
+  dir = dir / length(dir);
+  const v3* sh = reinterpret_cast<const v3*>(shs) + (size_t)idx * max_coeffs;
+  v3 result = SH_C0 * sh[0];
+  if (deg > 0) {
+    float x = dir.x, y = dir.y, z = dir.z;
+    result = result - SH_C1 * y * sh[1] + SH_C1 * z * sh[2] - SH_C1 * x * sh[3];
+    if (deg > 1) {
+      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      result = result + SH_C2[0] * xy * sh[4] + SH_C2[1] * yz * sh[5] + SH_C2[2] * (2.0f * zz - xx - yy) * sh[6] +
+               SH_C2[3] * xz * sh[7] + SH_C2[4] * (xx - yy) * sh[8];
+      if (deg > 2) {
+        result = result + SH_C3[0] * y * (3.0f * xx - yy) * sh[9] + SH_C3[1] * xy * z * sh[10] +
+                 SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[11] + SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12] +
+                 SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[13] + SH_C3[5] * z * (xx - yy) * sh[14] +
+                 SH_C3[6] * x * (xx - 3.0f * yy) * sh[15];
+      }
+    }
+  }
+  result = result + v3{ 0.5f, 0.5f, 0.5f };
+  clamped[3 * idx + 0] = (result.x < 0); clamped[3 * idx + 1] = (result.y < 0); clamped[3 * idx + 2] = (result.z < 0);
+  return { std::max(result.x, 0.0f), std::max(result.y, 0.0f), std::max(result.z, 0.0f) };
+}
+
+// auxiliary.h:109-120
+static inline v3 dnormvdv(v3 v, v3 dv) {
+  float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+  float invsum32 = 1.0f / std::sqrt(sum2 * sum2 * sum2);
+  v3 r;
+  r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+  r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+  r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+  return r;
+}
+
+// backward.cu:20-139; returns the mean-gradient contribution (added to dL_dmeans at :138), writes dL_dsh.
+static inline v3 computeColorFromSH_backward(int idx, int deg, int max_coeffs, const float* means, const float* campos_,
+                                             const float* shs, const uint8_t* clamped, const float* dL_dcolor, float* dL_dshs) {
+  v3 pos = { means[3 * idx], means[3 * idx + 1], means[3 * idx + 2] };
+  v3 campos = { campos_[0], campos_[1], campos_[2] };
+  v3 dir_orig = pos - campos;
+  v3 dir = dir_orig / length(dir_orig);
+  const v3* sh = reinterpret_cast<const v3*>(shs) + (size_t)idx * max_coeffs;
+  v3 dL_dRGB = { dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2] };
+  dL_dRGB.x *= clamped[3 * idx + 0] ? 0 : 1; dL_dRGB.y *= clamped[3 * idx + 1] ? 0 : 1; dL_dRGB.z *= clamped[3 * idx + 2] ? 0 : 1;
+  v3 dRGBdx = { 0, 0, 0 }, dRGBdy = { 0, 0, 0 }, dRGBdz = { 0, 0, 0 };
+  float x = dir.x, y = dir.y, z = dir.z;
+  v3* dL_dsh = reinterpret_cast<v3*>(dL_dshs) + (size_t)idx * max_coeffs;
+  float dRGBdsh0 = SH_C0;
+  dL_dsh[0] = dRGBdsh0 * dL_dRGB;
+  if (deg > 0) {
+    float dRGBdsh1 = -SH_C1 * y, dRGBdsh2 = SH_C1 * z, dRGBdsh3 = -SH_C1 * x;
+    dL_dsh[1] = dRGBdsh1 * dL_dRGB; dL_dsh[2] = dRGBdsh2 * dL_dRGB; dL_dsh[3] = dRGBdsh3 * dL_dRGB;
+    dRGBdx = -SH_C1 * sh[3]; dRGBdy = -SH_C1 * sh[1]; dRGBdz = SH_C1 * sh[2];
+    if (deg > 1) {
+      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      float dRGBdsh4 = SH_C2[0] * xy, dRGBdsh5 = SH_C2[1] * yz, dRGBdsh6 = SH_C2[2] * (2.f * zz - xx - yy);
+      float dRGBdsh7 = SH_C2[3] * xz, dRGBdsh8 = SH_C2[4] * (xx - yy);
+      dL_dsh[4] = dRGBdsh4 * dL_dRGB; dL_dsh[5] = dRGBdsh5 * dL_dRGB; dL_dsh[6] = dRGBdsh6 * dL_dRGB;
+      dL_dsh[7] = dRGBdsh7 * dL_dRGB; dL_dsh[8] = dRGBdsh8 * dL_dRGB;
+      dRGBdx = dRGBdx + (SH_C2[0] * y * sh[4] + SH_C2[2] * 2.f * -x * sh[6] + SH_C2[3] * z * sh[7] + SH_C2[4] * 2.f * x * sh[8]);
+      dRGBdy = dRGBdy + (SH_C2[0] * x * sh[4] + SH_C2[1] * z * sh[5] + SH_C2[2] * 2.f * -y * sh[6] + SH_C2[4] * 2.f * -y * sh[8]);
+      dRGBdz = dRGBdz + (SH_C2[1] * y * sh[5] + SH_C2[2] * 2.f * 2.f * z * sh[6] + SH_C2[3] * x * sh[7]);
+      if (deg > 2) {
+        float dRGBdsh9 = SH_C3[0] * y * (3.f * xx - yy), dRGBdsh10 = SH_C3[1] * xy * z, dRGBdsh11 = SH_C3[2] * y * (4.f * zz - xx - yy);
+        float dRGBdsh12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), dRGBdsh13 = SH_C3[4] * x * (4.f * zz - xx - yy);
+        float dRGBdsh14 = SH_C3[5] * z * (xx - yy), dRGBdsh15 = SH_C3[6] * x * (xx - 3.f * yy);
+        dL_dsh[9] = dRGBdsh9 * dL_dRGB; dL_dsh[10] = dRGBdsh10 * dL_dRGB; dL_dsh[11] = dRGBdsh11 * dL_dRGB;
+        dL_dsh[12] = dRGBdsh12 * dL_dRGB; dL_dsh[13] = dRGBdsh13 * dL_dRGB; dL_dsh[14] = dRGBdsh14 * dL_dRGB;
+        dL_dsh[15] = dRGBdsh15 * dL_dRGB;
+        dRGBdx = dRGBdx + (SH_C3[0] * sh[9] * 3.f * 2.f * xy + SH_C3[1] * sh[10] * yz + SH_C3[2] * sh[11] * -2.f * xy +
+                           SH_C3[3] * sh[12] * -3.f * 2.f * xz + SH_C3[4] * sh[13] * (-3.f * xx + 4.f * zz - yy) +
+                           SH_C3[5] * sh[14] * 2.f * xz + SH_C3[6] * sh[15] * 3.f * (xx - yy));
+        dRGBdy = dRGBdy + (SH_C3[0] * sh[9] * 3.f * (xx - yy) + SH_C3[1] * sh[10] * xz + SH_C3[2] * sh[11] * (-3.f * yy + 4.f * zz - xx) +
+                           SH_C3[3] * sh[12] * -3.f * 2.f * yz + SH_C3[4] * sh[13] * -2.f * xy + SH_C3[5] * sh[14] * -2.f * yz +
+                           SH_C3[6] * sh[15] * -3.f * 2.f * xy);
+        dRGBdz = dRGBdz + (SH_C3[1] * sh[10] * xy + SH_C3[2] * sh[11] * 4.f * 2.f * yz + SH_C3[3] * sh[12] * 3.f * (2.f * zz - xx - yy) +
+                           SH_C3[4] * sh[13] * 4.f * 2.f * xz + SH_C3[5] * sh[14] * (xx - yy));
+      }
+    }
+  }
+  v3 dL_ddir = { dot(dRGBdx, dL_dRGB), dot(dRGBdy, dL_dRGB), dot(dRGBdz, dL_dRGB) };
+  return dnormvdv(dir_orig, dL_ddir);
+}
+// glm: (vec3 * float) as used in the degree-3 derivative sums (sh[9] * 3.f ...)
+
 struct Ctx {
   int P = 0, W = 0, H = 0, R = 0;
   uint32_t gx = 0, gy = 0;
   // GeometryState (cuda_rasterizer/rasterizer_impl.h:30-45)
   std::vector<float> depths, cov3D, rgb;
+  std::vector<uint8_t> clamped;
+  int D = 0, M = 0;
   std::vector<int> radii;
   std::vector<f2> means2D;
   std::vector<f4> conic_opacity;
@@ -166,7 +276,7 @@ struct Ctx {
   std::vector<uint32_t> n_contrib;
   std::vector<float> accum_alpha, out_color;
   // gradients
-  std::vector<float> dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot;
+  std::vector<float> dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, dL_dsh;
 };
 
 // Shared body of preprocessCUDA (forward.cu:155-256) and filter_preprocessCUDA (:259-334).
@@ -294,7 +404,8 @@ void gso_visible_filter(void* h, int P, int W, int H, const float* means3D, cons
 // stage_mask: bit0 preprocess+binning (K1,K5,K7,K8,K9), bit1 render (K10).
 int gso_forward(void* h, int P, const float* bg, int W, int H, const float* means3D, const float* colors,
                 const float* opac, const float* scales, float mod, const float* rots, const float* cov3D_precomp,
-                const float* view, const float* proj, float tan_fovx, float tan_fovy) {
+                const float* view, const float* proj, float tan_fovx, float tan_fovy,
+                const float* shs, int D, int M, const float* campos) {
   Ctx* c = (Ctx*)h;
   c->P = P; c->W = W; c->H = H;
   c->gx = (W + BLOCK_X - 1) / BLOCK_X; c->gy = (H + BLOCK_Y - 1) / BLOCK_Y;
@@ -302,13 +413,21 @@ int gso_forward(void* h, int P, const float* bg, int W, int H, const float* mean
   c->depths.assign(P, 0.f); c->cov3D.assign((size_t)6 * P, 0.f); c->radii.assign(P, 0);
   c->means2D.assign(P, { 0, 0 }); c->conic_opacity.assign(P, { 0, 0, 0, 0 });
   c->tiles_touched.assign(P, 0); c->point_offsets.assign(P, 0);
-  c->rgb.assign(colors, colors + (size_t)3 * P);  // colors_precomp branch (forward.cu:241; rasterizer_impl.cu:321)
+  c->D = D; c->M = M;
+  c->clamped.assign((size_t)3 * P, 0);
+  if (colors) c->rgb.assign(colors, colors + (size_t)3 * P);  // colors_precomp branch (forward.cu:241; rasterizer_impl.cu:321)
+  else c->rgb.assign((size_t)3 * P, 0.f);
 
   // K1 preprocessCUDA
 #pragma omp parallel for schedule(static)
-  for (int i = 0; i < P; i++)
+  for (int i = 0; i < P; i++) {
     c->radii[i] = preprocess_one(c, i, true, means3D, scales, mod, rots, opac, cov3D_precomp, view, proj, W, H,
                                  tan_fovx, tan_fovy, focal_x, focal_y, &c->cov3D[(size_t)6 * i]);
+    if (!colors && c->radii[i] > 0) {  // forward.cu:241-247 (only for Gaussians that passed every reject)
+      v3 col = computeColorFromSH(i, D, M, means3D, campos, shs, c->clamped.data());
+      c->rgb[3 * i] = col.x; c->rgb[3 * i + 1] = col.y; c->rgb[3 * i + 2] = col.z;
+    }
+  }
   // K5 InclusiveSum (rasterizer_impl.cu:276-277) and K6 num_rendered (:281)
   uint32_t run = 0;
   for (int i = 0; i < P; i++) { run += c->tiles_touched[i]; c->point_offsets[i] = run; }
@@ -392,7 +511,8 @@ int gso_forward(void* h, int P, const float* bg, int W, int H, const float* mean
 // (lets a test check the per-Gaussian backward bit-exactly).
 void gso_backward(void* h, const float* bg, const float* means3D, const float* scales, float mod, const float* rots,
                   const float* cov3D_precomp, const float* view, const float* proj, float tan_fovx, float tan_fovy,
-                  const float* dL_dpix, const float* in_dL_dmean2D, const float* in_dL_dconic) {
+                  const float* dL_dpix, const float* in_dL_dmean2D, const float* in_dL_dconic,
+                  const float* shs, const float* campos) {
   Ctx* c = (Ctx*)h;
   const int P = c->P, W = c->W, H = c->H, R = c->R;
   const size_t HW = (size_t)W * H;
@@ -401,6 +521,7 @@ void gso_backward(void* h, const float* bg, const float* means3D, const float* s
   c->dL_dopacity.assign(P, 0.f); c->dL_dcolor.assign((size_t)3 * P, 0.f);
   c->dL_dmean3D.assign((size_t)3 * P, 0.f); c->dL_dcov3D.assign((size_t)6 * P, 0.f);
   c->dL_dscale.assign((size_t)3 * P, 0.f); c->dL_drot.assign((size_t)4 * P, 0.f);
+  c->dL_dsh.assign((size_t)3 * P * std::max(c->M, 0), 0.f);
 
   if (in_dL_dmean2D && in_dL_dconic) {
     std::memcpy(c->dL_dmean2D.data(), in_dL_dmean2D, sizeof(float) * 3 * P);
@@ -565,6 +686,10 @@ void gso_backward(void* h, const float* bg, const float* means3D, const float* s
     dm.y = (proj[4] * m_w - proj[7] * mul1) * gx2 + (proj[5] * m_w - proj[7] * mul2) * gy2;
     dm.z = (proj[8] * m_w - proj[11] * mul1) * gx2 + (proj[9] * m_w - proj[11] * mul2) * gy2;
     c->dL_dmean3D[3 * idx + 0] += dm.x; c->dL_dmean3D[3 * idx + 1] += dm.y; c->dL_dmean3D[3 * idx + 2] += dm.z;
+    if (shs) {  // backward.cu:390-391
+      v3 g = computeColorFromSH_backward(idx, c->D, c->M, means3D, campos, shs, c->clamped.data(), c->dL_dcolor.data(), c->dL_dsh.data());
+      c->dL_dmean3D[3 * idx + 0] += g.x; c->dL_dmean3D[3 * idx + 1] += g.y; c->dL_dmean3D[3 * idx + 2] += g.z;
+    }
     if (scales) {
       f4 rot = { rots[4 * idx], rots[4 * idx + 1], rots[4 * idx + 2], rots[4 * idx + 3] };
       f3 scale = { scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2] };
@@ -625,6 +750,8 @@ GSO_COPY(dL_dmean3D, dL_dmean3D, float)
 GSO_COPY(dL_dcov3D, dL_dcov3D, float)
 GSO_COPY(dL_dscale, dL_dscale, float)
 GSO_COPY(dL_drot, dL_drot, float)
+GSO_COPY(dL_dsh, dL_dsh, float)
+GSO_COPY(rgb, rgb, float)
 
 // Per-pixel instability flags for tolerance tests: bit0 set if any (pixel,Gaussian) decision of the
 // forward walk (power>0, alpha<1/255, test_T<1e-4) lies within `rel` of its threshold, i.e. a

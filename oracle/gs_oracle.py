@@ -61,6 +61,7 @@ class Oracle:
         self._l = lib()
         self._h = C.c_void_p(self._l.gso_create())
         self.P = self.W = self.H = 0
+        self.M = 0
 
     def __del__(self):
         try:
@@ -70,16 +71,18 @@ class Oracle:
 
     # -- CudaRasterizer::Rasterizer::forward (cuda_rasterizer/rasterizer_impl.cu:198-336)
     def forward(self, bg, means3D, colors, opacity, scales, scale_modifier, rotations, viewmatrix, projmatrix,
-                tanfovx, tanfovy, H, W, cov3D_precomp=None) -> int:
+                tanfovx, tanfovy, H, W, cov3D_precomp=None, sh=None, degree=0, campos=None) -> int:
         self._in = dict(bg=_f32(bg), means3D=_f32(means3D), colors=_f32(colors), opacity=_f32(opacity),
                         scales=_f32(scales), rotations=_f32(rotations), view=_f32(viewmatrix), proj=_f32(projmatrix),
-                        cov=_f32(cov3D_precomp), mod=float(scale_modifier), tx=float(tanfovx), ty=float(tanfovy))
+                        cov=_f32(cov3D_precomp), mod=float(scale_modifier), tx=float(tanfovx), ty=float(tanfovy),
+                        sh=_f32(sh), campos=_f32(campos), D=int(degree), M=0 if sh is None else int(np.asarray(sh).shape[1]))
+        self.M = self._in["M"]
         i = self._in
         self.P, self.W, self.H = int(i["means3D"].shape[0]), int(W), int(H)
         R = self._l.gso_forward(self._h, C.c_int(self.P), _p(i["bg"]), C.c_int(W), C.c_int(H), _p(i["means3D"]),
                                 _p(i["colors"]), _p(i["opacity"]), _p(i["scales"]), C.c_float(i["mod"]),
                                 _p(i["rotations"]), _p(i["cov"]), _p(i["view"]), _p(i["proj"]),
-                                C.c_float(i["tx"]), C.c_float(i["ty"]))
+                                C.c_float(i["tx"]), C.c_float(i["ty"]), _p(i["sh"]), C.c_int(i["D"]), C.c_int(i["M"]), _p(i["campos"]))
         self.R = int(R)
         return self.R
 
@@ -90,9 +93,9 @@ class Oracle:
         a, b = _f32(dL_dmean2D_in), _f32(dL_dconic_in)
         self._l.gso_backward(self._h, _p(i["bg"]), _p(i["means3D"]), _p(i["scales"]), C.c_float(i["mod"]),
                              _p(i["rotations"]), _p(i["cov"]), _p(i["view"]), _p(i["proj"]),
-                             C.c_float(i["tx"]), C.c_float(i["ty"]), _p(dL), _p(a), _p(b))
+                             C.c_float(i["tx"]), C.c_float(i["ty"]), _p(dL), _p(a), _p(b), _p(i["sh"]), _p(i["campos"]))
         return {k: self.get(k) for k in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D",
-                                         "dL_dcov3D", "dL_dscale", "dL_drot")}
+                                         "dL_dcov3D", "dL_dscale", "dL_drot", "dL_dsh")}
 
     _SHAPES = {
         "radii": (np.int32, lambda s: (s.P,)), "depths": (np.float32, lambda s: (s.P,)),
@@ -108,6 +111,7 @@ class Oracle:
         "dL_dopacity": (np.float32, lambda s: (s.P, 1)), "dL_dcolor": (np.float32, lambda s: (s.P, 3)),
         "dL_dmean3D": (np.float32, lambda s: (s.P, 3)), "dL_dcov3D": (np.float32, lambda s: (s.P, 6)),
         "dL_dscale": (np.float32, lambda s: (s.P, 3)), "dL_drot": (np.float32, lambda s: (s.P, 4)),
+        "dL_dsh": (np.float32, lambda s: (s.P, s.M, 3)), "rgb": (np.float32, lambda s: (s.P, 3)),
     }
 
     @property

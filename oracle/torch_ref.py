@@ -13,6 +13,34 @@ from __future__ import annotations
 import torch
 
 
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+SH_C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+         1.445305721320277, -0.5900435899266435]
+
+
+def sh_to_rgb(means3D, campos, sh, deg):
+    """Real spherical harmonics up to degree 3 evaluated in the view direction, +0.5, clamped at 0 (written from the
+    standard SH basis; the clamp's zero gradient is torch.clamp's)."""
+    d = means3D - campos[None, :]
+    d = d / d.norm(dim=1, keepdim=True)
+    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    res = SH_C0 * sh[:, 0]
+    if deg > 0:
+        res = res - SH_C1 * y * sh[:, 1] + SH_C1 * z * sh[:, 2] - SH_C1 * x * sh[:, 3]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        res = (res + SH_C2[0] * xy * sh[:, 4] + SH_C2[1] * yz * sh[:, 5] + SH_C2[2] * (2 * zz - xx - yy) * sh[:, 6]
+               + SH_C2[3] * xz * sh[:, 7] + SH_C2[4] * (xx - yy) * sh[:, 8])
+    if deg > 2:
+        res = (res + SH_C3[0] * y * (3 * xx - yy) * sh[:, 9] + SH_C3[1] * xy * z * sh[:, 10]
+               + SH_C3[2] * y * (4 * zz - xx - yy) * sh[:, 11] + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[:, 12]
+               + SH_C3[4] * x * (4 * zz - xx - yy) * sh[:, 13] + SH_C3[5] * z * (xx - yy) * sh[:, 14]
+               + SH_C3[6] * x * (xx - 3 * yy) * sh[:, 15])
+    return torch.clamp(res + 0.5, min=0.0)
+
+
 def render(means3D, scales, rotations, opacity, colors, bg, viewmatrix, projmatrix, tanfovx, tanfovy, H, W,
            radii, means2D_ref, scale_modifier=1.0):
     """All tensor args float64 (requires_grad where wanted); radii int tensor (P,), means2D_ref (P,2).

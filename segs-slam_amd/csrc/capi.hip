@@ -120,20 +120,23 @@ struct Geom {
   int* radii_internal() const { return (int*)(base + L.radii_internal); }
   uint32_t* block_sums() const { return (uint32_t*)(base + L.block_sums); }
   uint32_t* num_rendered() const { return (uint32_t*)(base + L.num_rendered); }
+  uint32_t* clamped() const { return (uint32_t*)(base + L.clamped); }
   float* gacc() const { return (float*)(base + L.gacc); }
 };
 Geom geom_at(char* p, int P) { return Geom{geom_layout(P), align_ptr(p)}; }
 
 int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, const float* colors, const float* opac,
                    const float* scales, float mod, const float* rots, const float* cov3D_precomp, const float* view,
-                   const float* proj, float tan_fovx, float tan_fovy, int* radii, hipStream_t st) {
+                   const float* proj, float tan_fovx, float tan_fovy, int* radii, const float* shs, int D, int M,
+                   const float* cam_pos, hipStream_t st) {
   const float focal_y = H / (2.0f * tan_fovy);   // rasterizer_impl.cu:221-222
   const float focal_x = W / (2.0f * tan_fovx);
   const uint32_t gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
   { PROF(K_PREPROCESS_FWD);
   preprocess_fwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, scales, mod, rots, opac, colors, cov3D_precomp, view,
                                                      proj, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, radii,
-                                                     G.rec(), G.bin(), G.block_sums(), G.block_sums() + (G.L.nblocks + 1));
+                                                     G.rec(), G.bin(), G.block_sums(), G.block_sums() + (G.L.nblocks + 1), shs, D, M, cam_pos,
+                                                     G.clamped());
   }
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
@@ -156,7 +159,7 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                            const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                            int* radii, void* stream, int* num_rendered) {
-  (void)D; (void)M; (void)cam_pos; (void)prefiltered;
+  (void)prefiltered;
   hipStream_t st = (hipStream_t)stream;
   if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(SEGS_ERR_INVALID_ARGUMENT, "null allocator callback");
   if (P < 0 || width <= 0 || height <= 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad P / image size");
@@ -164,8 +167,8 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   if (!background || !out_color || !viewmatrix || !projmatrix || !num_rendered) return fail(SEGS_ERR_INVALID_ARGUMENT, "null required pointer");
   if (P > 0 && (!means3D || !opacities)) return fail(SEGS_ERR_INVALID_ARGUMENT, "null means3D/opacities");
   if (P > 0 && !colors_precomp) {
-    if (shs) return fail(SEGS_ERR_UNSUPPORTED, "SH colour path not built yet: pass colors_precomp (the live SEGS-SLAM renderer always does, src/gaussian_renderer.cpp:86-99)");
-    return fail(SEGS_ERR_INVALID_ARGUMENT, "need colors_precomp");
+    if (!shs || !cam_pos || M <= 0 || D < 0 || (D + 1) * (D + 1) > M || D > 3)
+      return fail(SEGS_ERR_INVALID_ARGUMENT, "need colors_precomp, or shs + cam_pos with (D+1)^2 <= M, D <= 3");
   }
   if (P > 0 && !cov3D_precomp && (!scales || !rotations)) return fail(SEGS_ERR_INVALID_ARGUMENT, "need scales+rotations or cov3D_precomp");
   const uint32_t gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
@@ -184,7 +187,8 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   uint32_t hdr[3] = {0u, 0u, 0u};  // num_rendered, max(~depth_bits), max(depth_bits)
   if (P > 0) {
     int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales,
-                            scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, st);
+                            scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M,
+                            cam_pos, st);
     if (rc) return rc;
     { PROF(K_SCAN);
     scan_block_sums_kernel<<<1, 1024, 0, st>>>(G.block_sums(), G.L.nblocks, G.block_sums() + (G.L.nblocks + 1), G.num_rendered());
@@ -245,11 +249,11 @@ int segs_rasterize_backward(int P, int D, int M, int R, const float* background,
                             float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
                             const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                             float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream) {
-  (void)D; (void)M; (void)campos; (void)dL_dsh; (void)colors_precomp;
+  (void)colors_precomp;
   hipStream_t st = (hipStream_t)stream;
   if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad sizes");
   if (P == 0) return SEGS_OK;  // src/rasterize_points.cu:159
-  if (shs) return fail(SEGS_ERR_UNSUPPORTED, "SH colour path not built yet");
+  if (shs && (!campos || !dL_dsh || M <= 0)) return fail(SEGS_ERR_INVALID_ARGUMENT, "SH path needs campos, dL_dsh and M > 0");
   if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background || !means3D || !viewmatrix || !projmatrix)
     return fail(SEGS_ERR_INVALID_ARGUMENT, "null required pointer");
   if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
@@ -280,7 +284,7 @@ int segs_rasterize_backward(int P, int D, int M, int R, const float* background,
   preprocess_bwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, radii, cov3D_precomp ? nullptr : scales, rotations,
                                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
                                                      tan_fovx, tan_fovy, G.gacc(), G.rec(), (float)width, (float)height, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                                                     dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot);
+                                                     dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, shs, D, M, campos, G.clamped(), dL_dsh);
   }
   LAUNCH_TRY("preprocess_bwd_kernel");
   return SEGS_OK;
@@ -371,7 +375,7 @@ int segs_debug_preprocess_backward(int P, int width, int height, const float* me
                                                          scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
                                                          tan_fovx, tan_fovy, nullptr, nullptr, (float)width, (float)height, const_cast<float*>(dL_dmean2D),
                                                          const_cast<float*>(dL_dconic), nullptr, nullptr, dL_dmean3D, dL_dcov3D,
-                                                         dL_dscale, dL_drot);
+                                                         dL_dscale, dL_drot, nullptr, 0, 0, nullptr, nullptr, nullptr);
   LAUNCH_TRY("preprocess_bwd_kernel");
   return SEGS_OK;
 }
@@ -400,12 +404,12 @@ int segs_project2_image(int P, int D, int M, int width, int height, const float*
                         const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                         const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                         float* points_image, int* radii, void* stream) {
-  (void)D; (void)M; (void)cam_pos; (void)prefiltered;
+  (void)prefiltered;
   hipStream_t st = (hipStream_t)stream;
   if (P < 0 || width <= 0 || height <= 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad sizes");
   if (P == 0) return SEGS_OK;
-  if (shs && !colors_precomp) return fail(SEGS_ERR_UNSUPPORTED, "SH colour path not built yet");
-  if (!means3D || !colors_precomp || !opacities || !viewmatrix || !projmatrix || !out_color || !points_image || !radii)
+  if (!colors_precomp && (!shs || !cam_pos || M <= 0)) return fail(SEGS_ERR_INVALID_ARGUMENT, "need colors_precomp or shs + cam_pos");
+  if (!means3D || !opacities || !viewmatrix || !projmatrix || !out_color || !points_image || !radii)
     return fail(SEGS_ERR_INVALID_ARGUMENT, "null required pointer");
   // scratch: this entry has no allocator callbacks worth keeping (the reference allocates full geometry and
   // image states it then discards); use a stream-ordered temporary.
@@ -415,7 +419,8 @@ int segs_project2_image(int P, int D, int M, int width, int height, const float*
   Geom G = geom_at(raw, P);
   float* tmp = (float*)(align_ptr(raw) + GL.total - ALIGN);  // conic(4P) + depth(P) + tiles(P)
   int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales,
-                          scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, st);
+                          scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M,
+                          cam_pos, st);
   if (rc == SEGS_OK) {
     unpack_geometry_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, G.rec(), G.bin(), radii, points_image, tmp, tmp + (size_t)4 * P,
                                                             (uint32_t*)(tmp + (size_t)5 * P), out_color);

@@ -13,7 +13,8 @@ __global__ void preprocess_fwd_kernel(
     const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy,
     int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
-    uint32_t* __restrict__ depth_range);
+    uint32_t* __restrict__ depth_range, const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos,
+    uint32_t* __restrict__ clamped);
 
 __global__ void visible_filter_kernel(
     int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
@@ -31,7 +32,9 @@ __global__ void preprocess_bwd_kernel(
     const float* __restrict__ gacc, const float* __restrict__ rec_in, float img_w, float img_h,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
-    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot);
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+    const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, const uint32_t* __restrict__ clamped,
+    float* __restrict__ dL_dsh);
 
 // ---- binning.hip
 __global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, const uint32_t* __restrict__ depth_range,

@@ -184,13 +184,121 @@ __device__ __forceinline__ Projected project_gaussian(float3 p, float3 scale, fl
   return o;
 }
 
+
+// ---- spherical harmonics: SH -> RGB (forward.cu:20-71) and its backward (backward.cu:20-139).  Off the live
+// SEGS-SLAM path (the renderer always passes colors_precomp, src/gaussian_renderer.cpp:86-99); kept for API parity.
+// glm::vec3 semantics: componentwise ops, dot summed left to right.
+__device__ const float SH_C0 = 0.28209479177387814f;
+__device__ const float SH_C1 = 0.4886025119029199f;
+__device__ const float SH_C2[] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float SH_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                  -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+struct v3 { float x, y, z; };
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ v3 operator*(float s, v3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ v3 operator/(v3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float length(v3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ v3 ldv3(const float* p) { return {p[0], p[1], p[2]}; }
+
+__device__ v3 sh_to_rgb(int idx, int deg, int max_coeffs, float3 mean, const float* campos_, const float* shs, uint32_t* clamp_bits) {
+  v3 pos = {mean.x, mean.y, mean.z};
+  v3 campos = {campos_[0], campos_[1], campos_[2]};
+  v3 dir = pos - campos;
+  dir = dir / length(dir);
+  const float* shp = shs + (size_t)idx * max_coeffs * 3;
+#define SH(k) ldv3(shp + 3 * (k))
+  v3 result = SH_C0 * SH(0);
+  if (deg > 0) {
+    float x = dir.x, y = dir.y, z = dir.z;
+    result = result - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+    if (deg > 1) {
+      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      result = result + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) + SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+               SH_C2[3] * xz * SH(7) + SH_C2[4] * (xx - yy) * SH(8);
+      if (deg > 2) {
+        result = result + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+                 SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) + SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+                 SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
+                 SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+      }
+    }
+  }
+  result = result + v3{0.5f, 0.5f, 0.5f};
+  *clamp_bits = (result.x < 0 ? 1u : 0u) | (result.y < 0 ? 2u : 0u) | (result.z < 0 ? 4u : 0u);
+  return {fmaxf(result.x, 0.0f), fmaxf(result.y, 0.0f), fmaxf(result.z, 0.0f)};
+}
+
+__device__ __forceinline__ v3 dnormvdv(v3 v, v3 dv) {  // auxiliary.h:109-120
+  float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+  float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+  v3 r;
+  r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+  r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+  r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+  return r;
+}
+
+// returns the contribution to dL_dmean (backward.cu:138); writes the active rows of dL_dsh
+__device__ v3 sh_to_rgb_backward(int idx, int deg, int max_coeffs, float3 mean, const float* campos_, const float* shs,
+                                 uint32_t clamp_bits, v3 dL_dRGB, float* dL_dshs) {
+  v3 pos = {mean.x, mean.y, mean.z};
+  v3 campos = {campos_[0], campos_[1], campos_[2]};
+  v3 dir_orig = pos - campos;
+  v3 dir = dir_orig / length(dir_orig);
+  const float* shp = shs + (size_t)idx * max_coeffs * 3;
+  dL_dRGB.x *= (clamp_bits & 1u) ? 0 : 1; dL_dRGB.y *= (clamp_bits & 2u) ? 0 : 1; dL_dRGB.z *= (clamp_bits & 4u) ? 0 : 1;
+  v3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
+  float x = dir.x, y = dir.y, z = dir.z;
+  float* out = dL_dshs + (size_t)idx * max_coeffs * 3;
+#define ST(k, val) do { const v3 _v = (val); out[3 * (k)] = _v.x; out[3 * (k) + 1] = _v.y; out[3 * (k) + 2] = _v.z; } while (0)
+  float dRGBdsh0 = SH_C0;
+  ST(0, dRGBdsh0 * dL_dRGB);
+  if (deg > 0) {
+    float dRGBdsh1 = -SH_C1 * y, dRGBdsh2 = SH_C1 * z, dRGBdsh3 = -SH_C1 * x;
+    ST(1, dRGBdsh1 * dL_dRGB); ST(2, dRGBdsh2 * dL_dRGB); ST(3, dRGBdsh3 * dL_dRGB);
+    dRGBdx = -SH_C1 * SH(3); dRGBdy = -SH_C1 * SH(1); dRGBdz = SH_C1 * SH(2);
+    if (deg > 1) {
+      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      float dRGBdsh4 = SH_C2[0] * xy, dRGBdsh5 = SH_C2[1] * yz, dRGBdsh6 = SH_C2[2] * (2.f * zz - xx - yy);
+      float dRGBdsh7 = SH_C2[3] * xz, dRGBdsh8 = SH_C2[4] * (xx - yy);
+      ST(4, dRGBdsh4 * dL_dRGB); ST(5, dRGBdsh5 * dL_dRGB); ST(6, dRGBdsh6 * dL_dRGB); ST(7, dRGBdsh7 * dL_dRGB); ST(8, dRGBdsh8 * dL_dRGB);
+      dRGBdx = dRGBdx + (SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8));
+      dRGBdy = dRGBdy + (SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8));
+      dRGBdz = dRGBdz + (SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7));
+      if (deg > 2) {
+        float dRGBdsh9 = SH_C3[0] * y * (3.f * xx - yy), dRGBdsh10 = SH_C3[1] * xy * z, dRGBdsh11 = SH_C3[2] * y * (4.f * zz - xx - yy);
+        float dRGBdsh12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), dRGBdsh13 = SH_C3[4] * x * (4.f * zz - xx - yy);
+        float dRGBdsh14 = SH_C3[5] * z * (xx - yy), dRGBdsh15 = SH_C3[6] * x * (xx - 3.f * yy);
+        ST(9, dRGBdsh9 * dL_dRGB); ST(10, dRGBdsh10 * dL_dRGB); ST(11, dRGBdsh11 * dL_dRGB); ST(12, dRGBdsh12 * dL_dRGB);
+        ST(13, dRGBdsh13 * dL_dRGB); ST(14, dRGBdsh14 * dL_dRGB); ST(15, dRGBdsh15 * dL_dRGB);
+        dRGBdx = dRGBdx + (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
+                           SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                           SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy));
+        dRGBdy = dRGBdy + (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz + SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) +
+                           SH_C3[3] * SH(12) * -3.f * 2.f * yz + SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz +
+                           SH_C3[6] * SH(15) * -3.f * 2.f * xy);
+        dRGBdz = dRGBdz + (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz + SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                           SH_C3[4] * SH(13) * 4.f * 2.f * xz + SH_C3[5] * SH(14) * (xx - yy));
+      }
+    }
+  }
+#undef ST
+#undef SH
+  v3 dL_ddir = {dot(dRGBdx, dL_dRGB), dot(dRGBdy, dL_dRGB), dot(dRGBdz, dL_dRGB)};
+  return dnormvdv(dir_orig, dL_ddir);
+}
+
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ colors,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy,
     int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
-    uint32_t* __restrict__ depth_range /* per workgroup: [b] = max(depth_bits), [nblocks + b] = max(~depth_bits), visible only */) {
+    uint32_t* __restrict__ depth_range /* per workgroup: [b] = max(depth_bits), [nblocks + b] = max(~depth_bits), visible only */,
+    const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, uint32_t* __restrict__ clamped) {
   __shared__ float lds[768];
   __shared__ uint32_t wave_sums[4], wave_dmax[4], wave_dnmin[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -201,7 +309,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     sc = load_row3(scales, P, lds);
     if (idx < P) rot = reinterpret_cast<const float4*>(rotations)[idx];
   }
-  const float3 col = load_row3(colors, P, lds);
+  float3 col = make_float3(0.f, 0.f, 0.f);
+  if (colors) col = load_row3(colors, P, lds);
 
   uint32_t touched = 0, dbits_mine = 0;
   if (idx < P) {
@@ -216,6 +325,12 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       b.rect_max = g.maxx | (g.maxy << 16);
       b.tiles_touched = touched;
       const float op = opacities[idx];
+      if (!colors) {  // forward.cu:241-247
+        uint32_t cb;
+        const v3 c3 = sh_to_rgb(idx, D, M, p, cam_pos, shs, &cb);
+        col = make_float3(c3.x, c3.y, c3.z);
+        clamped[idx] = cb;
+      }
       float4* r4 = reinterpret_cast<float4*>(rec + (size_t)idx * REC_DWORDS);
       // A2/B2/C2: conic pre-scaled so the tile kernels evaluate alpha = o * exp2(A2 dx^2 + B2 dx dy + C2 dy^2)
       r4[0] = make_float4(g.px, g.py, (-0.5f * LOG2E) * g.conic.x, (-LOG2E) * g.conic.y);
@@ -285,7 +400,9 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     const float* __restrict__ gacc, const float* __restrict__ rec_in, float img_w, float img_h,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
-    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+    const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, const uint32_t* __restrict__ clamped,
+    float* __restrict__ dL_dsh) {
   __shared__ float lds[768];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const float3 mean = load_row3(means3D, P, lds);
@@ -294,6 +411,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
   if (idx >= P) return;
 
   float g2x, g2y, gcx, gcy, gcw;
+  float dcol0 = 0.f, dcol1 = 0.f, dcol2 = 0.f;
   if (gacc) {
     // Rows hold raw moments from the tile kernel (render.hip): Mx My Mxx Mxy | Myy S0 Sr Sg | Sb, sums over the
     // (pixel, Gaussian) pairs of w=dL_dG*G times 1, dx, dy, ...; the reference's per-pair terms
@@ -317,6 +435,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcw);
     dL_dopacity[idx] = dop;
     dL_dcolor[3 * (size_t)idx + 0] = a1.z; dL_dcolor[3 * (size_t)idx + 1] = a1.w; dL_dcolor[3 * (size_t)idx + 2] = a8;
+    dcol0 = a1.z; dcol1 = a1.w; dcol2 = a8;
   } else {
     g2x = dL_dmean2D[3 * (size_t)idx + 0]; g2y = dL_dmean2D[3 * (size_t)idx + 1];
     gcx = dL_dconic[4 * (size_t)idx + 0]; gcy = dL_dconic[4 * (size_t)idx + 1]; gcw = dL_dconic[4 * (size_t)idx + 3];
@@ -389,6 +508,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     float dmy = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
     float dmz = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
     out_mean[0] = k12x + dmx; out_mean[1] = k12y + dmy; out_mean[2] = k12z + dmz;  // "dL_dmeans[idx] += dL_dmean" (:387)
+    if (shs && gacc) {  // backward.cu:390-391 (needs the summed dL_dcolor of this Gaussian)
+      const v3 g = sh_to_rgb_backward(idx, D, M, mean, cam_pos, shs, clamped[idx], v3{dcol0, dcol1, dcol2}, dL_dsh);
+      out_mean[0] = out_mean[0] + g.x; out_mean[1] = out_mean[1] + g.y; out_mean[2] = out_mean[2] + g.z;
+    }
     // ---- computeCov3D backward: backward.cu:278-341 (no quaternion-normalisation Jacobian, F5b)
     if (scales) {
       const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
