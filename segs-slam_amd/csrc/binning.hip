@@ -93,72 +93,94 @@ __device__ __forceinline__ bool ellipse_hits_rect(float cx, float cy, float A, f
   return best <= k;
 }
 
-__global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
-    int P, const BinInfo* __restrict__ bin, const float* __restrict__ rec, const uint32_t* __restrict__ block_offsets,
-    uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx) {
+// Inclusive offsets of tiles_touched in DEPTH order (one per sorted slot): block prefix from scan_block_sums_kernel
+// plus an in-workgroup scan.
+__global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
+                                                              const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ incl) {
   __shared__ uint32_t wave_tot[4];
-  __shared__ uint32_t s_excl[4][64];
-  __shared__ uint4 s_bin[4][64];
-  __shared__ float s_geo[4][64][6];  // x, y, A, B, C, k
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int idx = blockIdx.x * 256 + tid;
-  uint4 b = make_uint4(0, 0, 0, 0);
-  if (idx < P) b = reinterpret_cast<const uint4*>(bin)[idx];
-  uint32_t x = b.w;
+  const int slot = blockIdx.x * 256 + tid;
+  uint32_t x = slot < P ? bin[order[slot]].tiles_touched : 0u;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     uint32_t y = __shfl_up(x, off, 64);
     if (lane >= off) x += y;
   }
   if (lane == 63) wave_tot[wv] = x;
-  s_excl[wv][lane] = x - b.w;
-  s_bin[wv][lane] = b;
-  if (b.w != 0u) {
+  __syncthreads();
+  uint32_t base = block_offsets[blockIdx.x];
+  for (int w = 0; w < wv; w++) base += wave_tot[w];
+  if (slot < P) incl[slot] = base + x;
+}
+
+// The emitter is parallel over OUTPUT slots, not over Gaussians: workgroup b owns instances [b*1024, (b+1)*1024) of the
+// unsorted list, finds the Gaussians (in depth order) that own them by binary search in the inclusive offsets, stages
+// those owners once in LDS and lets every lane resolve its slot with an LDS binary search ("load-balanced search").
+// A Gaussian covering thousands of tiles is thereby spread over many workgroups instead of serialising one wave,
+// and all 12-byte pairs leave as coalesced stores.
+constexpr int EMIT_SLOTS = 1024;
+__global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
+    int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec, const uint32_t* __restrict__ order,
+    const uint32_t* __restrict__ incl, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx) {
+  __shared__ uint32_t s_incl[EMIT_SLOTS + 1];
+  __shared__ uint32_t s_idx[EMIT_SLOTS + 1];
+  __shared__ uint4 s_bin[EMIT_SLOTS + 1];
+  __shared__ float s_geo[EMIT_SLOTS + 1][6];  // x, y, A, B, C, k
+  const int tid = threadIdx.x;
+  const uint32_t s0 = blockIdx.x * EMIT_SLOTS, s1 = min((uint32_t)R, s0 + EMIT_SLOTS);
+  // first owner: first g with incl[g] > s0; last owner: first g with incl[g] >= s1   (wave-uniform searches)
+  int lo = 0, hi = P;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (incl[mid] > s0) hi = mid; else lo = mid + 1; }
+  const int g_lo = lo;
+  lo = g_lo; hi = P;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (incl[mid] >= s1) hi = mid; else lo = mid + 1; }
+  const int n_own = min(lo, P - 1) - g_lo + 1;  // <= EMIT_SLOTS: every owner has at least one instance in range
+  const uint32_t excl0 = g_lo == 0 ? 0u : incl[g_lo - 1];
+  for (int k = tid; k < n_own; k += 256) {
+    const uint32_t idx = order[g_lo + k];
+    const uint4 b = reinterpret_cast<const uint4*>(bin)[idx];
+    s_idx[k] = idx; s_incl[k] = incl[g_lo + k]; s_bin[k] = b;
     const float* r = rec + (size_t)idx * REC_DWORDS;
     const float2 xy = *reinterpret_cast<const float2*>(r);
     const float4 q2 = reinterpret_cast<const float4*>(r)[2];  // b, A, B, C
     const float op = r[REC_O];
-    float* g = s_geo[wv][lane];
+    float* g = s_geo[k];
     g[0] = xy.x; g[1] = xy.y; g[2] = q2.y; g[3] = q2.z; g[4] = q2.w;
     g[5] = (op * 255.0f > 1.0f) ? 2.0f * __logf(255.0f * op) * 1.0001f + 1e-3f : -1.0f;
   }
   __syncthreads();
-  uint32_t base = block_offsets[blockIdx.x];
-  for (int w = 0; w < wv; w++) base += wave_tot[w];
-  if (idx < P) point_offsets[idx] = base + x;
-  const uint32_t total = wave_tot[wv];
-  const uint32_t* excl = s_excl[wv];
-  for (uint32_t j0 = 0; j0 < total; j0 += 64) {
-    const uint32_t j = j0 + lane;
-    if (j < total) {
-      // owner = last g with excl[g] <= j  (always has tiles > 0)
-      int g = 0;
 #pragma unroll
-      for (int step = 32; step > 0; step >>= 1) g += (excl[g + step] <= j) ? step : 0;
-      const uint4 bb = s_bin[wv][g];
-      const uint32_t t = j - excl[g];
-      const uint32_t minx = bb.y & 0xFFFFu, miny = bb.y >> 16, w = (bb.z & 0xFFFFu) - minx;
-      uint32_t q = (uint32_t)((float)t / (float)w);
-      if (q * w > t) q--;
-      if ((q + 1) * w <= t) q++;
-      const uint32_t ty = miny + q, tx = minx + (t - q * w);
-      const float* ge = s_geo[wv][g];
-      const float cx = ge[0], cy = ge[1], A = ge[2], B = ge[3], C = ge[4], k = ge[5];
-      uint32_t mask = 0u;
-      if (k > 0.f) {
-        const float fx = (float)(tx * TILE_X), fy = (float)(ty * TILE_Y);
+  for (int it = 0; it < EMIT_SLOTS / 256; it++) {
+    const uint32_t j = s0 + it * 256 + tid;
+    if (j >= s1) break;
+    // owner = first k with s_incl[k] > j
+    int a = 0, b2 = n_own - 1;
+    while (a < b2) { const int mid = (a + b2) >> 1; if (s_incl[mid] > j) b2 = mid; else a = mid + 1; }
+    const int g = a;
+    const uint32_t excl = g == 0 ? excl0 : s_incl[g - 1];
+    const uint4 bb = s_bin[g];
+    const uint32_t t = j - excl;
+    const uint32_t minx = bb.y & 0xFFFFu, miny = bb.y >> 16, w = (bb.z & 0xFFFFu) - minx;
+    uint32_t q = (uint32_t)((float)t / (float)w);
+    if (q * w > t) q--;
+    if ((q + 1) * w <= t) q++;
+    const uint32_t ty = miny + q, tx = minx + (t - q * w);
+    const float* ge = s_geo[g];
+    const float cx = ge[0], cy = ge[1], A = ge[2], B = ge[3], C = ge[4], k = ge[5];
+    uint32_t mask = 0u;
+    if (k > 0.f) {
+      const float fx = (float)(tx * TILE_X), fy = (float)(ty * TILE_Y);
 #pragma unroll
-        for (int qd = 0; qd < 4; qd++) {
-          const float x0 = fx + (float)((qd & 1) * 8), y0 = fy + (float)((qd >> 1) * 8);
-          if (ellipse_hits_rect(cx, cy, A, B, C, k, x0, x0 + 7.f, y0, y0 + 7.f)) mask |= 1u << qd;
-        }
+      for (int qd = 0; qd < 4; qd++) {
+        const float x0 = fx + (float)((qd & 1) * 8), y0 = fy + (float)((qd >> 1) * 8);
+        if (ellipse_hits_rect(cx, cy, A, B, C, k, x0, x0 + 7.f, y0, y0 + 7.f)) mask |= 1u << qd;
       }
-      uint64_t key = (uint64_t)(ty * gx + tx);
-      key <<= 32;
-      key |= (uint64_t)bb.x;
-      keys[base + j] = key;
-      vals[base + j] = (uint32_t)(blockIdx.x * 256 + wv * 64 + g) | (mask << ID_BITS);
     }
+    uint64_t key = (uint64_t)(ty * gx + tx);
+    key <<= 32;
+    key |= (uint64_t)bb.x;
+    keys[j] = key;
+    vals[j] = s_idx[g] | (mask << ID_BITS);
   }
 }
 
@@ -167,9 +189,10 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
 // [dmin, dmin + 2^dbits) covers every depth present (depth bits of positive floats are monotone, so the order,
 // ties included, is exactly that of the reference's 32+bit-bit key); the stored keys stay untouched.  A Replica-like
 // depth range (0.2 m .. 6 m) needs 26 of the 32 depth bits, i.e. 5 byte passes instead of 6 at 1080p.
+// dbits < 0 selects the tile id alone (key >> 32): used for the second, instance-level sort (see capi.hip).
 struct KeyMap { uint32_t dmin; int dbits; };
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, KeyMap km) {
-  const uint64_t kc = ((key >> 32) << km.dbits) | (uint64_t)((uint32_t)key - km.dmin);
+  const uint64_t kc = km.dbits < 0 ? (key >> 32) : (((key >> 32) << km.dbits) | (uint64_t)((uint32_t)key - km.dmin));
   return (uint32_t)(kc >> shift) & 0xFFu;
 }
 
@@ -386,6 +409,56 @@ __global__ void __launch_bounds__(256) unpack_geometry_kernel(
     rgb[3 * (size_t)idx + 0] = vis ? r[REC_R] : 0.f;
     rgb[3 * (size_t)idx + 1] = vis ? r[REC_G] : 0.f;
     rgb[3 * (size_t)idx + 2] = vis ? r[REC_B] : 0.f;
+  }
+}
+
+// Depth-sort input: one (depth bits, idx) pair per Gaussian.  Culled Gaussians (no instances) get a 1 in the tile
+// field, i.e. compacted key 1 << dbits, strictly behind every visible one when sorting dbits + 1 bits.
+__global__ void __launch_bounds__(256) make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, uint32_t dmin,
+                                                              uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const uint4 b = reinterpret_cast<const uint4*>(bin)[i];
+  keys[i] = b.w ? (uint64_t)b.x : ((1ull << 32) | (uint64_t)dmin);
+  vals[i] = (uint32_t)i;
+}
+// Per-workgroup sums of tiles_touched taken in depth order (feeds scan_block_sums_kernel for the emitter).
+__global__ void __launch_bounds__(256) ordered_block_sums_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
+                                                                 uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t wave_sums[4];
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  uint32_t s = slot < P ? bin[order[slot]].tiles_touched : 0u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+}
+// GeometryState::point_offsets (inclusive scan of tiles_touched in index order, rasterizer_impl.cu:276-277).  The
+// pipeline itself no longer needs it (instances are emitted in depth order); produced on request for parity checks.
+__global__ void __launch_bounds__(1024) point_offsets_kernel(int P, const BinInfo* __restrict__ bin, uint32_t* __restrict__ offsets) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < P; base += 1024) {
+    const int i = base + tid;
+    uint32_t x = i < P ? bin[i].tiles_touched : 0u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[wv] = x;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wv; w++) wbase += wave_tot[w];
+    const uint32_t carry = carry_s;
+    if (i < P) offsets[i] = carry + wbase + x;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + x;
+    __syncthreads();
   }
 }
 

@@ -199,8 +199,9 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
     R = (int)hdr[0];
     if (R < 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "num_rendered overflows int32");
   }
-  const BinningLayout BL = binning_layout(R);
-  char* bin_raw = binning_alloc(binning_ctx, BL.total);
+  const BinningLayout BL = binning_layout(R);            // instance-level state (what backward re-parses)
+  const GaussSortLayout GS = gauss_sort_layout(R, P);    // + Gaussian-level depth sort scratch behind it
+  char* bin_raw = binning_alloc(binning_ctx, GS.total);
   if (!bin_raw) return fail(SEGS_ERR_ALLOC, "binning allocator returned null");
   char* bin = align_ptr(bin_raw);
 
@@ -209,29 +210,53 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)gx * gy * sizeof(uint2), st));   // rasterizer_impl.cu:310
   }
   if (R > 0) {
-    // The reference sorts key bits [0, 32+bit) (rasterizer_impl.cu:300-308); the same order is obtained from the
-    // compacted key (tile << dbits) | (depth_bits - dmin), see binning.hip.
+    // The reference sorts all R instances on key bits [0, 32+bit) = (tile | depth) (rasterizer_impl.cu:300-308).
+    // Same order, far less traffic: (1) stable-sort the P GAUSSIANS by depth (P << R), (2) emit instances in that
+    // order, (3) stable-sort the R instances by tile id only.  Ties in (tile, depth) keep increasing Gaussian index in
+    // both formulations, so keys / point_list / ranges are bit-identical.
     const int bit = (int)getHigherMsb(gx * gy);
     const uint32_t dmin = ~hdr[1], dspan = hdr[2] - dmin;
     int dbits = 1;
     while (dbits < 32 && (dspan >> dbits) != 0u) dbits++;
-    const int end_bit = dbits + bit;
-    const int passes = (end_bit + 7) / 8;
-    const int side = passes & 1;
+    // (1)
+    char* gbin = bin + GS.base;
+    const BinningLayout& GL = GS.inner;
+    const int gside = ((dbits + 1 + 7) / 8) & 1;  // dbits depth bits + 1 "culled" bit
     { PROF(K_DUPLICATE);
-    duplicate_with_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), G.rec(), G.block_sums(), G.offsets(),
-                                                            (uint64_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx);
+    make_depth_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), dmin, (uint64_t*)(gbin + GL.keys[gside]), (uint32_t*)(gbin + GL.vals[gside]));
+    }
+    LAUNCH_TRY("make_depth_keys_kernel");
+    int rc = sort_pairs(gbin, GL, P, dbits + 1, dmin, dbits, st);
+    if (rc) return rc;
+    const uint32_t* order = (const uint32_t*)(gbin + GL.vals[0]);
+    // (2)
+    uint32_t* sums2 = (uint32_t*)(bin + GS.block_sums);
+    { PROF(K_SCAN);
+    ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2);
+    }
+    LAUNCH_TRY("ordered_block_sums_kernel");
+    { PROF(K_SCAN);
+    scan_block_sums_kernel<<<1, 1024, 0, st>>>(sums2, G.L.nblocks, G.block_sums() + (G.L.nblocks + 1), sums2 + G.L.nblocks);
+    }
+    LAUNCH_TRY("scan_block_sums_kernel");
+    const int tpasses = (bit + 7) / 8;
+    const int side = tpasses & 1;
+    { PROF(K_SCAN);
+    ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2, G.offsets());
+    }
+    LAUNCH_TRY("ordered_offsets_kernel");
+    { PROF(K_DUPLICATE);
+    duplicate_with_keys_kernel<<<(R + 1023) / 1024, 256, 0, st>>>(P, R, G.bin(), G.rec(), order, G.offsets(),
+                                                                  (uint64_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx);
     }
     LAUNCH_TRY("duplicate_with_keys_kernel");
-    int rc = sort_pairs(bin, BL, R, end_bit, dmin, dbits, st);
+    // (3)
+    rc = sort_pairs(bin, BL, R, bit, 0u, -1, st);
     if (rc) return rc;
     { PROF(K_RANGES);
     identify_tile_ranges_kernel<<<(R + 255) / 256, 256, 0, st>>>(R, (const uint64_t*)(bin + BL.keys[0]), ranges);
     }
     LAUNCH_TRY("identify_tile_ranges_kernel");
-  } else if (P > 0) {
-    // still materialise point_offsets (all zero) for parity with GeometryState::point_offsets
-    HIP_TRY(hipMemsetAsync(G.offsets(), 0, (size_t)P * 4, st));
   }
   { PROF(K_RENDER_FWD);
   render_fwd_kernel<<<dim3(gx, gy), 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(),
@@ -328,7 +353,10 @@ int segs_debug_unpack_geometry(const char* geom_buffer, int P, const int* radii,
   if (!radii) radii = G.radii_internal();
   unpack_geometry_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, G.rec(), G.bin(), radii, means2D, conic_opacity, depths, tiles_touched, rgb);
   LAUNCH_TRY("unpack_geometry_kernel");
-  if (point_offsets) HIP_TRY(hipMemcpyAsync(point_offsets, G.offsets(), (size_t)P * 4, hipMemcpyDeviceToDevice, st));
+  if (point_offsets) {
+    point_offsets_kernel<<<1, 1024, 0, st>>>(P, G.bin(), point_offsets);
+    LAUNCH_TRY("point_offsets_kernel");
+  }
   return SEGS_OK;
 }
 

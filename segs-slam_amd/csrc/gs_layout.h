@@ -94,6 +94,7 @@ struct BinningLayout {
   int R, nblocks;
 };
 // Mirrors BinningState::fromChunk (rasterizer_impl.cu:181-194): ping-pong key/value arrays + sort temp.
+// The same layout (with n = P) is used for the Gaussian-level depth sort; `binning_bytes(R, P)` holds both.
 inline BinningLayout binning_layout(int R) {
   BinningLayout b{};
   b.R = R;
@@ -105,6 +106,18 @@ inline BinningLayout binning_layout(int R) {
   b.digit_totals = o; o = align_up(o + 256 * 4);
   b.total = o + ALIGN;
   return b;
+}
+struct GaussSortLayout {   // appended after the instance-level BinningLayout inside the binning buffer
+  size_t base, block_sums, total;
+  BinningLayout inner;
+};
+inline GaussSortLayout gauss_sort_layout(int R, int P) {
+  GaussSortLayout g{};
+  g.inner = binning_layout(P);
+  g.base = align_up(binning_layout(R).total);
+  g.block_sums = g.base + align_up(g.inner.total);
+  g.total = g.block_sums + align_up((size_t)((P + 255) / 256 + 4) * 4) + ALIGN;
+  return g;
 }
 
 inline char* align_ptr(char* p) { return (char*)(((uintptr_t)p + ALIGN - 1) / ALIGN * ALIGN); }

@@ -39,10 +39,11 @@ __global__ void preprocess_bwd_kernel(
 // ---- binning.hip
 __global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, const uint32_t* __restrict__ depth_range,
                                        uint32_t* __restrict__ total);
-__global__ void duplicate_with_keys_kernel(int P, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
-                                           const uint32_t* __restrict__ block_offsets,
-                                           uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
-                                           uint32_t* __restrict__ vals, uint32_t gx);
+__global__ void ordered_offsets_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
+                                       const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ incl);
+__global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
+                                           const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
+                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx);
 __global__ void radix_count_kernel(const uint64_t* __restrict__ keys, int n, int shift, uint32_t dmin, int dbits,
                                    uint32_t* __restrict__ block_hist, int nblocks);
 __global__ void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_totals);
@@ -66,6 +67,11 @@ __global__ void unpack_geometry_kernel(int P, const float* __restrict__ rec, con
                                        float* __restrict__ conic_opacity, float* __restrict__ depths,
                                        uint32_t* __restrict__ tiles_touched, float* __restrict__ rgb);
 
+__global__ void make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, uint32_t dmin, uint64_t* __restrict__ keys,
+                                       uint32_t* __restrict__ vals);
+__global__ void ordered_block_sums_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
+                                          uint32_t* __restrict__ block_sums);
+__global__ void point_offsets_kernel(int P, const BinInfo* __restrict__ bin, uint32_t* __restrict__ offsets);
 __global__ void strip_mask_kernel(int n, const uint32_t* __restrict__ vals, uint32_t* __restrict__ out);
 
 }  // namespace segs
