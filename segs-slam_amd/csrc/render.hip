@@ -155,6 +155,10 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(
       }
       v_nxt = v_nn;
     }
+#ifndef FWD_UNROLL
+#define FWD_UNROLL 1
+#endif
+#pragma unroll FWD_UNROLL
     for (int k = 0; k < n; k++) {
       const float4 q0 = s_rec[wv][k][0], q1 = s_rec[wv][k][1];
       const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[wv][k][2]);
@@ -311,6 +315,10 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
       }
       wave_lds_fence();
       // ---------------- (1) pixel role
+#ifndef PIX_UNROLL
+#define PIX_UNROLL 1
+#endif
+#pragma unroll PIX_UNROLL
       for (int sl = 0; sl < nb; sl++) {
         const float4 q0 = L.rec[sl][0], q1 = L.rec[sl][1];
         const float2 q2 = *reinterpret_cast<const float2*>(&L.rec[sl][2]);
