@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--workload", default="c2_1080p", help="scene config name (segs_slam_amd.scenes.CONFIGS)")
     ap.add_argument("--mode", default="raster", choices=["raster", "trainer"],
                     help="raster: fwd+bwd raster (+all-reduce); trainer: + L1/SSIM loss (torch ops) and fused Adam")
+    ap.add_argument("--sync-forward", action="store_true",
+                    help="use the reference-shaped forward that blocks on a D2H copy of num_rendered every step "
+                         "(default: resident no-sync entry points after one calibrating step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     args = ap.parse_args()
@@ -76,7 +79,7 @@ def main():
     bg, m3, col, op, sca, rot = t(sc.bg), t(sc.means3D), t(sc.colors), t(sc.opacity), t(sc.scales), t(sc.rotations)
     view, proj, campos = t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center)
     dL = t(sc.dL_dout_color)
-    eng = RasterEngine(sc.P, cam.width, cam.height, dev)
+    eng = RasterEngine(sc.P, cam.width, cam.height, dev, resident=not args.sync_forward)
 
     if args.mode == "trainer":
         from segs_slam_amd.gaussian_trainer import TrainerStep, keyframe_tensors
@@ -125,6 +128,7 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
+        eng.check()
         R = eng.R
         P_vis = int((eng.radii > 0).sum().item())
         gx, gy = (cam.width + 15) // 16, (cam.height + 15) // 16
@@ -154,7 +158,8 @@ def main():
                                    "fwd+bwd raster" + (", RCCL all-reduce of parameter grads" if world > 1 else "")
                                    + (" + L1/SSIM loss + fused Adam" if args.mode == "trainer" else ""),
                        "P": sc.P, "P_visible": P_vis, "num_rendered": R, "width": cam.width, "height": cam.height,
-                       "sort_passes": passes, "parallelism": f"keyframe-dp{world}"},
+                       "sort_passes": passes, "parallelism": f"keyframe-dp{world}",
+                       "forward": "sync (reference API)" if args.sync_forward else "resident (no host sync)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],

@@ -37,7 +37,8 @@ typedef char* (*segs_alloc_fn)(void* ctx, size_t bytes);
 const char* segs_last_error(void);
 
 /* Scratch sizes (reference: CudaRasterizer::required<GeometryState|ImageState|BinningState>,
- * cuda_rasterizer/rasterizer_impl.h:66-72).  For callers that pre-allocate instead of using callbacks. */
+ * cuda_rasterizer/rasterizer_impl.h:66-72).  segs_binning_bytes(n) is also the temp size of segs_sort_pairs(n); the
+ * forward's own binning request (through the callback) additionally covers a P-sized depth sort. */
 size_t segs_geometry_bytes(int P);
 size_t segs_image_bytes(int width, int height);
 size_t segs_binning_bytes(int num_rendered);
@@ -117,6 +118,29 @@ int segs_debug_preprocess_backward(int P, int width, int height, const float* me
  * segs_binning_bytes(n) bytes; results land in keys_out / vals_out. */
 int segs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                     int n, int end_bit, char* temp, void* stream);
+
+/* ---- Resident (steady-state) variants for training loops: NO host synchronisation and a fixed launch sequence
+ * (hipGraph-capturable).  The caller owns all scratch: geom_buffer >= segs_geometry_bytes(P), image_buffer >=
+ * segs_image_bytes(W,H), binning_buffer >= segs_resident_binning_bytes(P, capacity) where `capacity` bounds the number of
+ * (Gaussian, tile) instances.  `status` is 4 device words: [0] = num_rendered R, [3] = 1 if R exceeded the capacity
+ * (outputs of that call are then meaningless; re-run with a larger capacity).  The reference has no counterpart: its
+ * forward always blocks on a device-to-host copy of R (rasterizer_impl.cu:281). */
+size_t segs_resident_binning_bytes(int P, int capacity);
+int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity,
+                                    int P, int D, int M, const float* background, int width, int height,
+                                    const float* means3D, const float* shs, const float* colors_precomp,
+                                    const float* opacities, const float* scales, float scale_modifier,
+                                    const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                                    float* out_color, int* radii, uint32_t* status, void* stream);
+int segs_rasterize_backward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity,
+                                     int P, int D, int M, const float* background, int width, int height,
+                                     const float* means3D, const float* shs, const float* scales, float scale_modifier,
+                                     const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                     const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                                     const int* radii, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                                     float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream);
 
 /* ---- Measurement support (bench.py): per-kernel timing with HIP events recorded on the launch stream.
  * kernel_mask bit i selects kernel id i (ids 0..segs_profile_kernel_count()-1, names via

@@ -32,6 +32,11 @@ SYMBOLS = {
                                      _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     "segs_rasterize_backward": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "segs_resident_binning_bytes": (_sz, [_i, _i]),
+    "segs_rasterize_forward_resident": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp,
+                                              _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "segs_rasterize_backward_resident": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp,
+                                               _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "segs_visible_filter": (_i, [_i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),
     "segs_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "segs_project2_image": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i,

@@ -121,13 +121,16 @@ __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const BinIn
 constexpr int EMIT_SLOTS = 1024;
 __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec, const uint32_t* __restrict__ order,
-    const uint32_t* __restrict__ incl, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx) {
+    const uint32_t* __restrict__ incl, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
+    const uint32_t* __restrict__ n_dev /* resident mode: R lives on the device, `R` is the capacity */) {
   __shared__ uint32_t s_incl[EMIT_SLOTS + 1];
+  if (n_dev) R = (int)min(*n_dev, (uint32_t)R);
   __shared__ uint32_t s_idx[EMIT_SLOTS + 1];
   __shared__ uint4 s_bin[EMIT_SLOTS + 1];
   __shared__ float s_geo[EMIT_SLOTS + 1][6];  // x, y, A, B, C, k
   const int tid = threadIdx.x;
   const uint32_t s0 = blockIdx.x * EMIT_SLOTS, s1 = min((uint32_t)R, s0 + EMIT_SLOTS);
+  if (s0 >= (uint32_t)R) return;
   // first owner: first g with incl[g] > s0; last owner: first g with incl[g] >= s1   (wave-uniform searches)
   int lo = 0, hi = P;
   while (lo < hi) { const int mid = (lo + hi) >> 1; if (incl[mid] > s0) hi = mid; else lo = mid + 1; }
@@ -214,8 +217,10 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {  // number of set bits o
 // Count matrix: block_hist[d * nblocks + b] = number of keys of workgroup b's 4096-key tile with digit d.
 __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const uint64_t* __restrict__ keys, int n, int shift,
                                                                     uint32_t dmin, int dbits,
-                                                                    uint32_t* __restrict__ block_hist, int nblocks) {
+                                                                    uint32_t* __restrict__ block_hist, int nblocks,
+                                                                    const uint32_t* __restrict__ n_dev) {
   const KeyMap km{dmin, dbits};
+  if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   __shared__ uint32_t cnt[4][256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int i = tid; i < 4 * 256; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
@@ -276,8 +281,9 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ 
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int n, int shift, uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist,
-    const uint32_t* __restrict__ digit_totals, int nblocks) {
+    const uint32_t* __restrict__ digit_totals, int nblocks, const uint32_t* __restrict__ n_dev) {
   const KeyMap km{dmin, dbits};
+  if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   __shared__ uint64_t s_keys[SORT_TILE];
   __shared__ uint32_t s_vals[SORT_TILE];
   __shared__ uint32_t cnt[4][256];       // per-wave running digit counters, then per-wave bases
@@ -290,7 +296,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 
   const size_t tile_base = (size_t)blockIdx.x * SORT_TILE;
   const size_t wave_base = tile_base + (size_t)wv * (SORT_TILE / 4);
-  const int nvalid = (int)min((size_t)SORT_TILE, (size_t)n - tile_base);
+  const int nvalid = (size_t)n > tile_base ? (int)min((size_t)SORT_TILE, (size_t)n - tile_base) : 0;
 
   uint64_t key[SORT_ITEMS_PER_THREAD];
   uint32_t val[SORT_ITEMS_PER_THREAD];
@@ -375,7 +381,8 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 // ---------------------------------------------------------------------------------------------
 // K9 (ranges are zeroed by the caller with hipMemsetAsync, as rasterizer_impl.cu:310 does).
 __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ keys,
-                                                                   uint2* __restrict__ ranges) {
+                                                                   uint2* __restrict__ ranges, const uint32_t* __restrict__ n_dev) {
+  if (n_dev) L = (int)min(*n_dev, (uint32_t)L);
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= L) return;
   const uint32_t cur = (uint32_t)(keys[idx] >> 32);

@@ -82,7 +82,8 @@ uint32_t getHigherMsb(uint32_t n) {
 
 // K8: stable LSD radix sort, 8 bits per pass over key bits [0,end_bit).  Input is expected in side
 // `passes & 1` of the ping-pong pair so that the result lands in side 0.
-int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t dmin, int dbits, hipStream_t st) {
+int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t dmin, int dbits, hipStream_t st,
+               const uint32_t* n_dev = nullptr) {
   if (n <= 0) return SEGS_OK;
   const int passes = (end_bit + 7) / 8;
   int side = passes & 1;
@@ -95,7 +96,7 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     uint32_t* vout = (uint32_t*)(bin + L.vals[side ^ 1]);
     const int shift = 8 * p;
     { PROF(K_RADIX_COUNT);
-    radix_count_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, block_hist, L.nblocks);
+    radix_count_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, block_hist, L.nblocks, n_dev);
     }
     LAUNCH_TRY("radix_count_kernel");
     { PROF(K_RADIX_SCAN);
@@ -103,7 +104,8 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     }
     LAUNCH_TRY("radix_scan_kernel");
     { PROF(K_RADIX_SCATTER);
-    radix_scatter_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, block_hist, digit_totals, L.nblocks);
+    radix_scatter_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, block_hist, digit_totals, L.nblocks,
+                                                             n_dev);
     }
     LAUNCH_TRY("radix_scatter_kernel");
     side ^= 1;
@@ -141,6 +143,59 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
 }
+
+// Tile binning (K7, K8, K9).  The reference sorts all R instances on key bits [0, 32+bit) = (tile | depth)
+// (rasterizer_impl.cu:300-308).  Same order, far less traffic: (1) stable-sort the P GAUSSIANS by depth (P << R),
+// (2) emit instances in that order, (3) stable-sort the R instances by tile id only.  Ties in (tile, depth) keep
+// increasing Gaussian index in both formulations, so keys / point_list / ranges are bit-identical.
+// `n_cap` is R (host-known) or, in resident mode, the capacity of the instance arrays with the true R in *n_dev.
+// `total_out` (3 device words) receives the instance count produced by the depth-ordered scan.
+int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSortLayout& GS, uint2* ranges, int P, int n_cap,
+                const uint32_t* n_dev, uint32_t dmin, int dbits, uint32_t gx, uint32_t gy, uint32_t* total_out, hipStream_t st) {
+  const int bit = (int)getHigherMsb(gx * gy);
+  // (1)
+  char* gbin = bin + GS.base;
+  const BinningLayout& GL = GS.inner;
+  const int gside = ((dbits + 1 + 7) / 8) & 1;  // dbits depth bits + 1 "culled" bit
+  { PROF(K_DUPLICATE);
+  make_depth_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), dmin, (uint64_t*)(gbin + GL.keys[gside]), (uint32_t*)(gbin + GL.vals[gside]));
+  }
+  LAUNCH_TRY("make_depth_keys_kernel");
+  int rc = sort_pairs(gbin, GL, P, dbits + 1, dmin, dbits, st);
+  if (rc) return rc;
+  const uint32_t* order = (const uint32_t*)(gbin + GL.vals[0]);
+  // (2)
+  uint32_t* sums2 = (uint32_t*)(bin + GS.block_sums);
+  { PROF(K_SCAN);
+  ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2);
+  }
+  LAUNCH_TRY("ordered_block_sums_kernel");
+  { PROF(K_SCAN);
+  scan_block_sums_kernel<<<1, 1024, 0, st>>>(sums2, G.L.nblocks, G.block_sums() + (G.L.nblocks + 1), total_out);
+  }
+  LAUNCH_TRY("scan_block_sums_kernel");
+  const int tpasses = (bit + 7) / 8;
+  const int side = tpasses & 1;
+  { PROF(K_SCAN);
+  ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2, G.offsets());
+  }
+  LAUNCH_TRY("ordered_offsets_kernel");
+  { PROF(K_DUPLICATE);
+  duplicate_with_keys_kernel<<<(n_cap + 1023) / 1024, 256, 0, st>>>(P, n_cap, G.bin(), G.rec(), order, G.offsets(),
+                                                                    (uint64_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev);
+  }
+  LAUNCH_TRY("duplicate_with_keys_kernel");
+  // (3)
+  rc = sort_pairs(bin, BL, n_cap, bit, 0u, -1, st, n_dev);
+  if (rc) return rc;
+  { PROF(K_RANGES);
+  identify_tile_ranges_kernel<<<(n_cap + 255) / 256, 256, 0, st>>>(n_cap, (const uint64_t*)(bin + BL.keys[0]), ranges, n_dev);
+  }
+  LAUNCH_TRY("identify_tile_ranges_kernel");
+  return SEGS_OK;
+}
+
+__global__ void overflow_flag_kernel(uint32_t* status, uint32_t capacity) { status[3] = status[0] > capacity ? 1u : 0u; }
 
 }  // namespace
 
@@ -210,53 +265,12 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)gx * gy * sizeof(uint2), st));   // rasterizer_impl.cu:310
   }
   if (R > 0) {
-    // The reference sorts all R instances on key bits [0, 32+bit) = (tile | depth) (rasterizer_impl.cu:300-308).
-    // Same order, far less traffic: (1) stable-sort the P GAUSSIANS by depth (P << R), (2) emit instances in that
-    // order, (3) stable-sort the R instances by tile id only.  Ties in (tile, depth) keep increasing Gaussian index in
-    // both formulations, so keys / point_list / ranges are bit-identical.
-    const int bit = (int)getHigherMsb(gx * gy);
     const uint32_t dmin = ~hdr[1], dspan = hdr[2] - dmin;
     int dbits = 1;
     while (dbits < 32 && (dspan >> dbits) != 0u) dbits++;
-    // (1)
-    char* gbin = bin + GS.base;
-    const BinningLayout& GL = GS.inner;
-    const int gside = ((dbits + 1 + 7) / 8) & 1;  // dbits depth bits + 1 "culled" bit
-    { PROF(K_DUPLICATE);
-    make_depth_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), dmin, (uint64_t*)(gbin + GL.keys[gside]), (uint32_t*)(gbin + GL.vals[gside]));
-    }
-    LAUNCH_TRY("make_depth_keys_kernel");
-    int rc = sort_pairs(gbin, GL, P, dbits + 1, dmin, dbits, st);
+    uint32_t* total_scratch = (uint32_t*)(bin + GS.block_sums) + G.L.nblocks;
+    int rc = run_binning(G, bin, BL, GS, ranges, P, R, nullptr, dmin, dbits, gx, gy, total_scratch, st);
     if (rc) return rc;
-    const uint32_t* order = (const uint32_t*)(gbin + GL.vals[0]);
-    // (2)
-    uint32_t* sums2 = (uint32_t*)(bin + GS.block_sums);
-    { PROF(K_SCAN);
-    ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2);
-    }
-    LAUNCH_TRY("ordered_block_sums_kernel");
-    { PROF(K_SCAN);
-    scan_block_sums_kernel<<<1, 1024, 0, st>>>(sums2, G.L.nblocks, G.block_sums() + (G.L.nblocks + 1), sums2 + G.L.nblocks);
-    }
-    LAUNCH_TRY("scan_block_sums_kernel");
-    const int tpasses = (bit + 7) / 8;
-    const int side = tpasses & 1;
-    { PROF(K_SCAN);
-    ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2, G.offsets());
-    }
-    LAUNCH_TRY("ordered_offsets_kernel");
-    { PROF(K_DUPLICATE);
-    duplicate_with_keys_kernel<<<(R + 1023) / 1024, 256, 0, st>>>(P, R, G.bin(), G.rec(), order, G.offsets(),
-                                                                  (uint64_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx);
-    }
-    LAUNCH_TRY("duplicate_with_keys_kernel");
-    // (3)
-    rc = sort_pairs(bin, BL, R, bit, 0u, -1, st);
-    if (rc) return rc;
-    { PROF(K_RANGES);
-    identify_tile_ranges_kernel<<<(R + 255) / 256, 256, 0, st>>>(R, (const uint64_t*)(bin + BL.keys[0]), ranges);
-    }
-    LAUNCH_TRY("identify_tile_ranges_kernel");
   }
   { PROF(K_RENDER_FWD);
   render_fwd_kernel<<<dim3(gx, gy), 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(),
@@ -460,6 +474,67 @@ int segs_project2_image(int P, int D, int M, int width, int height, const float*
   return rc;
 }
 
+
+// ---- Resident (steady-state) variants: no host synchronisation, fixed launch sequence (hipGraph-capturable). ----
+size_t segs_resident_binning_bytes(int P, int capacity) { return gauss_sort_layout(capacity < 0 ? 0 : capacity, P < 0 ? 0 : P).total; }
+
+int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity, int P, int D, int M,
+                                    const float* background, int width, int height, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                                    const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, float* out_color,
+                                    int* radii, uint32_t* status, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (P <= 0 || capacity <= 0 || width <= 0 || height <= 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (P > MAX_GAUSSIANS) return fail(SEGS_ERR_INVALID_ARGUMENT, "P exceeds 2^28 Gaussians");
+  if (!geom_buffer || !binning_buffer || !image_buffer || !status || !background || !out_color || !viewmatrix || !projmatrix ||
+      !means3D || !opacities)
+    return fail(SEGS_ERR_INVALID_ARGUMENT, "null required pointer");
+  if (!colors_precomp && (!shs || !cam_pos || M <= 0 || D < 0 || (D + 1) * (D + 1) > M || D > 3))
+    return fail(SEGS_ERR_INVALID_ARGUMENT, "need colors_precomp, or shs + cam_pos with (D+1)^2 <= M, D <= 3");
+  if (!cov3D_precomp && (!scales || !rotations)) return fail(SEGS_ERR_INVALID_ARGUMENT, "need scales+rotations or cov3D_precomp");
+  const uint32_t gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+  if (gx > 0xFFFFu || gy > 0xFFFFu) return fail(SEGS_ERR_INVALID_ARGUMENT, "image too large for 16-bit tile coordinates");
+  Geom G = geom_at(geom_buffer, P);
+  char* img = align_ptr(image_buffer);
+  char* bin = align_ptr(binning_buffer);
+  const ImageLayout IL = image_layout(width, height);
+  const BinningLayout BL = binning_layout(capacity);
+  const GaussSortLayout GS = gauss_sort_layout(capacity, P);
+  if (!radii) radii = G.radii_internal();
+  int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales, scale_modifier,
+                          rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M, cam_pos, st);
+  if (rc) return rc;
+  uint2* ranges = (uint2*)(img + IL.ranges);
+  { PROF(K_MEMSET);
+  HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)gx * gy * sizeof(uint2), st));
+  }
+  // depth keys are sorted on all 32 bits (+1): the exact range is only known on the device
+  rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, 0u, 32, gx, gy, status, st);
+  if (rc) return rc;
+  overflow_flag_kernel<<<1, 1, 0, st>>>(status, (uint32_t)capacity);
+  LAUNCH_TRY("overflow_flag_kernel");
+  { PROF(K_RENDER_FWD);
+  render_fwd_kernel<<<dim3(gx, gy), 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(), background,
+                                                  (float*)(img + IL.final_T), (uint32_t*)(img + IL.n_contrib), out_color);
+  }
+  LAUNCH_TRY("render_fwd_kernel");
+  return SEGS_OK;
+}
+
+int segs_rasterize_backward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity, int P, int D, int M,
+                                     const float* background, int width, int height, const float* means3D, const float* shs,
+                                     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                     const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                                     float tan_fovy, const int* radii, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
+                                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                                     float* dL_dscale, float* dL_drot, void* stream) {
+  // identical to segs_rasterize_backward except that the scratch layout is keyed by the capacity, not by R
+  return segs_rasterize_backward(P, D, M, capacity, background, width, height, means3D, shs, nullptr, scales, scale_modifier, rotations,
+                                 cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
+                                 image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+                                 dL_dscale, dL_drot, stream);
+}
 
 // ---- measurement support (bench.py): HIP events recorded on the launch stream around selected kernels.
 int segs_profile_begin(unsigned kernel_mask) {

@@ -43,14 +43,17 @@ __global__ void ordered_offsets_kernel(int P, const BinInfo* __restrict__ bin, c
                                        const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ incl);
 __global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
-                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx);
+                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
+                                           const uint32_t* __restrict__ n_dev);
 __global__ void radix_count_kernel(const uint64_t* __restrict__ keys, int n, int shift, uint32_t dmin, int dbits,
-                                   uint32_t* __restrict__ block_hist, int nblocks);
+                                   uint32_t* __restrict__ block_hist, int nblocks, const uint32_t* __restrict__ n_dev);
 __global__ void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_totals);
 __global__ void radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                      uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
-                                     uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_totals, int nblocks);
-__global__ void identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges);
+                                     uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_totals, int nblocks,
+                                     const uint32_t* __restrict__ n_dev);
+__global__ void identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges,
+                                            const uint32_t* __restrict__ n_dev);
 
 // ---- render.hip
 __global__ void render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,

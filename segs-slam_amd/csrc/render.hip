@@ -340,14 +340,24 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
       }
       wave_lds_fence();
       // ---------------- (2) Gaussian role: lane = (part, gs): slot gs, pixels part*16 .. part*16+15
+      // Moments are taken about the quadrant pixel NEAREST to the Gaussian's centre (cx, cy in 0..7), not about the
+      // quadrant corner: for a centre inside the quadrant |gxr - cx| <= 0.5, so the later shift to centre-relative
+      // moments (Mxx = g'^2 S0 - 2 g' S1x + Sxx) subtracts nothing large even for sub-pixel Gaussians.
+      const float2 gxy = *reinterpret_cast<const float2*>(&L.rec[gs][0]);
+      const float gxr = gxy.x - qx0f, gyr = gxy.y - qy0f;
+      const float cx = fminf(7.f, fmaxf(0.f, rintf(gxr))), cy = fminf(7.f, fmaxf(0.f, rintf(gyr)));
+      float px8[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) px8[c] = (float)c - cx;
+      const float pyc0 = pyl0 - cy, pyc1 = pyl1 - cy;
       float S0 = 0.f, S1x = 0.f, S1y = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int p = part * 16 + i;
         const float w = L.wt[gs][p], a = L.at[gs][p];
         const float4 d = L.dp[p];
-        const float pxl = (float)(i & 7);
-        const float pyl = (i >> 3) ? pyl1 : pyl0;
+        const float pxl = px8[i & 7];
+        const float pyl = (i >> 3) ? pyc1 : pyc0;
         const float wx = w * pxl, wy = w * pyl;
         S0 += w; S1x += wx; S1y += wy;
         Sxx += wx * pxl; Sxy += wx * pyl; Syy += wy * pyl;
@@ -365,12 +375,11 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
         const float4 m0 = *reinterpret_cast<const float4*>(&mom[gs][0]);  // S0 S1x S1y Sxx
         const float4 m1 = *reinterpret_cast<const float4*>(&mom[gs][4]);  // Sxy Syy Sr Sg
         const float m8 = mom[gs][8];
-        const float2 gxy = *reinterpret_cast<const float2*>(&L.rec[gs][0]);
-        const float gxr = gxy.x - qx0f, gyr = gxy.y - qy0f;   // dx = gxr - pxl, dy = gyr - pyl
-        const float Mx = gxr * m0.x - m0.y, My = gyr * m0.x - m0.z;
-        const float Mxx = gxr * (gxr * m0.x - 2.f * m0.y) + m0.w;
-        const float Mxy = gxr * (gyr * m0.x - m0.z) - gyr * m0.y + m1.x;
-        const float Myy = gyr * (gyr * m0.x - 2.f * m0.z) + m1.y;
+        const float hx = gxr - cx, hy = gyr - cy;   // dx = hx - pxl', dy = hy - pyl'  (pxl', pyl' relative to (cx, cy))
+        const float Mx = hx * m0.x - m0.y, My = hy * m0.x - m0.z;
+        const float Mxx = hx * (hx * m0.x - 2.f * m0.y) + m0.w;
+        const float Mxy = hx * (hy * m0.x - m0.z) - hy * m0.y + m1.x;
+        const float Myy = hy * (hy * m0.x - 2.f * m0.z) + m1.y;
         wave_lds_fence();
         if (part == 0) {
           *reinterpret_cast<float4*>(&mom[gs][0]) = make_float4(Mx, My, Mxx, Mxy);

@@ -153,7 +153,7 @@ class TrainerStep:
         opt = opt or OptimizationParams()
         P = scene.P
         cam = scene.camera
-        eng = RasterEngine(P, cam.width, cam.height, device)
+        eng = RasterEngine(P, cam.width, cam.height, device, resident=True)
         params_flat = torch.empty(FLOATS_PER_GAUSSIAN * P, dtype=torch.float32, device=device)
         views = split_flat(params_flat, P)
         for name, arr in (("means3D", scene.means3D), ("scales", scene.scales), ("rotations", scene.rotations),

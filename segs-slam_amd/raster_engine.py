@@ -40,9 +40,17 @@ def split_flat(flat: torch.Tensor, P: int):
 
 
 class RasterEngine:
-    """forward()/backward() over resident buffers; one instance per (P, W, H) on one device."""
+    """forward()/backward() over resident buffers; one instance per (P, W, H) on one device.
 
-    def __init__(self, P: int, width: int, height: int, device="cuda:0"):
+    resident=True uses the no-host-sync entry points (segs_rasterize_*_resident): the first forward goes through the
+    synchronising reference-shaped call to learn R, later calls run with capacity = 1.3 R + slack and only read the
+    status words back asynchronously; `check()` (called at the start of the next forward) raises the capacity and
+    reports an overflow if R ever outgrew it."""
+
+    def __init__(self, P: int, width: int, height: int, device="cuda:0", resident: bool = False):
+        self.resident = bool(resident)
+        self.capacity = 0
+        self._status_host = None
         self.P, self.W, self.H = int(P), int(width), int(height)
         self.device = torch.device(device)
         f = dict(dtype=torch.float32, device=self.device)
@@ -61,11 +69,50 @@ class RasterEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    # ---- resident mode plumbing
+    def _setup_resident(self, R: int):
+        self.capacity = int(R * 1.3) + 65536
+        dev = self.device
+        self._geom_r = torch.empty(self._lib.segs_geometry_bytes(self.P), dtype=torch.uint8, device=dev)
+        self._img_r = torch.empty(self._lib.segs_image_bytes(self.W, self.H), dtype=torch.uint8, device=dev)
+        self._bin_r = torch.empty(self._lib.segs_resident_binning_bytes(self.P, self.capacity), dtype=torch.uint8, device=dev)
+        self._status = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._status_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._status_event = torch.cuda.Event()
+        self._status_pending = False
+
+    def check(self):
+        """Resolve the last asynchronous status read-back (resident mode)."""
+        if self.resident and self._status_host is not None and self._status_pending:
+            self._status_event.synchronize()
+            self._status_pending = False
+            self.R = int(self._status_host[0])
+            if int(self._status_host[3]) != 0:
+                need = self.R
+                self.capacity = 0  # next forward re-calibrates through the synchronising path
+                raise RuntimeError(f"resident rasterizer: {need} instances exceeded the capacity; outputs of that step are invalid")
+
     def forward(self, bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
                 scale_modifier: float = 1.0) -> torch.Tensor:
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         for t in (bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos):
             assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+        if self.resident and self.capacity > 0:
+            self.check()
+            st = self._lib.segs_rasterize_forward_resident(
+                p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P, 0, 0, p(bg), self.W, self.H, p(means3D),
+                None, p(colors), p(opacity), p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix),
+                p(campos), float(tanfovx), float(tanfovy), p(self.out_color), p(self.radii), p(self._status), self._stream())
+            _capi.check(st, "segs_rasterize_forward_resident")
+            if not torch.cuda.is_current_stream_capturing():
+                self._status_host.copy_(self._status, non_blocking=True)
+                self._status_event.record(torch.cuda.current_stream(self.device))
+                self._status_pending = True
+            self._last = (bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+                          scale_modifier)
+            self._last_resident = True
+            return self.out_color
+        self._last_resident = False
         n = C.c_int(0)
         st = self._lib.segs_rasterize_forward(
             self.geom.cb, None, self.binning.cb, None, self.img.cb, None, self.P, 0, 0, p(bg), self.W, self.H, p(means3D),
@@ -75,6 +122,8 @@ class RasterEngine:
         self.R = int(n.value)
         self._last = (bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
                       scale_modifier)
+        if self.resident and self.capacity == 0:
+            self._setup_resident(self.R)  # calibrated: later forwards take the no-sync path
         return self.out_color
 
     def backward(self, dL_dout_color: torch.Tensor):
@@ -84,6 +133,15 @@ class RasterEngine:
         assert dL_dout_color.is_contiguous() and dL_dout_color.dtype == torch.float32
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         g = self.grads
+        if getattr(self, "_last_resident", False):
+            st = self._lib.segs_rasterize_backward_resident(
+                p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P, 0, 0, p(bg), self.W, self.H, p(means3D),
+                None, p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix), p(campos),
+                float(tanfovx), float(tanfovy), p(self.radii), p(dL_dout_color), p(self.dL_dmean2D), p(self.dL_dconic),
+                p(g["opacity"]), p(g["colors"]), p(g["means3D"]), p(self.dL_dcov3D), None, p(g["scales"]), p(g["rotations"]),
+                self._stream())
+            _capi.check(st, "segs_rasterize_backward_resident")
+            return g
         st = self._lib.segs_rasterize_backward(
             self.P, 0, 0, self.R, p(bg), self.W, self.H, p(means3D), None, p(colors), p(scales), float(scale_modifier),
             p(rotations), None, p(viewmatrix), p(projmatrix), p(campos), float(tanfovx), float(tanfovy), p(self.radii),

@@ -265,3 +265,31 @@ def test_autograd_module_matches_oracle():
     assert_grad_close("colors", wide.grad[:, :3].cpu().numpy(), ref["dL_dcolor"])
     with pytest.raises(RuntimeError):
         rast(m3, means2D, op, True, True, True, True, False, colors_precomp=col, scales=sca, rotations=rot)
+
+
+def test_resident_engine_matches_sync_path():
+    """The no-host-sync entry points (segs_rasterize_*_resident) give bit-identical images, radii and per-Gaussian
+    backward products as the reference-shaped synchronising call (same kernels, capacity-keyed scratch)."""
+    from segs_slam_amd.raster_engine import RasterEngine
+    sc = scenes.make_scene(30_000, 320, 240, 260.0, 260.0, seed=17, bg=(0.1, 0.2, 0.3))
+    sc.scales *= 2.0
+    cam = sc.camera
+    a = dict(bg=_t(sc.bg), m=_t(sc.means3D), c=_t(sc.colors), o=_t(sc.opacity), s=_t(sc.scales), r=_t(sc.rotations),
+             v=_t(cam.world_view_transform), p=_t(cam.full_proj_transform), cp=_t(cam.camera_center))
+    dL = _t(sc.dL_dout_color)
+    outs = []
+    for resident in (False, True):
+        eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=resident)
+        for it in range(3):  # resident: first call calibrates through the sync path, the rest are no-sync
+            img = eng.forward(a["bg"], a["m"], a["c"], a["o"], a["s"], a["r"], a["v"], a["p"], a["cp"], cam.tanfovx, cam.tanfovy).clone()
+            eng.backward(dL)
+        eng.check()
+        torch.cuda.synchronize()
+        assert (not resident) or (eng.capacity > eng.R > 0 and eng._last_resident)
+        outs.append((img.cpu().numpy(), eng.radii.cpu().numpy(), eng.R, eng.dL_dcov3D.cpu().numpy().copy(),
+                     {k: v.cpu().numpy().copy() for k, v in eng.grads.items()}))
+    (i0, r0, R0, c0, g0), (i1, r1, R1, c1, g1) = outs
+    assert R0 == R1 and np.array_equal(r0, r1) and np.array_equal(i0, i1)
+    # gradients: float atomics are order-dependent -> tolerance, not bits
+    for k in g0:
+        assert_grad_close(k, g1[k], g0[k])
