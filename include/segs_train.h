@@ -12,6 +12,7 @@
  */
 #ifndef SEGS_TRAIN_H_
 #define SEGS_TRAIN_H_
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -29,6 +30,16 @@ typedef struct segs_adam_segment {
 int segs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                    const segs_adam_segment* segments, int nseg,
                    float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad, void* stream);
+
+/* Fused L1 + SSIM loss of the trainer/mapper step and its gradient w.r.t. the rendered image:
+ *     loss = (1 - lambda) * mean|img1 - img2| + lambda * (1 - mean(SSIM(img1, img2)))
+ * (src/gaussian_trainer.cpp:89-90, src/gaussian_mapper.cpp:924-928 with loss_utils::l1_loss / ssim,
+ * include/loss_utils.h:29-32,51-124: 11x11 window, sigma 1.5, zero padding 5, C1 = 1e-4, C2 = 9e-4, mean over all
+ * 3*H*W elements).  img1/img2/dL_dimg1 are (3,H,W) planar fp32; loss_out is 3 device floats {loss, l1, ssim};
+ * temp holds segs_l1_ssim_temp_bytes(H, W) bytes. */
+size_t segs_l1_ssim_temp_bytes(int H, int W);
+int segs_l1_ssim_loss(const float* img1, const float* img2, int H, int W, float lambda_dssim, float* loss_out,
+                      float* dL_dimg1, char* temp, void* stream);
 
 #ifdef __cplusplus
 }

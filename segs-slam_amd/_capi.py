@@ -53,6 +53,8 @@ SYMBOLS = {
     "segs_scale_and_transform_points": (_i, [_i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "segs_reproject_depths_pinhole": (_i, [_i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "segs_search_neighborhood_depth": (_i, [_i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "segs_l1_ssim_temp_bytes": (_sz, [_i, _i]),
+    "segs_l1_ssim_loss": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "segs_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, C.c_int64, _f, _i, _vp]),
     "segs_profile_begin": (_i, [C.c_uint]),
     "segs_profile_end": (_i, []),

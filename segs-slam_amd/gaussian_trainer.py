@@ -76,6 +76,26 @@ class FusedAdam:
         self._capi.check(st, "segs_adam_step")
 
 
+class FusedL1SSIM:
+    """segs_l1_ssim_loss (include/segs_train.h): loss and dL/dimage in two HBM-streaming kernels."""
+
+    def __init__(self, H: int, W: int, device, lambda_dssim: float):
+        from . import _capi
+        self._capi, self._lib = _capi, _capi.lib()
+        self.H, self.W, self.lam = int(H), int(W), float(lambda_dssim)
+        self.temp = torch.empty(self._lib.segs_l1_ssim_temp_bytes(H, W), dtype=torch.uint8, device=device)
+        self.out = torch.zeros(3, dtype=torch.float32, device=device)     # loss, l1, ssim
+        self.dL = torch.empty((3, H, W), dtype=torch.float32, device=device)
+
+    def __call__(self, image: torch.Tensor, gt: torch.Tensor):
+        assert image.is_contiguous() and gt.is_contiguous() and image.shape == (3, self.H, self.W) == gt.shape
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        st = self._lib.segs_l1_ssim_loss(p(image), p(gt), self.H, self.W, self.lam, p(self.out), p(self.dL), p(self.temp),
+                                         C.c_void_p(torch.cuda.current_stream(image.device).cuda_stream))
+        self._capi.check(st, "segs_l1_ssim_loss")
+        return self.out[0], self.dL
+
+
 class TorchAdam:
     """Same arithmetic with torch ops (LibTorch C++ Adam formula); used for CPU tests of the distributed logic."""
 
@@ -122,8 +142,12 @@ class TrainerStep:
         return {"means3D": expon_lr(iteration, o.position_lr_init, o.position_lr_final, o.position_lr_max_steps),
                 "scales": o.scaling_lr, "rotations": o.rotation_lr, "opacity": o.opacity_lr, "colors": o.feature_lr}
 
+    fused_loss = None  # set by on_gpu(): FusedL1SSIM
+
     def loss_and_grad(self, image: torch.Tensor, gt: torch.Tensor):
         """Ll1 and (1-lambda) Ll1 + lambda (1 - SSIM)  (src/gaussian_trainer.cpp:89-90) and its gradient wrt image."""
+        if self.fused_loss is not None:
+            return self.fused_loss(image, gt)
         img = image.detach().requires_grad_(True)
         Ll1 = loss_utils.l1_loss(img, gt)
         loss = (1.0 - self.opt.lambda_dssim) * Ll1 + self.opt.lambda_dssim * (1.0 - loss_utils.ssim(img, gt))
@@ -167,11 +191,19 @@ class TrainerStep:
                                 params["rotations"], view, proj, campos, tanx, tany)
             loss, dL = dL_fn(image)
             eng.backward(dL)
+            if not eng.check(raise_on_overflow=False):
+                # the instance count outgrew the resident capacity (the map changed): redo this keyframe through the
+                # synchronising path, which re-sizes the scratch; gradients are fully overwritten by the second pass
+                image = eng.forward(bg, params["means3D"], params["colors"], params["opacity"], params["scales"],
+                                    params["rotations"], view, proj, campos, tanx, tany)
+                loss, dL = dL_fn(image)
+                eng.backward(dL)
             return loss
 
         step = TrainerStep(params_flat, P, render_backward, FusedAdam(params_flat.numel(), device, opt), opt, eng.grads_flat,
                            process_group)
         step.engine = eng
+        step.fused_loss = FusedL1SSIM(cam.height, cam.width, device, opt.lambda_dssim)
         return step
 
 

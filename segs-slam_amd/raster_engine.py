@@ -71,7 +71,7 @@ class RasterEngine:
 
     # ---- resident mode plumbing
     def _setup_resident(self, R: int):
-        self.capacity = int(R * 1.3) + 65536
+        self.capacity = int(R * 1.5) + 65536
         dev = self.device
         self._geom_r = torch.empty(self._lib.segs_geometry_bytes(self.P), dtype=torch.uint8, device=dev)
         self._img_r = torch.empty(self._lib.segs_image_bytes(self.W, self.H), dtype=torch.uint8, device=dev)
@@ -81,16 +81,20 @@ class RasterEngine:
         self._status_event = torch.cuda.Event()
         self._status_pending = False
 
-    def check(self):
-        """Resolve the last asynchronous status read-back (resident mode)."""
+    def check(self, raise_on_overflow: bool = True) -> bool:
+        """Resolve the last asynchronous status read-back (resident mode).  Returns False (or raises) if the instance
+        count outgrew the capacity: that call's outputs are invalid and the next forward re-calibrates."""
         if self.resident and self._status_host is not None and self._status_pending:
             self._status_event.synchronize()
             self._status_pending = False
             self.R = int(self._status_host[0])
             if int(self._status_host[3]) != 0:
                 need = self.R
-                self.capacity = 0  # next forward re-calibrates through the synchronising path
-                raise RuntimeError(f"resident rasterizer: {need} instances exceeded the capacity; outputs of that step are invalid")
+                self.capacity = 0  # next forward goes through the synchronising path and sizes the scratch anew
+                if raise_on_overflow:
+                    raise RuntimeError(f"resident rasterizer: {need} instances exceeded the capacity; outputs of that step are invalid")
+                return False
+        return True
 
     def forward(self, bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
                 scale_modifier: float = 1.0) -> torch.Tensor:
@@ -98,7 +102,8 @@ class RasterEngine:
         for t in (bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos):
             assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
         if self.resident and self.capacity > 0:
-            self.check()
+            self.check(raise_on_overflow=False)  # an overflow noticed here was already handled by the caller's own check
+        if self.resident and self.capacity > 0:
             st = self._lib.segs_rasterize_forward_resident(
                 p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P, 0, 0, p(bg), self.W, self.H, p(means3D),
                 None, p(colors), p(opacity), p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix),

@@ -102,3 +102,27 @@ def test_trainer_step_reduces_loss():
     losses = [float(step.training_once([kf], [gt])) for _ in range(8)]
     assert losses[-1] < losses[0], losses
     assert all(np.isfinite(losses))
+
+
+@pytest.mark.parametrize("H,W", [(48, 64), (37, 53), (680, 1200)])
+def test_fused_l1_ssim_matches_loss_utils(H, W):
+    """Fused HIP loss (forward value, L1, SSIM and dL/dimage) vs the reference's op chain (loss_utils mirror + autograd)."""
+    from segs_slam_amd import loss_utils
+    from segs_slam_amd.gaussian_trainer import FusedL1SSIM
+    gen = torch.Generator().manual_seed(H * W)
+    gt = torch.rand(3, H, W, generator=gen).to(DEV)
+    img = (gt + 0.2 * torch.randn(3, H, W, generator=gen).to(DEV)).clamp(0, 1).contiguous()
+    img[:, : H // 4] = gt[:, : H // 4]  # exact-equality region: sign(0) = 0 in the L1 gradient
+    lam = 0.2
+    fused = FusedL1SSIM(H, W, DEV, lam)
+    loss, dL = fused(img, gt)
+    x = img.clone().requires_grad_(True)
+    l1 = loss_utils.l1_loss(x, gt)
+    ss = loss_utils.ssim(x, gt)
+    ref = (1.0 - lam) * l1 + lam * (1.0 - ss)
+    (g,) = torch.autograd.grad(ref, x)
+    torch.cuda.synchronize()
+    assert abs(float(fused.out[1]) - float(l1)) < 1e-6 and abs(float(fused.out[2]) - float(ss)) < 2e-6
+    assert abs(float(loss) - float(ref)) < 2e-6
+    err = (dL - g).abs().max().item()
+    assert err <= 2e-5 * g.abs().max().item() + 1e-12, (err, g.abs().max().item())
