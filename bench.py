@@ -22,14 +22,16 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 
 
-def algorithmic_bytes(P, P_vis, R, W, H, passes):
-    """algorithmic bytes per kernel of one fwd+bwd raster."""
+def algorithmic_bytes(P, P_vis, R, W, H, passes_depth, passes_tile):
+    """algorithmic bytes per kernel of one fwd+bwd raster.  The sort line is this design's
+    two-level sort (P depth keys, then R tile keys; per pass: count reads the 8-B key, scatter reads and writes the
+    12-B key+value pair), which moves fewer bytes than the reference's (8+24*passes)*R single 64-bit sort."""
     T = ((W + 15) // 16) * ((H + 15) // 16)
     return {
         "preprocess_fwd_kernel": 104 * P_vis + 8 * (P - P_vis),
         "scan_block_sums_kernel": 8 * P,
         "duplicate_with_keys_kernel": 20 * P + 12 * R,
-        "radix_sort(all passes)": (8 + 24 * passes) * R,
+        "radix_sort(all passes)": 32 * (passes_depth * P + passes_tile * R),
         "identify_tile_ranges_kernel": 8 * R + 8 * T,
         "render_fwd_kernel": 40 * R + 20 * W * H,
         "render_bwd_kernel": 40 * R + 20 * W * H + 36 * R,
@@ -146,11 +148,13 @@ def main():
         R = eng.R
         P_vis = int((eng.radii > 0).sum().item())
         gx, gy = (cam.width + 15) // 16, (cam.height + 15) // 16
-        bit = max(1, int(gx * gy).bit_length())
-        passes = (32 + bit + 7) // 8
-        ab = algorithmic_bytes(sc.P, P_vis, R, cam.width, cam.height, passes)
+        passes_tile = (max(1, int(gx * gy - 1).bit_length()) + 7) // 8
+        passes = int(round(breakdown.get("radix_scatter_kernel", {"launches": 0})["launches"] / max(args.warmup, 1)))
+        passes_depth = max(passes - passes_tile, 0)
+        ab = algorithmic_bytes(sc.P, P_vis, R, cam.width, cam.height, passes_depth, passes_tile)
         dom = prof_dom.result[dominant]
-        dom_bytes = ab[dominant] if dominant in ab else ab["radix_sort(all passes)"] / (3 * passes)
+        dom_bytes = ab[dominant] if dominant in ab else ab["radix_sort(all passes)"] / (3 * max(passes, 1))
+        traffic, traffic_src = pmc_traffic(args.workload, dominant) if args.mode == "raster" else (None, None)
         achieved = dom_bytes / (dom["avg_ms"] * 1e-3) / 1e9
         total_bytes = sum(ab.values())
         ms_per_step = elapsed / args.steps * 1e3
@@ -172,10 +176,10 @@ def main():
                                    "fwd+bwd raster" + (", RCCL all-reduce of parameter grads" if world > 1 else "")
                                    + (" + L1/SSIM loss + fused Adam" if args.mode == "trainer" else ""),
                        "P": sc.P, "P_visible": P_vis, "num_rendered": R, "width": cam.width, "height": cam.height,
-                       "sort_passes": passes, "parallelism": f"keyframe-dp{world}",
+                       "sort_passes": {"depth_keys_P": passes_depth, "tile_keys_R": passes_tile}, "parallelism": f"keyframe-dp{world}",
                        "forward": "sync (reference API)" if args.sync_forward else "resident (no host sync)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
                          "note": "tile kernels are VALU-bound, not HBM-bound (SURVEY 8d); see DESIGN.md"},
             "raster": {"algorithmic_bytes": total_bytes, "kernel_ms_sum": raster_ms,
@@ -191,6 +195,22 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE and
+    WRITE_SIZE need separate passes, so they cannot be collected inside the timed run): profiles/rNN_pmc_<workload>.json,
+    written by tools/collect_profiles.sh + tools/pmc_summary.py (FETCH_SIZE doubled per the gfx950 correction)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{workload}.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        tab = json.load(f)
+    e = tab.get("segs::" + kernel)
+    if not e or "hbm_bytes" not in e:
+        return None, None
+    return e["hbm_bytes"], os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(sc):
