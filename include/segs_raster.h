@@ -36,6 +36,14 @@ typedef char* (*segs_alloc_fn)(void* ctx, size_t bytes);
 /* Human-readable text for the last non-zero status returned on this thread. */
 const char* segs_last_error(void);
 
+/* Behaviour switches of the forward entry points, per host thread; returns the previous value.
+ * SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY: a Gaussian whose opacity is <= 0 is treated as absent (radius 0, not binned).
+ * Such a Gaussian never contributes (alpha >= 1/255 is impossible), so image and gradients are unchanged; only `radii`
+ * and R differ.  Used with segs_neural_forward's candidate-domain outputs (segs_neural.h), where it stands for the
+ * reference's boolean-mask compaction in front of the rasterizer (src/gaussian_renderer.cpp:320). */
+#define SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY 1u
+uint32_t segs_raster_set_flags(uint32_t flags);
+
 /* Scratch sizes (reference: CudaRasterizer::required<GeometryState|ImageState|BinningState>,
  * cuda_rasterizer/rasterizer_impl.h:66-72).  segs_binning_bytes(n) is also the temp size of segs_sort_pairs(n); the
  * forward's own binning request (through the callback) additionally covers a P-sized depth sort. */

@@ -17,6 +17,12 @@ LIB_PATH = os.path.join(CSRC, "libsegs_raster.so")
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 
+class NeuralDims(C.Structure):
+    """segs_neural_dims (include/segs_neural.h)."""
+    _fields_ = [("feat_dim", C.c_int), ("n_offsets", C.c_int), ("appearance_dim", C.c_int), ("use_feat_bank", C.c_int),
+                ("add_opacity_dist", C.c_int), ("add_cov_dist", C.c_int), ("add_color_dist", C.c_int)]
+
+
 class AdamSegment(C.Structure):
     """segs_adam_segment (include/segs_train.h)."""
     _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("lr", C.c_float)]
@@ -25,6 +31,11 @@ class AdamSegment(C.Structure):
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
     "segs_last_error": (C.c_char_p, []),
+    "segs_raster_set_flags": (C.c_uint, [C.c_uint]),
+    "segs_neural_param_layout": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "segs_neural_temp_bytes": (_sz, [_vp, _i]),
+    "segs_neural_forward": (_i, [_vp, _i] + [_vp] * 16),
+    "segs_neural_backward": (_i, [_vp, _i] + [_vp] * 19),
     "segs_geometry_bytes": (_sz, [_i]),
     "segs_image_bytes": (_sz, [_i, _i]),
     "segs_binning_bytes": (_sz, [_i]),

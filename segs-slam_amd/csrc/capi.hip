@@ -18,6 +18,7 @@ using namespace segs;
 namespace {
 
 thread_local std::string g_err;
+thread_local uint32_t g_flags = 0u;   // segs_raster_set_flags
 
 int fail(int code, const char* what) {
   g_err = what;
@@ -138,7 +139,7 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
   preprocess_fwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, scales, mod, rots, opac, colors, cov3D_precomp, view,
                                                      proj, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, radii,
                                                      G.rec(), G.bin(), G.block_sums(), G.block_sums() + (G.L.nblocks + 1), shs, D, M, cam_pos,
-                                                     G.clamped());
+                                                     G.clamped(), g_flags);
   }
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
@@ -202,6 +203,12 @@ __global__ void overflow_flag_kernel(uint32_t* status, uint32_t capacity) { stat
 extern "C" {
 
 const char* segs_last_error(void) { return g_err.c_str(); }
+
+uint32_t segs_raster_set_flags(uint32_t flags) {
+  const uint32_t old = g_flags;
+  g_flags = flags;
+  return old;
+}
 
 size_t segs_geometry_bytes(int P) { return geom_layout(P < 0 ? 0 : P).total; }
 size_t segs_image_bytes(int width, int height) { return image_layout(width, height).total; }

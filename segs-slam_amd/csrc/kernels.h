@@ -14,7 +14,7 @@ __global__ void preprocess_fwd_kernel(
     int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy,
     int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
     uint32_t* __restrict__ depth_range, const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos,
-    uint32_t* __restrict__ clamped);
+    uint32_t* __restrict__ clamped, uint32_t flags);
 
 __global__ void visible_filter_kernel(
     int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,

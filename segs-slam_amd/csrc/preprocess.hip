@@ -298,7 +298,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy,
     int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
     uint32_t* __restrict__ depth_range /* per workgroup: [b] = max(depth_bits), [nblocks + b] = max(~depth_bits), visible only */,
-    const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, uint32_t* __restrict__ clamped) {
+    const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, uint32_t* __restrict__ clamped,
+    uint32_t flags) {
   __shared__ float lds[768];
   __shared__ uint32_t wave_sums[4], wave_dmax[4], wave_dnmin[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -316,6 +317,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   if (idx < P) {
     Projected g = project_gaussian(p, sc, mod, rot, cov3D_precomp ? cov3D_precomp + (size_t)6 * idx : nullptr,
                                    viewmatrix, projmatrix, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy);
+    // SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY: such a Gaussian can never pass alpha >= 1/255; dropping it here equals
+    // the reference's compaction of masked-out neural Gaussians before the rasterizer (gaussian_renderer.cpp:320)
+    if ((flags & 1u) && !(opacities[idx] > 0.f)) g.radius = 0;
     BinInfo b{0u, 0u, 0u, 0u};
     if (g.radius > 0) {
       touched = (g.maxy - g.miny) * (g.maxx - g.minx);

@@ -1,0 +1,325 @@
+"""Scaffold-GS anchors -> neural Gaussians on the GPU, and the anchor-level trainer step around it.
+
+Host mirror of GaussianRenderer::generate_neural_gaussians / render / prefilter_voxel (src/gaussian_renderer.cpp:214-334,
+21-129, 131-199) and of the anchor-level loop body of GaussianTrainer::trainingOnce (src/gaussian_trainer.cpp:47-117) /
+GaussianMapper::trainForOneIteration (src/gaussian_mapper.cpp:823-1032) over the C ABI of include/segs_neural.h.
+No CPU fallback: everything here needs the HIP library.
+
+All trainable state of the model (the reference's Adam groups 0-2, 4, 6-8, 10, 11: anchor, offset, anchor_feat,
+scaling, the MLPs) lives in ONE flat fp32 bucket with a same-shaped gradient bucket: the operand of the fused Adam and
+of the keyframe-parallel all-reduce.  `_opacity` and `_rotation` (groups 3, 5) never receive a gradient
+ and are kept outside the bucket.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _capi
+from .gaussian_trainer import FusedL1SSIM, expon_lr
+from .raster_engine import RasterEngine
+
+
+@dataclass
+class ModelDims:
+    """Model.* keys of cfg/gaussian_mapper/RGB-D/Replica/office0.yaml:13-26 that shape the MLPs."""
+    feat_dim: int = 32
+    n_offsets: int = 10
+    appearance_dim: int = 32
+    use_feat_bank: bool = True
+    add_opacity_dist: bool = False
+    add_cov_dist: bool = False
+    add_color_dist: bool = False
+
+    def c_struct(self) -> _capi.NeuralDims:
+        return _capi.NeuralDims(self.feat_dim, self.n_offsets, self.appearance_dim, int(self.use_feat_bank),
+                                int(self.add_opacity_dist), int(self.add_cov_dist), int(self.add_color_dist))
+
+    def mlp_tensor_names(self) -> List[str]:
+        names = []
+        for m in ("mlp_opacity", "mlp_cov", "mlp_color"):
+            names += [f"{m}.0.weight", f"{m}.0.bias", f"{m}.2.weight", f"{m}.2.bias"]
+        if self.appearance_dim > 0:
+            names += ["mlp_apperance.0.weight", "mlp_apperance.0.bias"]
+        if self.use_feat_bank:
+            names += [f"mlp_feature_bank.{k}" for k in ("0.weight", "0.bias", "2.weight", "2.bias")]
+        return names
+
+    def mlp_tensor_shape(self, name: str) -> Tuple[int, ...]:
+        fd, no = self.feat_dim, self.n_offsets
+        m, layer, kind = name.split(".")
+        if m == "mlp_apperance":
+            return (self.appearance_dim, 7) if kind == "weight" else (self.appearance_dim,)
+        if m == "mlp_feature_bank":
+            out, inn = (fd, 4) if layer == "0" else (3, fd)
+        else:
+            extra = {"mlp_opacity": int(self.add_opacity_dist), "mlp_cov": int(self.add_cov_dist),
+                     "mlp_color": int(self.add_color_dist) + self.appearance_dim}[m]
+            nout = {"mlp_opacity": no, "mlp_cov": 7 * no, "mlp_color": 3 * no}[m]
+            out, inn = (fd, fd + 3 + extra) if layer == "0" else (nout, fd)
+        return (out, inn) if kind == "weight" else (out,)
+
+
+@dataclass
+class ScaffoldOptimizationParams:
+    """Optimization.* of cfg/gaussian_mapper/RGB-D/Replica/office0.yaml:76-137 used by the step."""
+    lambda_dssim: float = 0.2
+    position_lr_init: float = 0.0
+    position_lr_final: float = 0.0
+    position_lr_max_steps: int = 30000
+    offset_lr_init: float = 0.08
+    offset_lr_final: float = 0.0001
+    offset_lr_max_steps: int = 30000
+    feature_lr: float = 0.0010
+    scaling_lr: float = 0.005
+    mlp_opacity_lr_init: float = 0.002
+    mlp_opacity_lr_final: float = 0.00002
+    mlp_opacity_lr_max_steps: int = 30000
+    mlp_cov_lr_init: float = 0.004
+    mlp_cov_lr_final: float = 0.004
+    mlp_cov_lr_max_steps: int = 30000
+    mlp_color_lr_init: float = 0.008
+    mlp_color_lr_final: float = 0.00005
+    mlp_color_lr_max_steps: int = 30000
+    mlp_featurebank_lr_init: float = 0.01
+    mlp_featurebank_lr_final: float = 0.00001
+    mlp_featurebank_lr_max_steps: int = 30000
+    appearance_lr_init: float = 0.05
+    appearance_lr_final: float = 0.0005
+    appearance_lr_max_steps: int = 30000
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-15
+
+
+_p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+
+
+class ScaffoldModel:
+    """Anchors + MLPs in one flat parameter bucket (and a same-shaped gradient bucket) on `device`."""
+
+    ANCHOR_FIELDS = (("anchor", 3), ("offset", None), ("anchor_feat", None), ("scaling", 6))
+
+    def __init__(self, A: int, dims: ModelDims, device):
+        self.A, self.dims, self.device = int(A), dims, torch.device(device)
+        self._lib = _capi.lib()
+        self._cdims = dims.c_struct()
+        offs = (C.c_int64 * 18)()
+        cnts = (C.c_int64 * 18)()
+        nt, total = C.c_int(0), C.c_int64(0)
+        _capi.check(self._lib.segs_neural_param_layout(C.byref(self._cdims), offs, cnts, C.byref(nt), C.byref(total)),
+                    "segs_neural_param_layout")
+        names = dims.mlp_tensor_names()
+        assert nt.value == len(names)
+        self.mlp_total = int(total.value)
+        widths = {"anchor": 3, "offset": 3 * dims.n_offsets, "anchor_feat": dims.feat_dim, "scaling": 6}
+        self.segments: Dict[str, Tuple[int, int]] = {}
+        pos = 0
+        for name in ("anchor", "offset", "anchor_feat", "scaling"):
+            self.segments[name] = (pos, self.A * widths[name])
+            pos += self.A * widths[name]
+        self.mlp_offset = pos
+        self.n_params = pos + self.mlp_total
+        f = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(self.n_params, **f)
+        self.grads = torch.zeros(self.n_params, **f)
+        self.mlp_layout = {n: (pos + int(offs[i]), int(cnts[i])) for i, n in enumerate(names)}
+        self.rotation = torch.zeros((self.A, 4), **f)   # _rotation: identity quaternion, never trained
+        self.rotation[:, 0] = 1.0
+        self.opacity = torch.zeros((self.A, 1), **f)    # _opacity: unused by the forward
+
+    # -- views
+    def _view(self, bucket, name):
+        if name in self.segments:
+            o, n = self.segments[name]
+            shape = {"anchor": (self.A, 3), "offset": (self.A, self.dims.n_offsets, 3),
+                     "anchor_feat": (self.A, self.dims.feat_dim), "scaling": (self.A, 6)}[name]
+            return bucket[o:o + n].view(shape)
+        o, n = self.mlp_layout[name]
+        return bucket[o:o + n].view(self.dims.mlp_tensor_shape(name))
+
+    def param(self, name):
+        return self._view(self.params, name)
+
+    def grad(self, name):
+        return self._view(self.grads, name)
+
+    @property
+    def mlp_params(self):
+        return self.params[self.mlp_offset:]
+
+    @property
+    def mlp_grads(self):
+        return self.grads[self.mlp_offset:]
+
+    def load(self, anchor, offset, anchor_feat, scaling_log, mlp: Dict[str, torch.Tensor]):
+        for name, t in (("anchor", anchor), ("offset", offset), ("anchor_feat", anchor_feat), ("scaling", scaling_log)):
+            self.param(name).copy_(t.to(self.device, torch.float32))
+        for name in self.dims.mlp_tensor_names():
+            self.param(name).copy_(mlp[name].to(self.device, torch.float32))
+
+    def adam_groups(self, lrs: Dict[str, float]) -> List[Tuple[int, int, float]]:
+        """(offset, count, lr) per Adam group in the reference's order (src/gaussian_model.cpp:632-690)."""
+        out = [(*self.segments["anchor"], lrs["anchor"]), (*self.segments["offset"], lrs["offset"]),
+               (*self.segments["anchor_feat"], lrs["anchor_feat"]), (*self.segments["scaling"], lrs["scaling"])]
+        for m, key in (("mlp_opacity", "mlp_opacity"), ("mlp_cov", "mlp_cov"), ("mlp_color", "mlp_color"),
+                       ("mlp_apperance", "appearance"), ("mlp_feature_bank", "mlp_featurebank")):
+            names = [n for n in self.mlp_layout if n.startswith(m + ".")]
+            if names:
+                o = self.mlp_layout[names[0]][0]
+                out.append((o, sum(self.mlp_layout[n][1] for n in names), lrs[key]))
+        return out
+
+
+class NeuralGaussians:
+    """segs_neural_forward / segs_neural_backward over resident candidate-domain buffers (A * n_offsets rows)."""
+
+    def __init__(self, model: ScaffoldModel):
+        self.model = model
+        A, no, dev = model.A, model.dims.n_offsets, model.device
+        self._lib = model._lib
+        f = dict(dtype=torch.float32, device=dev)
+        self.P = A * no
+        self.means3D = torch.zeros((self.P, 3), **f)
+        self.colors = torch.zeros((self.P, 3), **f)
+        self.opacity = torch.zeros((self.P, 1), **f)
+        self.scales = torch.zeros((self.P, 3), **f)
+        self.rotations = torch.zeros((self.P, 4), **f)
+        self.neural_opacity = torch.zeros((self.P, 1), **f)
+        self.temp = torch.empty(self._lib.segs_neural_temp_bytes(C.byref(model._cdims), A), dtype=torch.uint8, device=dev)
+        self._last = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.model.device).cuda_stream)
+
+    def forward(self, camera_center: torch.Tensor, pose7: torch.Tensor, visible_radii: Optional[torch.Tensor]):
+        m = self.model
+        st = self._lib.segs_neural_forward(
+            C.byref(m._cdims), m.A, _p(m.param("anchor")), _p(m.param("offset")), _p(m.param("anchor_feat")),
+            _p(m.param("scaling")), _p(visible_radii), _p(m.mlp_params), _p(camera_center), _p(pose7), _p(self.means3D),
+            _p(self.colors), _p(self.opacity), _p(self.scales), _p(self.rotations), _p(self.neural_opacity), _p(self.temp),
+            self._stream())
+        _capi.check(st, "segs_neural_forward")
+        self._last = (camera_center, pose7)
+        return self.means3D, self.colors, self.opacity, self.scales, self.rotations
+
+    def mask(self):
+        """The reference's `mask` (neural_opacity > 0, src/gaussian_renderer.cpp:279) in the candidate domain."""
+        return self.neural_opacity.view(-1) > 0
+
+    def backward(self, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations):
+        """Accumulates into model.grads."""
+        m = self.model
+        camera_center, pose7 = self._last
+        st = self._lib.segs_neural_backward(
+            C.byref(m._cdims), m.A, _p(m.param("anchor")), _p(m.param("offset")), _p(m.param("anchor_feat")),
+            _p(m.param("scaling")), _p(m.mlp_params), _p(camera_center), _p(pose7), _p(dL_dmeans3D), _p(dL_dcolors),
+            _p(dL_dopacity), _p(dL_dscales), _p(dL_drotations), _p(m.grad("anchor")), _p(m.grad("offset")),
+            _p(m.grad("anchor_feat")), _p(m.grad("scaling")), _p(m.mlp_grads), _p(self.temp), self._stream())
+        _capi.check(st, "segs_neural_backward")
+
+
+@dataclass
+class Keyframe:
+    """What the step needs of a GaussianKeyframe (src/gaussian_keyframe.cpp:151-184): device tensors + scalars."""
+    view: torch.Tensor
+    proj: torch.Tensor
+    campos: torch.Tensor
+    pose7: torch.Tensor      # (t_xyz, q_wxyz), gaussian_renderer.cpp:258-261
+    tanfovx: float
+    tanfovy: float
+
+
+class ScaffoldTrainerStep:
+    """prefilter_voxel -> generate_neural_gaussians -> rasterize -> L1/SSIM -> backward -> [all-reduce] -> fused Adam,
+    all on the device without a host synchronisation in steady state."""
+
+    def __init__(self, model: ScaffoldModel, width: int, height: int, opt: Optional[ScaffoldOptimizationParams] = None,
+                 spatial_lr_scale: float = 1.0, process_group=None):
+        self.model, self.opt = model, opt or ScaffoldOptimizationParams()
+        self.W, self.H = int(width), int(height)
+        dev = model.device
+        self._lib = model._lib
+        self.neural = NeuralGaussians(model)
+        self.engine = RasterEngine(self.neural.P, width, height, dev, resident=True, skip_nonpositive_opacity=True)
+        self.loss_fn = FusedL1SSIM(height, width, dev, self.opt.lambda_dssim)
+        self.bg = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.visible_radii = torch.zeros(model.A, dtype=torch.int32, device=dev)
+        self.exp_avg = torch.zeros_like(model.params)
+        self.exp_avg_sq = torch.zeros_like(model.params)
+        self.spatial_lr_scale = float(spatial_lr_scale)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self.iteration = 0
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.model.device).cuda_stream)
+
+    def learning_rates(self, it: int) -> Dict[str, float]:
+        """updateLearningRate (src/gaussian_model.cpp:874-915); anchor/offset scaled by spatial_lr_scale (:637,640)."""
+        o = self.opt
+        return {
+            "anchor": expon_lr(it, o.position_lr_init * self.spatial_lr_scale, o.position_lr_final * self.spatial_lr_scale,
+                               o.position_lr_max_steps),
+            "offset": expon_lr(it, o.offset_lr_init * self.spatial_lr_scale, o.offset_lr_final * self.spatial_lr_scale,
+                               o.offset_lr_max_steps),
+            "anchor_feat": o.feature_lr, "scaling": o.scaling_lr,
+            "mlp_opacity": expon_lr(it, o.mlp_opacity_lr_init, o.mlp_opacity_lr_final, o.mlp_opacity_lr_max_steps),
+            "mlp_cov": expon_lr(it, o.mlp_cov_lr_init, o.mlp_cov_lr_final, o.mlp_cov_lr_max_steps),
+            "mlp_color": expon_lr(it, o.mlp_color_lr_init, o.mlp_color_lr_final, o.mlp_color_lr_max_steps),
+            "mlp_featurebank": expon_lr(it, o.mlp_featurebank_lr_init, o.mlp_featurebank_lr_final, o.mlp_featurebank_lr_max_steps),
+            "appearance": expon_lr(it, o.appearance_lr_init, o.appearance_lr_final, o.appearance_lr_max_steps),
+        }
+
+    def prefilter_voxel(self, kf: Keyframe) -> torch.Tensor:
+        """radii of the anchors drawn as Gaussians with exp(scaling[:, :3]) and normalize(rotation)
+        (src/gaussian_renderer.cpp:131-199); the result stays on the device."""
+        m = self.model
+        scales = torch.exp(m.param("scaling")[:, :3]).contiguous()
+        rots = torch.nn.functional.normalize(m.rotation)
+        st = self._lib.segs_visible_filter(m.A, 0, self.W, self.H, _p(m.param("anchor")), _p(scales), 1.0, _p(rots), None,
+                                           _p(kf.view), _p(kf.proj), float(kf.tanfovx), float(kf.tanfovy), 0,
+                                           _p(self.visible_radii), self._stream())
+        _capi.check(st, "segs_visible_filter")
+        return self.visible_radii
+
+    def render(self, kf: Keyframe) -> torch.Tensor:
+        ng = self.neural
+        ng.forward(kf.campos, kf.pose7, self.prefilter_voxel(kf))
+        return self.engine.forward(self.bg, ng.means3D, ng.colors, ng.opacity, ng.scales, ng.rotations, kf.view, kf.proj,
+                                   kf.campos, kf.tanfovx, kf.tanfovy)
+
+    def _forward_backward(self, kf: Keyframe, gt: torch.Tensor):
+        image = self.render(kf)
+        loss, dL = self.loss_fn(image, gt)
+        g = self.engine.backward(dL)
+        self.neural.backward(g["means3D"], g["colors"], g["opacity"], g["scales"], g["rotations"])
+        return loss
+
+    def keyframe_for(self, step: int, n_keyframes: int) -> int:
+        return (step * self.world + self.rank) % n_keyframes
+
+    def training_once(self, keyframes: List[Keyframe], gt_images: List[torch.Tensor]) -> torch.Tensor:
+        self.iteration += 1
+        lrs = self.learning_rates(self.iteration)
+        k = self.keyframe_for(self.iteration - 1, len(keyframes))
+        loss = self._forward_backward(keyframes[k], gt_images[k])
+        if not self.engine.check(raise_on_overflow=False):
+            self.model.grads.zero_()                   # the overflowed pass left partial gradients behind
+            loss = self._forward_backward(keyframes[k], gt_images[k])
+        if self.world > 1:
+            dist.all_reduce(self.model.grads, group=self.pg)
+        groups = self.model.adam_groups(lrs)
+        segs = (_capi.AdamSegment * len(groups))()
+        for i, (o, n, lr) in enumerate(groups):
+            segs[i].offset, segs[i].count, segs[i].lr = o, n, float(lr)
+        st = self._lib.segs_adam_step(_p(self.model.params), _p(self.model.grads), _p(self.exp_avg), _p(self.exp_avg_sq), segs,
+                                      len(groups), self.opt.beta1, self.opt.beta2, self.opt.eps, self.iteration,
+                                      1.0 / self.world, 1, self._stream())
+        _capi.check(st, "segs_adam_step")
+        return loss

@@ -47,8 +47,11 @@ class RasterEngine:
     status words back asynchronously; `check()` (called at the start of the next forward) raises the capacity and
     reports an overflow if R ever outgrew it."""
 
-    def __init__(self, P: int, width: int, height: int, device="cuda:0", resident: bool = False):
+    def __init__(self, P: int, width: int, height: int, device="cuda:0", resident: bool = False,
+                 skip_nonpositive_opacity: bool = False):
         self.resident = bool(resident)
+        # SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY (segs_raster.h): candidate-domain inputs of segs_neural_forward
+        self.flags = 1 if skip_nonpositive_opacity else 0
         self.capacity = 0
         self._status_host = None
         self.P, self.W, self.H = int(P), int(width), int(height)
@@ -103,6 +106,7 @@ class RasterEngine:
             assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
         if self.resident and self.capacity > 0:
             self.check(raise_on_overflow=False)  # an overflow noticed here was already handled by the caller's own check
+        self._lib.segs_raster_set_flags(self.flags)  # per host thread; set on every call
         if self.resident and self.capacity > 0:
             st = self._lib.segs_rasterize_forward_resident(
                 p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P, 0, 0, p(bg), self.W, self.H, p(means3D),

@@ -4,6 +4,7 @@ instead of falling back to a CPU path."""
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -70,3 +71,32 @@ def test_camera_tensors_match_reference_logger_dump():
         assert np.allclose(full, np.array(kf["full_proj_transform"]), atol=2e-3)
         center = np.linalg.inv(wvt)[3, :3]
         assert np.allclose(center, np.array(kf["camera_center"]), atol=2e-3)
+
+
+def test_neural_param_layout_matches_state_dict_order():
+    """segs_neural_param_layout (host-only) lists the MLP tensors in the order and sizes of the reference's Sequential
+    stacks (src/gaussian_model.cpp:61-98), as restated in oracle/neural_ref.py."""
+    import ctypes as C
+    from oracle import neural_ref
+    from segs_slam_amd import _capi
+    lib = _capi.lib()
+    for kw in (dict(), dict(appearance_dim=0, use_feat_bank=False), dict(appearance_dim=16, use_feat_bank=False, add_color_dist=True),
+               dict(add_opacity_dist=True, add_cov_dist=True)):
+        rd = neural_ref.NeuralDims(**kw)
+        cd = _capi.NeuralDims(rd.feat_dim, rd.n_offsets, rd.appearance_dim, int(rd.use_feat_bank), int(rd.add_opacity_dist),
+                              int(rd.add_cov_dist), int(rd.add_color_dist))
+        offs, cnts = (C.c_int64 * 18)(), (C.c_int64 * 18)()
+        nt, total = C.c_int(0), C.c_int64(0)
+        assert lib.segs_neural_param_layout(C.byref(cd), offs, cnts, C.byref(nt), C.byref(total)) == 0
+        shapes = rd.tensor_shapes()
+        assert nt.value == len(shapes)
+        pos = 0
+        for i, (_name, shape) in enumerate(shapes):
+            n = int(np.prod(shape))
+            assert (offs[i], cnts[i]) == (pos, n)
+            pos += n
+        assert total.value == pos
+        assert lib.segs_neural_temp_bytes(C.byref(cd), 1000) > 1000 * 512 * 4
+    bad = _capi.NeuralDims(64, 10, 0, 0, 0, 0, 0)
+    assert lib.segs_neural_param_layout(C.byref(bad), None, None, None, None) != 0
+    assert lib.segs_neural_temp_bytes(C.byref(bad), 10) == 0
