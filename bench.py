@@ -45,8 +45,11 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2_1080p", help="scene config name (segs_slam_amd.scenes.CONFIGS)")
-    ap.add_argument("--mode", default="raster", choices=["raster", "trainer"],
-                    help="raster: fwd+bwd raster (+all-reduce); trainer: + L1/SSIM loss (torch ops) and fused Adam")
+    ap.add_argument("--mode", default="raster", choices=["raster", "trainer", "scaffold"],
+                    help="raster: fwd+bwd raster (+all-reduce); trainer: + fused L1/SSIM loss and fused Adam over the "
+                         "Gaussians; scaffold: the anchor-level mapper step (prefilter, neural-Gaussian MLPs, raster, loss, "
+                         "their backward, Adam) over --anchors anchors x 10 offsets (SURVEY 8d config 3)")
+    ap.add_argument("--anchors", type=int, default=50000)
     ap.add_argument("--sync-forward", action="store_true",
                     help="use the reference-shaped forward that blocks on a D2H copy of num_rendered every step "
                          "(default: resident no-sync entry points after one calibrating step)")
@@ -85,6 +88,14 @@ def main():
     dL = t(sc.dL_dout_color)
     eng = RasterEngine(sc.P, cam.width, cam.height, dev, resident=not args.sync_forward)
 
+    if args.mode == "scaffold":
+        from segs_slam_amd import neural_gaussians as ng
+        model = ng.synthetic_model(args.anchors, ng.ModelDims(), cam, dev, seed=rank)
+        tstep = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
+        eng = tstep.engine
+        kfs = [ng.Keyframe(view, proj, campos, torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)]
+        gts = [torch.rand(3, cam.height, cam.width, device=dev)]
+        tstep.keyframe_for = lambda step, n: 0
     if args.mode == "trainer":
         from segs_slam_amd.gaussian_trainer import TrainerStep, keyframe_tensors
         tstep = TrainerStep.on_gpu(sc, dev)
@@ -94,7 +105,7 @@ def main():
         tstep.keyframe_for = lambda step, n: 0
 
     def step():
-        if args.mode == "trainer":
+        if args.mode in ("trainer", "scaffold"):
             tstep.training_once(kfs, gts)
             return
         eng.forward(bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy)
@@ -151,7 +162,7 @@ def main():
         passes_tile = (max(1, int(gx * gy - 1).bit_length()) + 7) // 8
         passes = int(round(breakdown.get("radix_scatter_kernel", {"launches": 0})["launches"] / max(args.warmup, 1)))
         passes_depth = max(passes - passes_tile, 0)
-        ab = algorithmic_bytes(sc.P, P_vis, R, cam.width, cam.height, passes_depth, passes_tile)
+        ab = algorithmic_bytes(eng.P, P_vis, R, cam.width, cam.height, passes_depth, passes_tile)
         dom = prof_dom.result[dominant]
         dom_bytes = ab[dominant] if dominant in ab else ab["radix_sort(all passes)"] / (3 * max(passes, 1))
         traffic, traffic_src = pmc_traffic(args.workload, dominant) if args.mode == "raster" else (None, None)
@@ -172,10 +183,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {sc.P} Gaussians, {cam.width}x{cam.height}, 1 keyframe per GPU, "
+            "config": {"workload": f"{args.workload}: {eng.P} Gaussians, {cam.width}x{cam.height}, 1 keyframe per GPU, "
                                    "fwd+bwd raster" + (", RCCL all-reduce of parameter grads" if world > 1 else "")
-                                   + (" + L1/SSIM loss + fused Adam" if args.mode == "trainer" else ""),
-                       "P": sc.P, "P_visible": P_vis, "num_rendered": R, "width": cam.width, "height": cam.height,
+                                   + (" + L1/SSIM loss + fused Adam" if args.mode == "trainer" else "")
+                                   + (f"; anchor-level mapper step: {args.anchors} anchors x 10 offsets -> neural Gaussians "
+                                      "(MLPs fwd+bwd), L1/SSIM, fused Adam" if args.mode == "scaffold" else ""),
+                       "P": eng.P, "P_visible": P_vis, "num_rendered": R, "width": cam.width, "height": cam.height,
                        "sort_passes": {"depth_keys_P": passes_depth, "tile_keys_R": passes_tile}, "parallelism": f"keyframe-dp{world}",
                        "forward": "sync (reference API)" if args.sync_forward else "resident (no host sync)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

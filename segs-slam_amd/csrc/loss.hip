@@ -31,7 +31,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 __global__ void __launch_bounds__(256) ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
                                                        Win win, float* __restrict__ Dm, float* __restrict__ D11,
-                                                       float* __restrict__ D12, float* __restrict__ sums /*[0]=sum|d|,[1]=sum S*/) {
+                                                       float* __restrict__ D12, float2* __restrict__ partial /* per workgroup: (sum|d|, sum S) */) {
   __shared__ float s1[TW][TW + 1], s2[TW][TW + 1];
   __shared__ float h[5][TW][TS + 1];
   __shared__ float red[4];
@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(const float* __restrict__
   const float t1 = block_sum(l1, red);
   __syncthreads();
   const float t2 = block_sum(S, red);
-  if (tid == 0) { atomicAdd(sums, t1); atomicAdd(sums + 1, t2); }
+  // one slot per workgroup (a same-address float atomic from ~10^4 workgroups serialises: 0.25 ms at 1200x680)
+  if (tid == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_float2(t1, t2);
 }
 
 __global__ void __launch_bounds__(256) ssim_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
@@ -134,17 +135,33 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(const float* __restrict__
   }
 }
 
-__global__ void finish_loss_kernel(const float* sums, float inv_n, float lambda_dssim, float* out) {
-  const float l1 = sums[0] * inv_n, ssim = sums[1] * inv_n;
-  out[0] = (1.f - lambda_dssim) * l1 + lambda_dssim * (1.f - ssim);
-  out[1] = l1;
-  out[2] = ssim;
+__global__ void __launch_bounds__(1024) finish_loss_kernel(const float2* __restrict__ partial, int n, float inv_n,
+                                                            float lambda_dssim, float* __restrict__ out) {
+  __shared__ float r1[16], r2[16];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) { const float2 v = partial[i]; a += v.x; b += v.y; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+  if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = a; r2[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int w = 0; w < 16; w++) { s1 += r1[w]; s2 += r2[w]; }
+    const float l1 = s1 * inv_n, ssim = s2 * inv_n;
+    out[0] = (1.f - lambda_dssim) * l1 + lambda_dssim * (1.f - ssim);
+    out[1] = l1;
+    out[2] = ssim;
+  }
 }
 }  // namespace
 
 extern "C" {
 
-size_t segs_l1_ssim_temp_bytes(int H, int W) { return (size_t)3 * 3 * H * W * sizeof(float) + 256; }
+static size_t partial_bytes(int H, int W) {
+  const size_t nblk = (size_t)3 * ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
+  return (nblk * sizeof(float2) + 255) & ~(size_t)255;
+}
+size_t segs_l1_ssim_temp_bytes(int H, int W) { return (size_t)3 * 3 * H * W * sizeof(float) + partial_bytes(H, W); }
 
 int segs_l1_ssim_loss(const float* img1, const float* img2, int H, int W, float lambda_dssim, float* loss_out, float* dL_dimg1,
                       char* temp, void* stream) {
@@ -159,18 +176,16 @@ int segs_l1_ssim_loss(const float* img1, const float* img2, int H, int W, float 
   }
   for (int x = 0; x < 11; ++x) win.g[x] /= sum;
   const size_t plane3 = (size_t)3 * H * W;
-  float* sums = reinterpret_cast<float*>(temp);
-  float* Dm = reinterpret_cast<float*>(temp + 256);
+  float2* partial = reinterpret_cast<float2*>(temp);
+  float* Dm = reinterpret_cast<float*>(temp + partial_bytes(H, W));
   float* D11 = Dm + plane3;
   float* D12 = D11 + plane3;
-  hipError_t e = hipMemsetAsync(sums, 0, 2 * sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
   const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, 3), block(TS, TS);
-  ssim_fwd_kernel<<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, sums);
+  ssim_fwd_kernel<<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, partial);
   const float inv_n = 1.0f / (float)plane3;
-  finish_loss_kernel<<<1, 1, 0, st>>>(sums, inv_n, lambda_dssim, loss_out);
+  finish_loss_kernel<<<1, 1024, 0, st>>>(partial, (int)(grid.x * grid.y * grid.z), inv_n, lambda_dssim, loss_out);
   ssim_bwd_kernel<<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, (1.f - lambda_dssim) * inv_n, lambda_dssim * inv_n, dL_dimg1);
-  e = hipGetLastError();
+  hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : (int)e;
 }
 

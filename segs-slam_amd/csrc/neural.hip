@@ -36,7 +36,8 @@ constexpr int R_DO = 320;  // dL/d(opacity MLP output pre-tanh) [10]
 constexpr int R_DC = 352;  // dL/d(cov MLP output) [70]
 constexpr int R_DK = 448;  // dL/d(colour MLP output pre-sigmoid) [30]
 constexpr int R_DF = 480;  // dL/d(feature-bank logits) [3]
-constexpr int WG_WAVES = 128;  // waves per weight-gradient job
+constexpr int WG_WAVES = 256;  // waves per weight-gradient job
+constexpr int WG_UNROLL = 8;   // row pairs whose operand loads are in flight together
 constexpr int WG_JOBS = 8;
 constexpr int WG_TILE = 2 * 3 * 1024;  // floats of partial sums per (job, wave): up to 2x3 tiles of 32x32
 constexpr int MAX_APP = 64;
@@ -501,28 +502,37 @@ __global__ void __launch_bounds__(64) wgrad_mfma_kernel(WJobs jobs, const uint32
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[it][jt][r] = 0.f;
   float bsum[3] = {0.f, 0.f, 0.f};
-  // rows are dealt to the WG_WAVES waves of this job in interleaved pairs
-  for (uint32_t k0 = 2u * blockIdx.x; k0 < n; k0 += 2u * WG_WAVES) {
-    const uint32_t k = k0 + (uint32_t)half;
-    const bool live = k < n;
-    const float* row = rows + (size_t)k * ROW;
-    float av[2], bv[3];
+  // rows are dealt to the WG_WAVES waves of this job in interleaved pairs; WG_UNROLL pairs are loaded before their
+  // MFMAs are issued (the loop is load-latency bound otherwise: one dependent L2 round trip per row pair)
+  for (uint32_t k0 = 2u * blockIdx.x; k0 < n; k0 += 2u * WG_WAVES * WG_UNROLL) {
+    float av[WG_UNROLL][2], bv[WG_UNROLL][3];
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const int i = it * 32 + c;
-      av[it] = (live && i < job.M) ? row[job.a_off + i] : 0.f;
+    for (int u = 0; u < WG_UNROLL; u++) {
+      const uint32_t k = k0 + 2u * WG_WAVES * u + (uint32_t)half;
+      const bool live = k < n;
+      const float* row = rows + (size_t)k * ROW;
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const int i = it * 32 + c;
+        av[u][it] = (live && i < job.M) ? row[job.a_off + i] : 0.f;
+      }
+#pragma unroll
+      for (int jt = 0; jt < 3; jt++) {
+        const int j = jt * 32 + c;
+        bv[u][jt] = (live && j < job.N) ? row[job.b_off + j] : 0.f;
+      }
     }
 #pragma unroll
-    for (int jt = 0; jt < 3; jt++) {
-      const int j = jt * 32 + c;
-      bv[jt] = (live && j < job.N) ? row[job.b_off + j] : 0.f;
-      bsum[jt] += bv[jt];
+    for (int u = 0; u < WG_UNROLL; u++) {
+#pragma unroll
+      for (int jt = 0; jt < 3; jt++) bsum[jt] += bv[u][jt];
+#pragma unroll
+      for (int it = 0; it < 2; it++)
+#pragma unroll
+        for (int jt = 0; jt < 3; jt++)
+          if (it < nit && jt < njt)
+            acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][it], bv[u][jt], acc[it][jt], 0, 0, 0);
     }
-#pragma unroll
-    for (int it = 0; it < 2; it++)
-#pragma unroll
-      for (int jt = 0; jt < 3; jt++)
-        if (it < nit && jt < njt) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[it], bv[jt], acc[it][jt], 0, 0, 0);
   }
   float* out = partial + ((size_t)blockIdx.y * WG_WAVES + blockIdx.x) * WG_TILE;
   // partial tile layout: [it][jt][i_local 0..31][j_local 0..31]; C/D map: col = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5).

@@ -102,7 +102,6 @@ _p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
 class ScaffoldModel:
     """Anchors + MLPs in one flat parameter bucket (and a same-shaped gradient bucket) on `device`."""
 
-    ANCHOR_FIELDS = (("anchor", 3), ("offset", None), ("anchor_feat", None), ("scaling", 6))
 
     def __init__(self, A: int, dims: ModelDims, device):
         self.A, self.dims, self.device = int(A), dims, torch.device(device)
@@ -323,3 +322,29 @@ class ScaffoldTrainerStep:
                                       1.0 / self.world, 1, self._stream())
         _capi.check(st, "segs_adam_step")
         return loss
+
+
+def synthetic_model(A: int, dims: ModelDims, cam, device, seed: int = 0) -> ScaffoldModel:
+    """Seeded synthetic anchors inside the frustum of `cam` (a scenes.Camera at the origin looking down +z) with
+    torch::nn::Linear-style uniform MLP init: the mapper-loop workload of SURVEY 8d config 3 (no dataset in the image).
+    Anchor depth ~ U(1, 6) m, lateral position within 1.1x the field of view, per-anchor Gaussian scales
+    ~ exp(U(ln 0.006, ln 0.05)) (halved by the sigmoid in the forward), offsets ~ N(0, 0.5) voxels of 5 cm."""
+    import math
+    g = torch.Generator().manual_seed(0x5E65 + seed)
+    r = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
+    z = 1.0 + 5.0 * r(A)
+    x = (r(A) * 2 - 1) * 1.1 * cam.tanfovx * z
+    y = (r(A) * 2 - 1) * 1.1 * cam.tanfovy * z
+    anchor = torch.stack([x, y, z], dim=1)
+    offset = 0.5 * torch.randn(A, dims.n_offsets, 3, generator=g)
+    feat = 0.5 * torch.randn(A, dims.feat_dim, generator=g)
+    scaling_log = torch.cat([torch.full((A, 3), math.log(0.05)),
+                             math.log(0.006) + (math.log(0.05) - math.log(0.006)) * r(A, 3)], dim=1)
+    model = ScaffoldModel(A, dims, device)
+    mlp = {}
+    for name in dims.mlp_tensor_names():
+        shape = dims.mlp_tensor_shape(name)
+        fan_in = shape[1] if len(shape) == 2 else dims.feat_dim
+        mlp[name] = (r(*shape) * 2 - 1) / math.sqrt(fan_in)
+    model.load(anchor, offset, feat, scaling_log, mlp)
+    return model
