@@ -4,9 +4,10 @@
 //
 //   compact_visible_kernel : radii>0 -> visible-anchor list + device-side count (no host sync); clears the opacity of
 //                            the slots of invisible anchors so the rasterizer skips them
-//   neural_fwd_kernel      : thread = visible anchor; view direction, feature bank, three 35->32->{10,70,30} MLPs,
+//   neural_fwd_kernel      : wave = 32 visible anchors; view direction, feature bank, three 35->32->{10,70,30} MLPs
+//                            chained on fp32 MFMA (activations stay in registers, weights as LDS operand images),
 //                            mask, xyz/scale/rot assembly, written straight into the rasterizer's input arrays
-//   neural_bwd_kernel      : thread = visible anchor; recomputes the forward (cheaper than saving ~100 floats/anchor),
+//   neural_bwd_kernel      : same mapping; recomputes the forward (cheaper than saving ~100 floats/anchor),
 //                            back-propagates the candidate-domain gradients to anchor/offset/feature/scaling and leaves
 //                            the per-anchor (activation, pre-activation gradient) rows in scratch
 //   wgrad_mfma_kernel      : dW[j][i] = sum_anchors dpre[a][j] * act[a][i] for all eight Linear layers with
@@ -16,7 +17,8 @@
 //   wgrad_reduce_kernel    : deterministic sum of the partial tiles, += into the flat gradient block
 //   appearance_finish_kernel: the appearance embedding Linear(7->app) feeds every anchor the same vector, so it is
 //                            folded into the colour MLP's first bias; its gradients follow from that bias gradient.
-// MLP weights (30 KB) sit in LDS and are read as wave-uniform broadcasts; everything per anchor lives in registers.
+// A thread-per-anchor VALU version of the two MLP kernels (weights as LDS broadcasts) was LDS-issue bound: 119 / 289 us
+// at 35 k visible anchors; see DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
@@ -29,13 +31,15 @@ constexpr int FD = 32;     // feat_dim
 constexpr int NO = 10;     // n_offsets
 constexpr int XD = 36;     // MLP input: feat(32) | ob_view(3) | ob_dist(1)
 constexpr int ROW = 512;   // scratch floats per visible anchor
-constexpr int R_X = 0;     // x[36]
+// Every field is laid out so that each lane half of the backward kernel writes ONE contiguous run (wide stores): the
+// kernel is bound by the number of scattered VMEM wave-instructions (64 cache lines each), not by bytes.
+constexpr int R_X = 0;     // x[36] in lane order: position 18 h + s holds input 2 s + h
 constexpr int R_H = 64;    // + 32*m : hidden activations, m = 0 opacity, 1 cov, 2 colour, 3 feature bank
 constexpr int R_DH = 192;  // + 32*m : dL/d(hidden pre-activation)
-constexpr int R_DO = 320;  // dL/d(opacity MLP output pre-tanh) [10]
-constexpr int R_DC = 352;  // dL/d(cov MLP output) [70]
-constexpr int R_DK = 448;  // dL/d(colour MLP output pre-sigmoid) [30]
-constexpr int R_DF = 480;  // dL/d(feature-bank logits) [3]
+constexpr int R_DO = 320;  // dL/d(opacity MLP output pre-tanh): position 8 h + r  <-> output 5 h + r, r < 5      [16]
+constexpr int R_DK = 336;  // dL/d(colour MLP output pre-sigmoid): position 16 h + r <-> output 15 h + r, r < 15  [32]
+constexpr int R_DC = 368;  // dL/d(cov MLP output): position 36 h + r <-> output 35 h + r, r < 35                  [72]
+constexpr int R_DF = 440;  // dL/d(feature-bank logits) [3]
 constexpr int WG_WAVES = 256;  // waves per weight-gradient job
 constexpr int WG_UNROLL = 8;   // row pairs whose operand loads are in flight together
 constexpr int WG_JOBS = 8;
@@ -92,112 +96,177 @@ struct Temp {             // carve-up of the caller's scratch
   float* rows;            // [A][ROW]
   float* partial;         // [WG_JOBS][WG_WAVES][WG_TILE]
   float* gsum;            // [total + pad] this call's parameter-gradient sums
+  float* images;          // [N_IMG_BWD][64] MFMA A-operand images of the MLP weights (built by the forward call)
+  void* small;            // Small tables
 };
 size_t temp_carve(int A, int total, char* base, Temp* t) {
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
   const size_t o_count = take(256), o_vis = take((size_t)A * 4), o_rows = take((size_t)A * ROW * 4),
-               o_part = take((size_t)WG_JOBS * WG_WAVES * WG_TILE * 4), o_gsum = take((size_t)(total + 64) * 4);
+               o_part = take((size_t)WG_JOBS * WG_WAVES * WG_TILE * 4), o_gsum = take((size_t)(total + 64) * 4),
+               o_img = take((size_t)262 * 64 * 4), o_small = take(8192);
   if (t) {
     t->count = (uint32_t*)(base + o_count); t->vis = (uint32_t*)(base + o_vis); t->rows = (float*)(base + o_rows);
     t->partial = (float*)(base + o_part); t->gsum = (float*)(base + o_gsum);
+    t->images = (float*)(base + o_img); t->small = (void*)(base + o_small);
   }
   return off;
 }
 
-constexpr int PAD_O = 12, PAD_C = 72, PAD_K = 32;   // second-layer widths (10, 70, 30) padded to float4
-struct Lds {
-  float w1[3][FD][XD];      // [m][j][i]; column 35 is zero when the MLP does not see ob_dist
-  float b1[3][FD];          // colour: includes W1k[:, appearance columns] . appearance_feat
-  float w2o[FD][PAD_O], w2c[FD][PAD_C], w2k[FD][PAD_K];   // second layers TRANSPOSED: [hidden j][output o]
-  float b2o[PAD_O], b2c[PAD_C], b2k[PAD_K];
-  float fw1[FD][4], fb1[FD], fw2[FD][4], fb2[4];          // feature bank; fw2 transposed [j][c]
+// ---- MLP chain on the matrix cores ------------------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 (exact fp32): D[i][j] += sum_{k<2} A[i][k] B[k][j]; lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; D register r of lane l is D[i = rho(r, l>>5)][j = l&31], rho(r,h) = (r&3) + 8 (r>>2) + 4 h.
+// Here j (the lane) is the ANCHOR: a wave pushes 32 anchors at a time through  H = relu(W1 X + b1),  OUT = W2 H + b2
+// as transposed products, the weight matrices on the A side.  Because D's row index sits in the registers, a layer's
+// result is directly the next layer's B operand (register s <-> k index rho(s,h)); activations never leave registers
+// and there is no LDS traffic besides the A operands.  The A operands are precomputed once per workgroup as 64-float
+// "images" (one per MFMA issue, already in lane order, with the k / row permutations folded in) and read with one
+// conflict-free ds_read_b32 each.
+// Output rows are assigned so that lane half h of anchor n receives everything about candidates 5h .. 5h+4 of that
+// anchor: opacity tile rows rho(r,h), r<5; colour tile r<15 (candidate-major, rgb); three covariance tiles holding
+// candidates {0,1}, {2,3}, {4} of the half, 7 values each in registers 0..13.
+// Both kernels walk the five tiles in ONE rolled loop (the tile kind selects the element-wise code with wave-uniform
+// branches): fully unrolled, the straight-line code (20 / 40 KB, executed once per wave) made the kernels
+// instruction-fetch bound (SQ_WAIT_INST_ANY ~30 % of wave time, 32 / 116 us); see DESIGN.md.
+constexpr int L1_STEPS = XD / 2;        // 18
+constexpr int N_TILES = 5;              // 0 opacity | 1 colour | 2,3,4 covariance
+constexpr int I_L1 = 0;                 // [m][18]
+constexpr int I_L2 = 3 * L1_STEPS;      // [tile][16]
+constexpr int I_DH = I_L2 + N_TILES * 16;   // [tile][16]   backward: dH = W2^T dOUT
+constexpr int I_DX = I_DH + N_TILES * 16;   // [m][16]      backward: dX = W1^T dHpre (inputs 0..31)
+constexpr int N_IMG_FWD = I_DH, N_IMG_BWD = I_DX + 3 * 16;
+
+struct Small {                          // small per-workgroup tables next to the operand images
+  float b1[3][FD];                      // colour: includes W1k[:, appearance columns] . appearance_feat
+  float b2t[N_TILES][2][16];            // second-layer bias of the unit held in register r of lane half h, per tile
+  float w1tail[3][FD][4];               // W1_m[j][32..35]: view xyz, dist (0 when the MLP does not see it)
+  float fw1[FD][4], fb1[FD], fw2[FD][4], fb2[4];   // feature bank; fw2 transposed [j][c]
   float app[MAX_APP];
 };
 
-__device__ void stage_weights(Lds& S, const Layout& L, const float* __restrict__ P, const float* __restrict__ pose7) {
+__device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ int tile_mlp(int tile) { return tile == 0 ? 0 : (tile == 1 ? 2 : 1); }
+// output unit (row of the MLP's second weight matrix) held by lane half h in register r of `tile`, or -1
+__device__ __forceinline__ int out_row(int tile, int h, int r) {
+  if (tile == 0) return r < 5 ? 5 * h + r : -1;
+  if (tile == 1) return r < 15 ? 15 * h + r : -1;
+  const int cand = 2 * (tile - 2) + r / 7;       // this half's candidate 0..4: two per covariance tile, one in the last
+  return (r < 14 && cand < 5) ? 7 * (5 * h + cand) + r % 7 : -1;
+}
+
+// Built once per forward call by one small kernel into the caller's scratch (global), then copied into LDS by every
+// workgroup with coalesced float4 loads (gathering the images per workgroup cost 25-45 us of dependent loads).
+__global__ void __launch_bounds__(256) pack_tables_kernel(Layout L, const float* __restrict__ P, const float* __restrict__ pose7,
+                                                          float* __restrict__ img, Small* __restrict__ Sg) {
+  __shared__ float app[MAX_APP];
   const int tid = threadIdx.x, nt = blockDim.x;
-  if (L.app > 0) {
-    for (int a = tid; a < L.app; a += nt) {
-      float s = P[L.ab + a];
+  for (int a = tid; a < MAX_APP; a += nt) {
+    float s = 0.f;
+    if (a < L.app) {
+      s = P[L.ab + a];
       for (int q = 0; q < 7; q++) s += P[L.aw + a * 7 + q] * pose7[q];
-      S.app[a] = s;
     }
-    __syncthreads();
+    app[a] = s;
   }
-  for (int e = tid; e < 3 * FD * XD; e += nt) {
-    const int m = e / (FD * XD), r = e - m * FD * XD, j = r / XD, i = r - j * XD;
-    const int ncol = FD + 3 + L.dist[m];
-    (&S.w1[0][0][0])[e] = i < ncol ? P[L.w1[m] + j * L.in[m] + i] : 0.f;
+  __syncthreads();
+  for (int e = blockIdx.x * nt + tid; e < N_IMG_BWD * 64; e += gridDim.x * nt) {
+    const int im = e >> 6, l = e & 63, i = l & 31, hA = l >> 5;
+    float v = 0.f;
+    if (im < I_L2) {                     // layer 1: A[i = hidden][k = 2s + hA]
+      const int m = im / L1_STEPS, s = im - m * L1_STEPS, k = 2 * s + hA;
+      if (k < FD + 3 + L.dist[m]) v = P[L.w1[m] + i * L.in[m] + k];
+    } else if (im < I_DH) {              // layer 2: A[i = tile row][k <-> hidden rho(s, hA)]
+      const int tile = (im - I_L2) >> 4, s = (im - I_L2) & 15, m = tile_mlp(tile);
+      const int o = out_row(tile, (i >> 2) & 1, (i & 3) + 4 * (i >> 3));
+      if (o >= 0) v = P[L.w2[m] + o * FD + rho(s, hA)];
+    } else if (im < I_DX) {              // dH: A[i = hidden][k <-> tile row rho(s, hA)]
+      const int tile = (im - I_DH) >> 4, s = (im - I_DH) & 15, m = tile_mlp(tile);
+      const int o = out_row(tile, hA, s);
+      if (o >= 0) v = P[L.w2[m] + o * FD + i];
+    } else {                             // dX: A[i = input 0..31][k <-> hidden rho(s, hA)]
+      const int m = (im - I_DX) >> 4, s = (im - I_DX) & 15;
+      v = P[L.w1[m] + rho(s, hA) * L.in[m] + i];
+    }
+    img[e] = v;
   }
+  if (blockIdx.x != 0) return;
+  Small& S = *Sg;
   for (int e = tid; e < 3 * FD; e += nt) {
     const int m = e / FD, j = e - m * FD;
     float b = P[L.b1[m] + j];
     if (m == 2)
-      for (int a = 0; a < L.app; a++) b += P[L.w1[2] + j * L.in[2] + L.kapp + a] * S.app[a];
+      for (int a = 0; a < L.app; a++) b += P[L.w1[2] + j * L.in[2] + L.kapp + a] * app[a];
     S.b1[m][j] = b;
+    for (int c = 0; c < 4; c++) S.w1tail[m][j][c] = (c < 3 + L.dist[m]) ? P[L.w1[m] + j * L.in[m] + FD + c] : 0.f;
   }
-  for (int e = tid; e < FD * PAD_O; e += nt) { const int j = e / PAD_O, o = e - j * PAD_O; S.w2o[j][o] = o < NO ? P[L.w2[0] + o * FD + j] : 0.f; }
-  for (int e = tid; e < FD * PAD_C; e += nt) { const int j = e / PAD_C, o = e - j * PAD_C; S.w2c[j][o] = o < 7 * NO ? P[L.w2[1] + o * FD + j] : 0.f; }
-  for (int e = tid; e < FD * PAD_K; e += nt) { const int j = e / PAD_K, o = e - j * PAD_K; S.w2k[j][o] = o < 3 * NO ? P[L.w2[2] + o * FD + j] : 0.f; }
-  for (int e = tid; e < PAD_O; e += nt) S.b2o[e] = e < NO ? P[L.b2[0] + e] : 0.f;
-  for (int e = tid; e < PAD_C; e += nt) S.b2c[e] = e < 7 * NO ? P[L.b2[1] + e] : 0.f;
-  for (int e = tid; e < PAD_K; e += nt) S.b2k[e] = e < 3 * NO ? P[L.b2[2] + e] : 0.f;
-  if (L.bank) {
-    for (int e = tid; e < FD * 4; e += nt) (&S.fw1[0][0])[e] = P[L.fw1 + e];
-    for (int e = tid; e < FD; e += nt) S.fb1[e] = P[L.fb1 + e];
-    for (int e = tid; e < FD * 4; e += nt) { const int j = e >> 2, c = e & 3; S.fw2[j][c] = c < 3 ? P[L.fw2 + c * FD + j] : 0.f; }
-    for (int e = tid; e < 4; e += nt) S.fb2[e] = e < 3 ? P[L.fb2 + e] : 0.f;
+  for (int e = tid; e < N_TILES * 32; e += nt) {
+    const int tile = e >> 5, hh = (e >> 4) & 1, r = e & 15;
+    const int o = out_row(tile, hh, r);
+    S.b2t[tile][hh][r] = o >= 0 ? P[L.b2[tile_mlp(tile)] + o] : 0.f;
   }
+  for (int e = tid; e < FD * 4; e += nt) {
+    const int j = e >> 2, c = e & 3;
+    (&S.fw1[0][0])[e] = L.bank ? P[L.fw1 + e] : 0.f;
+    S.fw2[j][c] = (L.bank && c < 3) ? P[L.fw2 + c * FD + j] : 0.f;
+  }
+  for (int e = tid; e < FD; e += nt) S.fb1[e] = L.bank ? P[L.fb1 + e] : 0.f;
+  for (int e = tid; e < 4; e += nt) S.fb2[e] = (L.bank && e < 3) ? P[L.fb2 + e] : 0.f;
+  for (int e = tid; e < MAX_APP; e += nt) S.app[e] = app[e];
+}
+
+static_assert(sizeof(Small) % 16 == 0, "Small is copied as float4");
+__device__ __forceinline__ void stage_tables(float* __restrict__ img, Small& S, int n_img, const float* __restrict__ g_img,
+                                             const Small* __restrict__ g_small) {
+  const float4* src = reinterpret_cast<const float4*>(g_img);
+  float4* dst = reinterpret_cast<float4*>(img);
+#pragma unroll 4
+  for (int e = threadIdx.x; e < n_img * 16; e += 256) dst[e] = src[e];
+  const float4* s2 = reinterpret_cast<const float4*>(g_small);
+  float4* d2 = reinterpret_cast<float4*>(&S);
+  for (int e = threadIdx.x; e < (int)(sizeof(Small) / 16); e += 256) d2[e] = s2[e];
   __syncthreads();
 }
 
-__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
-
-// Two-layer MLP, hidden loop kept rolled: per hidden unit j one LDS row of each layer is read (wave-uniform broadcast);
-// x / out / dout / dx are register arrays with static indices only.
-template <int NOUT, int PAD>
-__device__ __forceinline__ void mlp_forward(const float (*w1)[XD], const float* b1, const float (*w2t)[PAD], const float* b2,
-                                            const float* x, float* out) {
-#pragma unroll
-  for (int o = 0; o < NOUT; o++) out[o] = b2[o];
-#pragma unroll 1
-  for (int j = 0; j < FD; j++) {
-    float s = b1[j];
-#pragma unroll
-    for (int i = 0; i < XD; i++) s += w1[j][i] * x[i];
-    const float hj = fmaxf(s, 0.f);
-#pragma unroll
-    for (int o = 0; o < NOUT; o++) out[o] += w2t[j][o] * hj;
-  }
+// v_exp_f32 / v_rcp_f32 (1 ulp) instead of the ocml routines: the MLP outputs are compared at 2e-5 absolute
+__device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
+__device__ __forceinline__ float sigmoidf(float v) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) {
+  const float e = fast_exp(-2.0f * fabsf(v));            // in (0, 1]: no overflow
+  const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+  return copysignf(t, v);
 }
-// Backward through the same MLP given dL/d(output pre-activation): accumulates dL/dx, stores the hidden activations
-// and the hidden pre-activation gradients (operands of the weight-gradient MFMAs) into the anchor's scratch row.
-template <int NOUT, int PAD>
-__device__ __forceinline__ void mlp_backward(const float (*w1)[XD], const float* b1, const float (*w2t)[PAD], const float* x,
-                                             const float* dout, float* dx, float* __restrict__ row_h, float* __restrict__ row_dh) {
-#pragma unroll 1
-  for (int j = 0; j < FD; j++) {
-    float s = b1[j];
+// Runs of N floats with only 4-byte alignment as dwordx4/x3/x2 accesses (gfx950 global memory needs dword alignment only).
+struct __attribute__((packed, aligned(4))) U4 { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) U3 { float x, y, z; };
+struct __attribute__((packed, aligned(4))) U2 { float x, y; };
+template <int N>
+__device__ __forceinline__ void ldn(const float* __restrict__ p, float* v) {
+  constexpr int Q = N / 4, R = N % 4;
 #pragma unroll
-    for (int i = 0; i < XD; i++) s += w1[j][i] * x[i];
-    float dh = 0.f;
-#pragma unroll
-    for (int o = 0; o < NOUT; o++) dh += w2t[j][o] * dout[o];
-    const float d = s > 0.f ? dh : 0.f;
-    row_h[j] = fmaxf(s, 0.f);
-    row_dh[j] = d;
-#pragma unroll
-    for (int i = 0; i < XD; i++) dx[i] += w1[j][i] * d;
-  }
+  for (int i = 0; i < Q; i++) { const U4 t = *reinterpret_cast<const U4*>(p + 4 * i); v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+  if (R == 3) { const U3 t = *reinterpret_cast<const U3*>(p + 4 * Q); v[4 * Q] = t.x; v[4 * Q + 1] = t.y; v[4 * Q + 2] = t.z; }
+  if (R == 2) { const U2 t = *reinterpret_cast<const U2*>(p + 4 * Q); v[4 * Q] = t.x; v[4 * Q + 1] = t.y; }
+  if (R == 1) v[4 * Q] = p[4 * Q];
 }
+template <int N>
+__device__ __forceinline__ void stn(float* __restrict__ p, const float* v) {
+  constexpr int Q = N / 4, R = N % 4;
+#pragma unroll
+  for (int i = 0; i < Q; i++) *reinterpret_cast<U4*>(p + 4 * i) = U4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+  if (R == 3) *reinterpret_cast<U3*>(p + 4 * Q) = U3{v[4 * Q], v[4 * Q + 1], v[4 * Q + 2]};
+  if (R == 2) *reinterpret_cast<U2*>(p + 4 * Q) = U2{v[4 * Q], v[4 * Q + 1]};
+  if (R == 1) p[4 * Q] = v[4 * Q];
+}
+__device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 64); }
 
-// Per-anchor inputs shared by forward and backward: view direction / distance, feature bank, MLP input vector x.
-struct AnchorState {
-  float x[XD];            // feat' (bank-blended) | view | dist
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Per-lane view of one anchor (both lane halves hold the same anchor).
+struct AnchorLane {
+  float xo[L1_STEPS];     // this half's inputs: xo[s] = x[2s + h], x = feat'(32) | view(3) | dist
   float anc[3], gs[6];    // anchor, exp(scaling_log)
+  float view[3], dist, inv_dist;
   float bw[3];            // feature-bank softmax weights
-  float inv_dist;
 };
 
 __device__ __forceinline__ void load_feat(const float* __restrict__ anchor_feat, uint32_t a, float* f) {
@@ -209,9 +278,23 @@ __device__ __forceinline__ void load_feat(const float* __restrict__ anchor_feat,
   }
 }
 
-__device__ __forceinline__ void anchor_state(const Lds& S, const Layout& L, uint32_t a, const float* __restrict__ anchor,
-                                             const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
-                                             const float* __restrict__ campos, AnchorState& st) {
+// feature-bank hidden units are split between the lane halves (16 each); returns this half's partial logits
+__device__ __forceinline__ void bank_logits_partial(const Small& S, int h, const float* cat4, float* lg) {
+  lg[0] = lg[1] = lg[2] = 0.f;
+#pragma unroll 4
+  for (int jj = 0; jj < FD / 2; jj++) {
+    const int j = 16 * h + jj;
+    const float4 w = *reinterpret_cast<const float4*>(S.fw1[j]);
+    const float s = S.fb1[j] + w.x * cat4[0] + w.y * cat4[1] + w.z * cat4[2] + w.w * cat4[3];
+    const float hj = fmaxf(s, 0.f);
+    const float4 u = *reinterpret_cast<const float4*>(S.fw2[j]);
+    lg[0] += u.x * hj; lg[1] += u.y * hj; lg[2] += u.z * hj;
+  }
+}
+
+__device__ __forceinline__ void anchor_lane(const Small& S, const Layout& L, uint32_t a, int h, const float* __restrict__ anchor,
+                                            const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
+                                            const float* __restrict__ campos, AnchorLane& st) {
   float feat[FD];
   load_feat(anchor_feat, a, feat);
 #pragma unroll
@@ -219,44 +302,76 @@ __device__ __forceinline__ void anchor_state(const Lds& S, const Layout& L, uint
 #pragma unroll
   for (int c = 0; c < 6; c++) st.gs[c] = expf(scaling_log[(size_t)a * 6 + c]);
   const float ox = st.anc[0] - campos[0], oy = st.anc[1] - campos[1], oz = st.anc[2] - campos[2];
-  const float dist = sqrtf(ox * ox + oy * oy + oz * oz);
-  st.inv_dist = 1.0f / dist;
-  st.x[FD] = ox / dist; st.x[FD + 1] = oy / dist; st.x[FD + 2] = oz / dist; st.x[FD + 3] = dist;
+  st.dist = sqrtf(ox * ox + oy * oy + oz * oz);
+  st.inv_dist = 1.0f / st.dist;
+  st.view[0] = ox / st.dist; st.view[1] = oy / st.dist; st.view[2] = oz / st.dist;
   if (L.bank) {
-    float lg[3] = {S.fb2[0], S.fb2[1], S.fb2[2]};
-#pragma unroll 1
-    for (int j = 0; j < FD; j++) {
-      float s = S.fb1[j];
+    const float cat4[4] = {st.view[0], st.view[1], st.view[2], st.dist};
+    float lg[3];
+    bank_logits_partial(S, h, cat4, lg);
 #pragma unroll
-      for (int i = 0; i < 4; i++) s += S.fw1[j][i] * st.x[FD + i];
-      const float hj = fmaxf(s, 0.f);
-#pragma unroll
-      for (int c = 0; c < 3; c++) lg[c] += S.fw2[j][c] * hj;
-    }
+    for (int c = 0; c < 3; c++) lg[c] = lg[c] + other_half(lg[c]) + S.fb2[c];
     const float mx = fmaxf(lg[0], fmaxf(lg[1], lg[2]));
     const float e0 = expf(lg[0] - mx), e1 = expf(lg[1] - mx), e2 = expf(lg[2] - mx);
     const float inv = 1.0f / (e0 + e1 + e2);
     st.bw[0] = e0 * inv; st.bw[1] = e1 * inv; st.bw[2] = e2 * inv;
-    // feat'[j] = feat[4 (j%8)] bw0 + feat[2 (j%16)] bw1 + feat[j] bw2   (gaussian_renderer.cpp:242-247)
+    // feat'[k] = feat[4 (k%8)] bw0 + feat[2 (k%16)] bw1 + feat[k] bw2   (gaussian_renderer.cpp:242-247), k = 2s + h
 #pragma unroll
-    for (int j = 0; j < FD; j++) st.x[j] = feat[4 * (j % 8)] * st.bw[0] + feat[2 * (j % 16)] * st.bw[1] + feat[j] * st.bw[2];
+    for (int s = 0; s < FD / 2; s++) {
+      const int k0 = 2 * s, k1 = 2 * s + 1;
+      const float v0 = feat[4 * (k0 % 8)] * st.bw[0] + feat[2 * (k0 % 16)] * st.bw[1] + feat[k0] * st.bw[2];
+      const float v1 = feat[4 * (k1 % 8)] * st.bw[0] + feat[2 * (k1 % 16)] * st.bw[1] + feat[k1] * st.bw[2];
+      st.xo[s] = h ? v1 : v0;
+    }
   } else {
     st.bw[0] = st.bw[1] = st.bw[2] = 0.f;
 #pragma unroll
-    for (int j = 0; j < FD; j++) st.x[j] = feat[j];
+    for (int s = 0; s < FD / 2; s++) st.xo[s] = h ? feat[2 * s + 1] : feat[2 * s];
   }
+  st.xo[16] = h ? st.view[1] : st.view[0];
+  st.xo[17] = h ? st.dist : st.view[2];
 }
+
+// H_pre = W1_m X + b1_m  (rows rho(r,h) in the registers); m is a runtime value
+__device__ __forceinline__ f32x16 layer1(const float* __restrict__ img, const Small& S, int m, int lane, int h, const float* xo) {
+  f32x16 d;
+#pragma unroll
+  for (int r = 0; r < 16; r++) d[r] = S.b1[m][rho(r, h)];
+  const float* im = img + (I_L1 + m * L1_STEPS) * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < L1_STEPS; s++) d = __builtin_amdgcn_mfma_f32_32x32x2f32(im[s * 64], xo[s], d, 0, 0, 0);
+  return d;
+}
+// OUT tile = W2 H + b2 for this half's candidates
+__device__ __forceinline__ f32x16 layer2(const float* __restrict__ img, const Small& S, int tile, int lane, int h, const f32x16& hpre) {
+  f32x16 d;
+#pragma unroll
+  for (int r = 0; r < 16; r++) d[r] = S.b2t[tile][h][r];
+  const float* im = img + (I_L2 + tile * 16) * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 16; s++) d = __builtin_amdgcn_mfma_f32_32x32x2f32(im[s * 64], fmaxf(hpre[s], 0.f), d, 0, 0, 0);
+  return d;
+}
+
+constexpr int NEURAL_GRID = 512;   // persistent workgroups (2 per CU), each loops over 128-anchor slabs
 
 __global__ void __launch_bounds__(256) compact_visible_kernel(int A, const int* __restrict__ radii, uint32_t* __restrict__ count,
                                                               uint32_t* __restrict__ vis, float* __restrict__ opacity,
                                                               float* __restrict__ neural_opacity) {
+  __shared__ uint32_t wave_n[4], block_base;
   const int a = blockIdx.x * 256 + threadIdx.x;
   const bool v = a < A && (radii == nullptr || radii[a] > 0);
   const uint64_t m = __ballot(v);
-  const int lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (lane == 0 && m) base = atomicAdd(count, (uint32_t)__popcll(m));
-  base = __shfl(base, 0, 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wave_n[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one returning atomic per workgroup (one per wave on a single word cost 10 us at A = 50 k)
+    const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+    block_base = tot ? atomicAdd(count, tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = block_base;
+  for (int w = 0; w < wv; w++) base += wave_n[w];
   if (v) vis[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)a;
   if (a < A && !v) {
 #pragma unroll
@@ -264,224 +379,310 @@ __global__ void __launch_bounds__(256) compact_visible_kernel(int A, const int* 
   }
 }
 
-__global__ void __launch_bounds__(256) neural_fwd_kernel(
+__global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
     Layout L, const uint32_t* __restrict__ count, const uint32_t* __restrict__ vis, const float* __restrict__ anchor,
     const float* __restrict__ offset, const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
-    const float* __restrict__ params, const float* __restrict__ campos, const float* __restrict__ pose7,
+    const float* __restrict__ g_img, const Small* __restrict__ g_small, const float* __restrict__ campos,
     float* __restrict__ means3D, float* __restrict__ colors, float* __restrict__ opacity, float* __restrict__ scales,
     float* __restrict__ rotations, float* __restrict__ neural_opacity) {
-  __shared__ Lds S;
+  extern __shared__ __align__(16) float lds_dyn[];
+  float* img = lds_dyn;
+  Small& S = *reinterpret_cast<Small*>(lds_dyn + N_IMG_FWD * 64);
   const uint32_t n = *count;
-  if (blockIdx.x * 256u >= n) return;
-  stage_weights(S, L, params, pose7);
-  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-  if (t >= n) return;
-  const uint32_t a = vis[t];
-  AnchorState st;
-  anchor_state(S, L, a, anchor, anchor_feat, scaling_log, campos, st);
-  const size_t c0 = (size_t)a * NO;
-  {
-    float out[NO];
-    mlp_forward<NO, PAD_O>(S.w1[0], S.b1[0], S.w2o, S.b2o, st.x, out);
+  if (blockIdx.x * 128u >= n) return;
+  stage_tables(img, S, N_IMG_FWD, g_img, g_small);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  for (uint32_t g0 = (blockIdx.x * 4u + wv) * 32u; g0 < n; g0 += gridDim.x * 128u) {
+    const uint32_t t = g0 + col;
+    const bool valid = t < n;
+    const uint32_t a = vis[valid ? t : n - 1];
+    AnchorLane st;
+    anchor_lane(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
+    const size_t c0 = (size_t)a * NO + 5 * h;     // first candidate of this lane half
+    f32x16 hp;
+#pragma unroll 1
+    for (int tile = 0; tile < N_TILES; tile++) {
+      if (tile <= 2) hp = layer1(img, S, tile_mlp(tile), lane, h, st.xo);
+      const f32x16 o = layer2(img, S, tile, lane, h, hp);
+      if (!valid) continue;
+      if (tile == 0) {
+        float op[5];
 #pragma unroll
-    for (int k = 0; k < NO; k++) {
-      const float op = tanhf(out[k]);
-      neural_opacity[c0 + k] = op;
-      opacity[c0 + k] = op;
-    }
-  }
-  {
-    float out[3 * NO];
-    mlp_forward<3 * NO, PAD_K>(S.w1[2], S.b1[2], S.w2k, S.b2k, st.x, out);
+        for (int r = 0; r < 5; r++) op[r] = fast_tanh(o[r]);
+        stn<5>(neural_opacity + c0, op);
+        stn<5>(opacity + c0, op);
+      } else if (tile == 1) {
+        float cv[15];
 #pragma unroll
-    for (int e = 0; e < 3 * NO; e++) colors[c0 * 3 + e] = sigmoidf(out[e]);
-  }
-  {
-    float out[7 * NO];
-    mlp_forward<7 * NO, PAD_C>(S.w1[1], S.b1[1], S.w2c, S.b2c, st.x, out);
+        for (int r = 0; r < 15; r++) cv[r] = sigmoidf(o[r]);
+        stn<15>(colors + c0 * 3, cv);
+      } else {
 #pragma unroll
-    for (int k = 0; k < NO; k++) {
-      const float* sr = out + 7 * k;
+        for (int cl = 0; cl < 2; cl++) {
+          const int cc = 2 * (tile - 2) + cl;
+          if (cc < 5) {
+            const float q0 = o[7 * cl + 3], q1 = o[7 * cl + 4], q2 = o[7 * cl + 5], q3 = o[7 * cl + 6];
+            float off[3], sc[3], mu[3];
+            ldn<3>(offset + (c0 + cc) * 3, off);
 #pragma unroll
-      for (int c = 0; c < 3; c++) scales[(c0 + k) * 3 + c] = st.gs[3 + c] * sigmoidf(sr[c]);   // :327-328
-      const float nrm = fmaxf(sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]), 1e-12f);  // F::normalize
-      reinterpret_cast<float4*>(rotations)[c0 + k] = make_float4(sr[3] / nrm, sr[4] / nrm, sr[5] / nrm, sr[6] / nrm);
-#pragma unroll
-      for (int c = 0; c < 3; c++) means3D[(c0 + k) * 3 + c] = st.anc[c] + offset[(c0 + k) * 3 + c] * st.gs[c];  // :331-332
+            for (int c = 0; c < 3; c++) {
+              sc[c] = st.gs[3 + c] * sigmoidf(o[7 * cl + c]);   // :327-328
+              mu[c] = st.anc[c] + off[c] * st.gs[c];            // :331-332
+            }
+            stn<3>(scales + (c0 + cc) * 3, sc);
+            const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);  // F::normalize
+            reinterpret_cast<float4*>(rotations)[c0 + cc] = make_float4(q0 / nrm, q1 / nrm, q2 / nrm, q3 / nrm);
+            stn<3>(means3D + (c0 + cc) * 3, mu);
+          }
+        }
+      }
     }
   }
 }
 
-__global__ void __launch_bounds__(256) neural_bwd_kernel(
+// End of one MLP in the backward pass: relu mask on dH = W2^T dOUT (accumulated tile by tile), H and dHpre to the
+// scratch row, dX (inputs 0..31) on the matrix cores and the view/dist tail on the VALU.
+__device__ __forceinline__ void finish_mlp(const float* __restrict__ img, const Small& S, int m, int lane, int h, const f32x16& hpre,
+                                           f32x16& dh, f32x16& dx, float* dtail, float* __restrict__ row, bool valid) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) dh[r] = hpre[r] > 0.f ? dh[r] : 0.f;
+  if (valid) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {    // registers 4g..4g+3 are hidden units 8g + 4h .. + 3
+      *reinterpret_cast<float4*>(row + R_H + FD * m + 8 * g + 4 * h) =
+          make_float4(fmaxf(hpre[4 * g], 0.f), fmaxf(hpre[4 * g + 1], 0.f), fmaxf(hpre[4 * g + 2], 0.f), fmaxf(hpre[4 * g + 3], 0.f));
+      *reinterpret_cast<float4*>(row + R_DH + FD * m + 8 * g + 4 * h) = make_float4(dh[4 * g], dh[4 * g + 1], dh[4 * g + 2], dh[4 * g + 3]);
+    }
+  }
+  const float* im = img + (I_DX + m * 16) * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 16; s++) dx = __builtin_amdgcn_mfma_f32_32x32x2f32(im[s * 64], dh[s], dx, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const float4 w = *reinterpret_cast<const float4*>(S.w1tail[m][rho(r, h)]);
+    dtail[0] += w.x * dh[r]; dtail[1] += w.y * dh[r]; dtail[2] += w.z * dh[r]; dtail[3] += w.w * dh[r];
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
     Layout L, const uint32_t* __restrict__ count, const uint32_t* __restrict__ vis, const float* __restrict__ anchor,
     const float* __restrict__ offset, const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
-    const float* __restrict__ params, const float* __restrict__ campos, const float* __restrict__ pose7,
+    const float* __restrict__ g_img, const Small* __restrict__ g_small, const float* __restrict__ campos,
     const float* __restrict__ g_means, const float* __restrict__ g_colors, const float* __restrict__ g_opacity,
     const float* __restrict__ g_scales, const float* __restrict__ g_rot, float* __restrict__ d_anchor,
     float* __restrict__ d_offset, float* __restrict__ d_feat, float* __restrict__ d_scaling_log, float* __restrict__ rows) {
-  __shared__ Lds S;
+  extern __shared__ __align__(16) float lds_dyn[];
+  float* img = lds_dyn;
+  Small& S = *reinterpret_cast<Small*>(lds_dyn + N_IMG_BWD * 64);
   const uint32_t n = *count;
-  if (blockIdx.x * 256u >= n) return;
-  stage_weights(S, L, params, pose7);
-  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-  if (t >= n) return;
-  const uint32_t a = vis[t];
-  float* row = rows + (size_t)t * ROW;
-  AnchorState st;
-  anchor_state(S, L, a, anchor, anchor_feat, scaling_log, campos, st);
+  if (blockIdx.x * 128u >= n) return;
+  stage_tables(img, S, N_IMG_BWD, g_img, g_small);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  for (uint32_t g0 = (blockIdx.x * 4u + wv) * 32u; g0 < n; g0 += gridDim.x * 128u) {
+    const uint32_t t = g0 + col;
+    const bool valid = t < n;
+    const uint32_t a = vis[valid ? t : n - 1];
+    float* row = rows + (size_t)(valid ? t : 0) * ROW;
+    AnchorLane st;
+    anchor_lane(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
+    if (valid) stn<L1_STEPS>(row + R_X + L1_STEPS * h, st.xo);
+    const size_t c0 = (size_t)a * NO + 5 * h;
+    f32x16 dx;
 #pragma unroll
-  for (int i = 0; i < XD; i++) row[R_X + i] = st.x[i];
-  const size_t c0 = (size_t)a * NO;
-  float dx[XD];
+    for (int r = 0; r < 16; r++) dx[r] = 0.f;
+    float dtail[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t keep = 0;   // bit r: candidate 5h + r has neural opacity > 0 (the reference's mask, :279)
+    float dgs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, danc[3] = {0.f, 0.f, 0.f};
+    f32x16 hp, dh;
+#pragma unroll 1
+    for (int tile = 0; tile < N_TILES; tile++) {
+      const int m = tile_mlp(tile);
+      if (tile <= 2) {
+        hp = layer1(img, S, m, lane, h, st.xo);
 #pragma unroll
-  for (int i = 0; i < XD; i++) dx[i] = 0.f;
-  uint32_t keep = 0;  // bit k: candidate k has neural opacity > 0 (the reference's mask, :279)
-
-  // ---- opacity MLP
-  {
-    float out[NO];
-    mlp_forward<NO, PAD_O>(S.w1[0], S.b1[0], S.w2o, S.b2o, st.x, out);
+        for (int r = 0; r < 16; r++) dh[r] = 0.f;
+      }
+      f32x16 o = layer2(img, S, tile, lane, h, hp);
+      // ---- element-wise: outputs -> dL/d(output pre-activation), in place
+      if (tile == 0) {
+        float g[5], d[5];
+        ldn<5>(g_opacity + c0, g);
 #pragma unroll
-    for (int k = 0; k < NO; k++) {
-      const float op = tanhf(out[k]);
-      float dpre = 0.f;
-      if (op > 0.f) { keep |= 1u << k; dpre = g_opacity[c0 + k] * (1.f - op * op); }
-      out[k] = dpre;
-      row[R_DO + k] = dpre;
-    }
-    mlp_backward<NO, PAD_O>(S.w1[0], S.b1[0], S.w2o, st.x, out, dx, row + R_H, row + R_DH);
-  }
-  // ---- colour MLP
-  {
-    float out[3 * NO];
-    mlp_forward<3 * NO, PAD_K>(S.w1[2], S.b1[2], S.w2k, S.b2k, st.x, out);
-#pragma unroll
-    for (int e = 0; e < 3 * NO; e++) {
-      const float col = sigmoidf(out[e]);
-      const float dpre = ((keep >> (e / 3)) & 1u) ? g_colors[c0 * 3 + e] * col * (1.f - col) : 0.f;
-      out[e] = dpre;
-      row[R_DK + e] = dpre;
-    }
-    mlp_backward<3 * NO, PAD_K>(S.w1[2], S.b1[2], S.w2k, st.x, out, dx, row + R_H + 2 * FD, row + R_DH + 2 * FD);
-  }
-  // ---- covariance MLP + per-candidate assembly
-  float dgs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, danc[3] = {0.f, 0.f, 0.f};
-  {
-    float out[7 * NO];
-    mlp_forward<7 * NO, PAD_C>(S.w1[1], S.b1[1], S.w2c, S.b2c, st.x, out);
-#pragma unroll
-    for (int k = 0; k < NO; k++) {
-      const bool on = (keep >> k) & 1u;
-      float* sr = out + 7 * k;
-      float dsr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      float doff[3] = {0.f, 0.f, 0.f};
-      if (on) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const float sg = sigmoidf(sr[c]);
-          const float gsc = g_scales[(c0 + k) * 3 + c];
-          dgs[3 + c] += gsc * sg;
-          dsr[c] = gsc * st.gs[3 + c] * sg * (1.f - sg);
-          const float gm = g_means[(c0 + k) * 3 + c];
-          danc[c] += gm;
-          doff[c] = gm * st.gs[c];
-          dgs[c] += gm * offset[(c0 + k) * 3 + c];
+        for (int r = 0; r < 5; r++) {
+          const float op = fast_tanh(o[r]);
+          d[r] = 0.f;
+          if (op > 0.f) { keep |= 1u << r; d[r] = g[r] * (1.f - op * op); }
         }
-        const float4 gr = reinterpret_cast<const float4*>(g_rot)[c0 + k];
-        const float nr = sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]);
-        if (nr >= 1e-12f) {   // r = v / |v|:  dv = (g - r (r.g)) / |v|
-          const float inv = 1.0f / nr;
-          const float r0 = sr[3] * inv, r1 = sr[4] * inv, r2 = sr[5] * inv, r3 = sr[6] * inv;
-          const float dot = r0 * gr.x + r1 * gr.y + r2 * gr.z + r3 * gr.w;
-          dsr[3] = (gr.x - r0 * dot) * inv; dsr[4] = (gr.y - r1 * dot) * inv;
-          dsr[5] = (gr.z - r2 * dot) * inv; dsr[6] = (gr.w - r3 * dot) * inv;
-        } else {              // clamp_min(|v|, eps) active: r = v / eps
-          dsr[3] = gr.x * 1e12f; dsr[4] = gr.y * 1e12f; dsr[5] = gr.z * 1e12f; dsr[6] = gr.w * 1e12f;
+        if (valid) stn<5>(row + R_DO + 8 * h, d);
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] = r < 5 ? d[r] : 0.f;
+      } else if (tile == 1) {
+        float g[15], d[15];
+        ldn<15>(g_colors + c0 * 3, g);
+#pragma unroll
+        for (int r = 0; r < 15; r++) {
+          const float colv = sigmoidf(o[r]);
+          d[r] = ((keep >> (r / 3)) & 1u) ? g[r] * colv * (1.f - colv) : 0.f;
         }
+        if (valid) stn<15>(row + R_DK + 16 * h, d);
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] = r < 15 ? d[r] : 0.f;
+      } else {
+#pragma unroll
+        for (int cl = 0; cl < 2; cl++) {
+          const int cc = 2 * (tile - 2) + cl;
+          const bool on = cc < 5 && ((keep >> cc) & 1u);
+          float dsr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          float doff[3] = {0.f, 0.f, 0.f};
+          if (on) {
+            const float sr3 = o[7 * cl + 3], sr4 = o[7 * cl + 4], sr5 = o[7 * cl + 5], sr6 = o[7 * cl + 6];
+            float gsc[3], gm[3], off[3];
+            ldn<3>(g_scales + (c0 + cc) * 3, gsc);
+            ldn<3>(g_means + (c0 + cc) * 3, gm);
+            ldn<3>(offset + (c0 + cc) * 3, off);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const float sg = sigmoidf(o[7 * cl + c]);
+              dgs[3 + c] += gsc[c] * sg;
+              dsr[c] = gsc[c] * st.gs[3 + c] * sg * (1.f - sg);
+              danc[c] += gm[c];
+              doff[c] = gm[c] * st.gs[c];
+              dgs[c] += gm[c] * off[c];
+            }
+            const float4 gr = reinterpret_cast<const float4*>(g_rot)[c0 + cc];
+            const float nr = sqrtf(sr3 * sr3 + sr4 * sr4 + sr5 * sr5 + sr6 * sr6);
+            if (nr >= 1e-12f) {   // r = v / |v|:  dv = (g - r (r.g)) / |v|
+              const float inv = 1.0f / nr;
+              const float r0 = sr3 * inv, r1 = sr4 * inv, r2 = sr5 * inv, r3 = sr6 * inv;
+              const float dot = r0 * gr.x + r1 * gr.y + r2 * gr.z + r3 * gr.w;
+              dsr[3] = (gr.x - r0 * dot) * inv; dsr[4] = (gr.y - r1 * dot) * inv;
+              dsr[5] = (gr.z - r2 * dot) * inv; dsr[6] = (gr.w - r3 * dot) * inv;
+            } else {              // clamp_min(|v|, eps) active: r = v / eps
+              dsr[3] = gr.x * 1e12f; dsr[4] = gr.y * 1e12f; dsr[5] = gr.z * 1e12f; dsr[6] = gr.w * 1e12f;
+            }
+          }
+          if (valid && cc < 5) {
+            if (on) {   // masked-out candidates add nothing
+              float cur[3];
+              ldn<3>(d_offset + (c0 + cc) * 3, cur);
+#pragma unroll
+              for (int c = 0; c < 3; c++) cur[c] += doff[c];
+              stn<3>(d_offset + (c0 + cc) * 3, cur);
+            }
+            stn<7>(row + R_DC + 36 * h + 7 * cc, dsr);
+          }
+#pragma unroll
+          for (int q = 0; q < 7; q++) o[7 * cl + q] = dsr[q];
+        }
+        o[14] = 0.f; o[15] = 0.f;
+      }
+      // ---- dH += W2^T dOUT for this tile
+      {
+        const float* im = img + (I_DH + tile * 16) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 16; s++) dh = __builtin_amdgcn_mfma_f32_32x32x2f32(im[s * 64], o[s], dh, 0, 0, 0);
+      }
+      if (tile != 2 && tile != 3) finish_mlp(img, S, m, lane, h, hp, dh, dx, dtail, row, valid);
+    }
+    // ---- combine the lane halves
+#pragma unroll
+    for (int c = 0; c < 6; c++) dgs[c] += other_half(dgs[c]);
+#pragma unroll
+    for (int c = 0; c < 3; c++) danc[c] += other_half(danc[c]);
+#pragma unroll
+    for (int c = 0; c < 4; c++) dtail[c] += other_half(dtail[c]);
+    if (valid && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) d_scaling_log[(size_t)a * 6 + c] += dgs[c] * st.gs[c];   // through exp()
+    }
+    // dL/dfeat' for all 32 inputs: mine = rows rho(r,h), the other half's = rows rho(r,1-h)
+    float dxf[FD];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float mine = dx[r], oth = other_half(dx[r]);
+      dxf[rho(r, 0)] = h ? oth : mine;
+      dxf[rho(r, 1)] = h ? mine : oth;
+    }
+    float dview[4] = {dtail[0], dtail[1], dtail[2], dtail[3]};   // view xyz, dist (weights are zero where unused)
+    float4* dfo = reinterpret_cast<float4*>(d_feat + (size_t)a * FD);
+    float df[FD];
+    if (L.bank) {
+      float feat[FD];
+      load_feat(anchor_feat, a, feat);
+      float dbw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < FD; j++) {
+        dbw[0] += dxf[j] * feat[4 * (j % 8)];
+        dbw[1] += dxf[j] * feat[2 * (j % 16)];
+        dbw[2] += dxf[j] * feat[j];
+        df[j] = st.bw[2] * dxf[j];
       }
 #pragma unroll
-      for (int c = 0; c < 3; c++) d_offset[(c0 + k) * 3 + c] += doff[c];
+      for (int j = 0; j < FD; j++) {
+        df[4 * (j % 8)] += st.bw[0] * dxf[j];
+        df[2 * (j % 16)] += st.bw[1] * dxf[j];
+      }
+      const float sdot = st.bw[0] * dbw[0] + st.bw[1] * dbw[1] + st.bw[2] * dbw[2];
+      float dlg[3];
 #pragma unroll
-      for (int q = 0; q < 7; q++) { sr[q] = dsr[q]; row[R_DC + 7 * k + q] = dsr[q]; }
+      for (int c = 0; c < 3; c++) dlg[c] = st.bw[c] * (dbw[c] - sdot);
+      if (valid && h == 0) stn<3>(row + R_DF, dlg);
+      // feature-bank hidden layer: this half's 16 units
+      const float cat4[4] = {st.view[0], st.view[1], st.view[2], st.dist};
+      float dv[4] = {0.f, 0.f, 0.f, 0.f};
+      float hfv[FD / 2], dfv[FD / 2];
+#pragma unroll
+      for (int jj = 0; jj < FD / 2; jj++) {
+        const int j = 16 * h + jj;
+        const float4 w = *reinterpret_cast<const float4*>(S.fw1[j]);
+        const float s = S.fb1[j] + w.x * cat4[0] + w.y * cat4[1] + w.z * cat4[2] + w.w * cat4[3];
+        const float4 u = *reinterpret_cast<const float4*>(S.fw2[j]);
+        float d = u.x * dlg[0] + u.y * dlg[1] + u.z * dlg[2];
+        d = s > 0.f ? d : 0.f;
+        hfv[jj] = fmaxf(s, 0.f); dfv[jj] = d;
+        dv[0] += w.x * d; dv[1] += w.y * d; dv[2] += w.z * d; dv[3] += w.w * d;
+      }
+      if (valid) { stn<FD / 2>(row + R_H + 3 * FD + 16 * h, hfv); stn<FD / 2>(row + R_DH + 3 * FD + 16 * h, dfv); }
+#pragma unroll
+      for (int c = 0; c < 4; c++) dview[c] += dv[c] + other_half(dv[c]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < FD; j++) df[j] = dxf[j];
     }
-    mlp_backward<7 * NO, PAD_C>(S.w1[1], S.b1[1], S.w2c, st.x, out, dx, row + R_H + FD, row + R_DH + FD);
-  }
+    if (valid) {   // each half adds its own 16 features: float4 groups 8g + 4h
 #pragma unroll
-  for (int c = 0; c < 6; c++) d_scaling_log[(size_t)a * 6 + c] += dgs[c] * st.gs[c];   // through exp()
-
-  // ---- input vector: feature bank, view direction, distance
-  float dview[4] = {dx[FD], dx[FD + 1], dx[FD + 2], dx[FD + 3]};   // the dist column of w1 is zero when unused
-  float4* dfo = reinterpret_cast<float4*>(d_feat + (size_t)a * FD);
-  if (L.bank) {
-    float feat[FD];
-    load_feat(anchor_feat, a, feat);
-    float dbw[3] = {0.f, 0.f, 0.f};
-    float df[FD];
-#pragma unroll
-    for (int j = 0; j < FD; j++) {
-      dbw[0] += dx[j] * feat[4 * (j % 8)];
-      dbw[1] += dx[j] * feat[2 * (j % 16)];
-      dbw[2] += dx[j] * feat[j];
-      df[j] = st.bw[2] * dx[j];
+      for (int g = 0; g < 4; g++) {
+        float4 v = dfo[2 * g + h];
+        v.x += h ? df[8 * g + 4] : df[8 * g]; v.y += h ? df[8 * g + 5] : df[8 * g + 1];
+        v.z += h ? df[8 * g + 6] : df[8 * g + 2]; v.w += h ? df[8 * g + 7] : df[8 * g + 3];
+        dfo[2 * g + h] = v;
+      }
     }
-#pragma unroll
-    for (int j = 0; j < FD; j++) {
-      df[4 * (j % 8)] += st.bw[0] * dx[j];
-      df[2 * (j % 16)] += st.bw[1] * dx[j];
-    }
-#pragma unroll
-    for (int q = 0; q < FD / 4; q++) {
-      float4 v = dfo[q];
-      v.x += df[4 * q]; v.y += df[4 * q + 1]; v.z += df[4 * q + 2]; v.w += df[4 * q + 3];
-      dfo[q] = v;
-    }
-    const float sdot = st.bw[0] * dbw[0] + st.bw[1] * dbw[1] + st.bw[2] * dbw[2];
-    float dlg[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { dlg[c] = st.bw[c] * (dbw[c] - sdot); row[R_DF + c] = dlg[c]; }
-#pragma unroll 1
-    for (int j = 0; j < FD; j++) {
-      float s = S.fb1[j];
-#pragma unroll
-      for (int i = 0; i < 4; i++) s += S.fw1[j][i] * st.x[FD + i];
-      float d = S.fw2[j][0] * dlg[0] + S.fw2[j][1] * dlg[1] + S.fw2[j][2] * dlg[2];
-      d = s > 0.f ? d : 0.f;
-      row[R_H + 3 * FD + j] = fmaxf(s, 0.f);
-      row[R_DH + 3 * FD + j] = d;
-#pragma unroll
-      for (int i = 0; i < 4; i++) dview[i] += S.fw1[j][i] * d;
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < FD / 4; q++) {
-      float4 v = dfo[q];
-      v.x += dx[4 * q]; v.y += dx[4 * q + 1]; v.z += dx[4 * q + 2]; v.w += dx[4 * q + 3];
-      dfo[q] = v;
+    // view = ob / |ob|, dist = |ob|:  d ob = (dview - view (view . dview)) / dist + ddist * view
+    if (valid && h == 0) {
+      const float vx = st.view[0], vy = st.view[1], vz = st.view[2];
+      const float dot = vx * dview[0] + vy * dview[1] + vz * dview[2];
+      d_anchor[(size_t)a * 3 + 0] += danc[0] + (dview[0] - vx * dot) * st.inv_dist + dview[3] * vx;
+      d_anchor[(size_t)a * 3 + 1] += danc[1] + (dview[1] - vy * dot) * st.inv_dist + dview[3] * vy;
+      d_anchor[(size_t)a * 3 + 2] += danc[2] + (dview[2] - vz * dot) * st.inv_dist + dview[3] * vz;
     }
   }
-  // view = ob / |ob|, dist = |ob|:  d ob = (dview - view (view . dview)) / dist + ddist * view
-  {
-    const float vx = st.x[FD], vy = st.x[FD + 1], vz = st.x[FD + 2];
-    const float dot = vx * dview[0] + vy * dview[1] + vz * dview[2];
-    danc[0] += (dview[0] - vx * dot) * st.inv_dist + dview[3] * vx;
-    danc[1] += (dview[1] - vy * dot) * st.inv_dist + dview[3] * vy;
-    danc[2] += (dview[2] - vz * dot) * st.inv_dist + dview[3] * vz;
-  }
-#pragma unroll
-  for (int c = 0; c < 3; c++) d_anchor[(size_t)a * 3 + c] += danc[c];
 }
 
 // ---- weight gradients ---------------------------------------------------------------------------------------------
 struct WJob {
-  int a_off, M;       // activation columns [a_off, a_off+M) of the scratch row (the Linear's input)
-  int b_off, N;       // pre-activation gradient columns (the Linear's output)
+  int a_off, M;       // activation field of the scratch row (the Linear's input), M columns
+  int a_x0;           // >= 0: the field is x in lane order and column i is input a_x0 + i at position 18 (k&1) + (k>>1)
+  int b_off, N;       // pre-activation gradient field (the Linear's output), N stored columns
+  int b_half;         // > 0: stored column j = b_half * h + r is output b_real * h + r for r < b_real (else padding)
+  int b_real;
   int w_off, ldw;     // dW[j][i] -> gsum[w_off + j*ldw + i]
   int bias_off;       // db[j]   -> gsum[bias_off + j]
   int active;
 };
 struct WJobs { WJob j[WG_JOBS]; };
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // One wave per (job, slice).  MFMA operands are read straight from the scratch rows in lane order: lane l supplies
 // act[row k0 + (l>>5)][column l&31] as A[i][k] and dpre[row][column l&31] as B[k][j]; both are 128-B contiguous per
@@ -514,7 +715,9 @@ __global__ void __launch_bounds__(64) wgrad_mfma_kernel(WJobs jobs, const uint32
 #pragma unroll
       for (int it = 0; it < 2; it++) {
         const int i = it * 32 + c;
-        av[u][it] = (live && i < job.M) ? row[job.a_off + i] : 0.f;
+        const int kx = job.a_x0 + i;
+        const int apos = job.a_x0 >= 0 ? 18 * (kx & 1) + (kx >> 1) : i;
+        av[u][it] = (live && i < job.M) ? row[job.a_off + apos] : 0.f;
       }
 #pragma unroll
       for (int jt = 0; jt < 3; jt++) {
@@ -558,25 +761,39 @@ __global__ void __launch_bounds__(64) wgrad_mfma_kernel(WJobs jobs, const uint32
 
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WJobs jobs, const float* __restrict__ partial, float* __restrict__ gsum,
                                                            float* __restrict__ dparams) {
+  __shared__ float part[4][64];
   const WJob job = jobs.j[blockIdx.y];
   if (!job.active) return;
   const int nelem = (job.M + 1) * job.N;   // weight entries + one bias row
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= nelem) return;
-  const int i = e / job.N, j = e - i * job.N;
-  int slot;
-  if (i < job.M) slot = (((i >> 5) * 3 + (j >> 5)) * 32 + (i & 31)) * 32 + (j & 31);
-  else slot = ((1 * 3 + (j >> 5)) * 32 + 31) * 32 + (j & 31);
-  const float* p = partial + (size_t)blockIdx.y * WG_WAVES * WG_TILE + slot;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int w = 0; w < WG_WAVES; w += 4) {
-    s0 += p[(size_t)w * WG_TILE]; s1 += p[(size_t)(w + 1) * WG_TILE];
-    s2 += p[(size_t)(w + 2) * WG_TILE]; s3 += p[(size_t)(w + 3) * WG_TILE];
+  if (blockIdx.x * 64 >= nelem) return;
+  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;   // element of this workgroup, slice of the partial waves
+  const int e = blockIdx.x * 64 + el;
+  float s = 0.f;
+  int dst = 0;
+  bool live = false;
+  if (e < nelem) {
+    const int i = e / job.N, j = e - i * job.N;
+    int slot;
+    if (i < job.M) slot = (((i >> 5) * 3 + (j >> 5)) * 32 + (i & 31)) * 32 + (j & 31);
+    else slot = ((1 * 3 + (j >> 5)) * 32 + 31) * 32 + (j & 31);
+    int o = j;   // output unit of stored column j
+    if (job.b_half > 0) { const int hh = j / job.b_half, r = j - hh * job.b_half; o = r < job.b_real ? job.b_real * hh + r : -1; }
+    live = o >= 0;
+    dst = i < job.M ? job.w_off + o * job.ldw + i : job.bias_off + o;
+    const float* p = partial + ((size_t)blockIdx.y * WG_WAVES + q * (WG_WAVES / 4)) * WG_TILE + slot;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < WG_WAVES / 4; w += 8)
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc[u] += p[(size_t)(w + u) * WG_TILE];
+    s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
-  const float s = (s0 + s1) + (s2 + s3);
-  const int dst = i < job.M ? job.w_off + j * job.ldw + i : job.bias_off + j;
-  gsum[dst] = s;
-  dparams[dst] += s;
+  part[q][el] = s;
+  __syncthreads();
+  if (q == 0 && live) {
+    const float t = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    gsum[dst] = t;
+    dparams[dst] += t;
+  }
 }
 
 // Appearance embedding: appearance_feat = Wa pose + ba is the same for every anchor and enters the colour MLP's first
@@ -607,14 +824,15 @@ __global__ void __launch_bounds__(64) appearance_finish_kernel(Layout L, const f
 
 WJobs make_jobs(const Layout& L) {
   WJobs J;
-  const int nout[3] = {NO, 7 * NO, 3 * NO};
+  const int nstored[3] = {16, 72, 32};          // opacity, cov, colour: stored (padded) output columns
+  const int per_half[3] = {8, 36, 16}, real_half[3] = {5, 35, 15};
   const int dout_off[3] = {R_DO, R_DC, R_DK};
   for (int m = 0; m < 3; m++) {
-    J.j[m] = WJob{R_X, FD + 3 + L.dist[m], R_DH + FD * m, FD, L.w1[m], L.in[m], L.b1[m], 1};
-    J.j[3 + m] = WJob{R_H + FD * m, FD, dout_off[m], nout[m], L.w2[m], FD, L.b2[m], 1};
+    J.j[m] = WJob{R_X, FD + 3 + L.dist[m], 0, R_DH + FD * m, FD, 0, 0, L.w1[m], L.in[m], L.b1[m], 1};
+    J.j[3 + m] = WJob{R_H + FD * m, FD, -1, dout_off[m], nstored[m], per_half[m], real_half[m], L.w2[m], FD, L.b2[m], 1};
   }
-  J.j[6] = WJob{R_X + FD, 4, R_DH + FD * 3, FD, L.fw1, 4, L.fb1, L.bank};
-  J.j[7] = WJob{R_H + FD * 3, FD, R_DF, 3, L.fw2, FD, L.fb2, L.bank};
+  J.j[6] = WJob{R_X, 4, FD, R_DH + FD * 3, FD, 0, 0, L.fw1, 4, L.fb1, L.bank};
+  J.j[7] = WJob{R_H + FD * 3, FD, -1, R_DF, 3, 0, 0, L.fw2, FD, L.fb2, L.bank};
   return J;
 }
 
@@ -654,8 +872,10 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
   if (e != hipSuccess) return (int)e;
   const int nb = (A + 255) / 256;
   compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity);
-  neural_fwd_kernel<<<nb, 256, 0, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, mlp_params, camera_center,
-                                        pose7, means3D, colors, opacity, scales, rotations, neural_opacity);
+  static_assert(N_IMG_BWD == 262 && sizeof(Small) <= 8192, "temp_carve sizes");
+  pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small);
+  neural_fwd_kernel<<<NEURAL_GRID, 256, N_IMG_FWD * 64 * sizeof(float) + sizeof(Small), st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
+                                        camera_center, means3D, colors, opacity, scales, rotations, neural_opacity);
   e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : (int)e;
 }
@@ -677,13 +897,16 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
     return SEGS_ERR_INVALID_ARGUMENT;
   Temp T;
   temp_carve(A, L.total, temp, &T);
-  const int nb = (A + 255) / 256;
-  neural_bwd_kernel<<<nb, 256, 0, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, mlp_params, camera_center,
-                                        pose7, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor,
+  constexpr size_t bwd_lds = N_IMG_BWD * 64 * sizeof(float) + sizeof(Small);   // > 64 KB: needs the opt-in below
+  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
+  if (attr_rc != hipSuccess) return (int)attr_rc;
+  neural_bwd_kernel<<<NEURAL_GRID, 256, bwd_lds, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
+                                        camera_center, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor,
                                         dL_doffset, dL_dfeat, dL_dscaling_log, T.rows);
   const WJobs J = make_jobs(L);
   wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), 64, 0, st>>>(J, T.count, T.rows, T.partial);
-  wgrad_reduce_kernel<<<dim3((37 * 70 + 255) / 256, WG_JOBS), 256, 0, st>>>(J, T.partial, T.gsum, dL_dmlp_params);
+  wgrad_reduce_kernel<<<dim3((37 * 72 + 63) / 64, WG_JOBS), 256, 0, st>>>(J, T.partial, T.gsum, dL_dmlp_params);
   if (L.app > 0) appearance_finish_kernel<<<1, 64, 0, st>>>(L, mlp_params, pose7, T.gsum, dL_dmlp_params);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : (int)e;

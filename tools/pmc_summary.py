@@ -21,7 +21,7 @@ def main():
             for row in csv.DictReader(open(f)):
                 k = (row["Dispatch_Id"], row["Counter_Name"])
                 per_dispatch[k] += float(row["Counter_Value"])  # rows may be split per XCD/instance
-                names[row["Dispatch_Id"]] = row["Kernel_Name"].split("(")[0]
+                names[row["Dispatch_Id"]] = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             for (disp, cname), v in per_dispatch.items():
                 a = acc[names[disp]][cname]
                 a[0] += v
