@@ -100,11 +100,16 @@ _p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
 
 
 class ScaffoldModel:
-    """Anchors + MLPs in one flat parameter bucket (and a same-shaped gradient bucket) on `device`."""
+    """Anchors + MLPs in one flat parameter bucket (plus same-shaped gradient and Adam-moment buckets) on `device`.
 
+    The anchor segments are laid out for `capacity` >= A anchors so that densification (densify.AnchorDensifier) appends
+    and prunes rows in place; views returned by param()/grad() cover the first A rows."""
 
-    def __init__(self, A: int, dims: ModelDims, device):
+    WIDTHS = (("anchor", 3), ("offset", None), ("anchor_feat", None), ("scaling", 6))
+
+    def __init__(self, A: int, dims: ModelDims, device, capacity: Optional[int] = None):
         self.A, self.dims, self.device = int(A), dims, torch.device(device)
+        self.capacity = max(int(capacity or A), self.A, 1)
         self._lib = _capi.lib()
         self._cdims = dims.c_struct()
         offs = (C.c_int64 * 18)()
@@ -112,40 +117,69 @@ class ScaffoldModel:
         nt, total = C.c_int(0), C.c_int64(0)
         _capi.check(self._lib.segs_neural_param_layout(C.byref(self._cdims), offs, cnts, C.byref(nt), C.byref(total)),
                     "segs_neural_param_layout")
-        names = dims.mlp_tensor_names()
-        assert nt.value == len(names)
+        self._mlp_names = dims.mlp_tensor_names()
+        assert nt.value == len(self._mlp_names)
         self.mlp_total = int(total.value)
-        widths = {"anchor": 3, "offset": 3 * dims.n_offsets, "anchor_feat": dims.feat_dim, "scaling": 6}
-        self.segments: Dict[str, Tuple[int, int]] = {}
+        self._mlp_rel = {n: (int(offs[i]), int(cnts[i])) for i, n in enumerate(self._mlp_names)}
+        self.widths = {"anchor": 3, "offset": 3 * dims.n_offsets, "anchor_feat": dims.feat_dim, "scaling": 6}
+        self._allocate(self.capacity)
+
+    def _allocate(self, capacity: int):
+        self.capacity = int(capacity)
+        self.seg_offset: Dict[str, int] = {}
         pos = 0
         for name in ("anchor", "offset", "anchor_feat", "scaling"):
-            self.segments[name] = (pos, self.A * widths[name])
-            pos += self.A * widths[name]
+            self.seg_offset[name] = pos
+            pos += self.capacity * self.widths[name]
         self.mlp_offset = pos
         self.n_params = pos + self.mlp_total
         f = dict(dtype=torch.float32, device=self.device)
         self.params = torch.zeros(self.n_params, **f)
         self.grads = torch.zeros(self.n_params, **f)
-        self.mlp_layout = {n: (pos + int(offs[i]), int(cnts[i])) for i, n in enumerate(names)}
-        self.rotation = torch.zeros((self.A, 4), **f)   # _rotation: identity quaternion, never trained
+        self.exp_avg = torch.zeros(self.n_params, **f)       # Adam moments, same layout (torch::optim::Adam state)
+        self.exp_avg_sq = torch.zeros(self.n_params, **f)
+        self.mlp_layout = {n: (pos + o, c) for n, (o, c) in self._mlp_rel.items()}
+        self.rotation = torch.zeros((self.capacity, 4), **f)   # _rotation: identity quaternion, never trained
         self.rotation[:, 0] = 1.0
-        self.opacity = torch.zeros((self.A, 1), **f)    # _opacity: unused by the forward
+        self.opacity = torch.zeros((self.capacity, 1), **f)    # _opacity: unused by the forward
+
+    def reserve(self, capacity: int):
+        """Grow the buckets to `capacity` anchors, keeping the first A rows of every segment and the MLP block."""
+        if capacity <= self.capacity:
+            return
+        old = {k: getattr(self, k) for k in ("params", "grads", "exp_avg", "exp_avg_sq")}
+        old_off, old_mlp, old_rot, old_op = dict(self.seg_offset), self.mlp_offset, self.rotation, self.opacity
+        self._allocate(capacity)
+        for k, src in old.items():
+            dst = getattr(self, k)
+            for name, w in self.widths.items():
+                n = self.A * w
+                dst[self.seg_offset[name]:self.seg_offset[name] + n] = src[old_off[name]:old_off[name] + n]
+            dst[self.mlp_offset:] = src[old_mlp:]
+        self.rotation[:self.A] = old_rot[:self.A]
+        self.opacity[:self.A] = old_op[:self.A]
+
+    @property
+    def segments(self) -> Dict[str, Tuple[int, int]]:
+        """(offset, live element count) of the anchor segments."""
+        return {n: (self.seg_offset[n], self.A * w) for n, w in self.widths.items()}
 
     # -- views
-    def _view(self, bucket, name):
-        if name in self.segments:
-            o, n = self.segments[name]
-            shape = {"anchor": (self.A, 3), "offset": (self.A, self.dims.n_offsets, 3),
-                     "anchor_feat": (self.A, self.dims.feat_dim), "scaling": (self.A, 6)}[name]
-            return bucket[o:o + n].view(shape)
+    def _view(self, bucket, name, rows=None):
+        if name in self.widths:
+            rows = self.A if rows is None else rows
+            o = self.seg_offset[name]
+            shape = {"anchor": (rows, 3), "offset": (rows, self.dims.n_offsets, 3),
+                     "anchor_feat": (rows, self.dims.feat_dim), "scaling": (rows, 6)}[name]
+            return bucket[o:o + rows * self.widths[name]].view(shape)
         o, n = self.mlp_layout[name]
         return bucket[o:o + n].view(self.dims.mlp_tensor_shape(name))
 
-    def param(self, name):
-        return self._view(self.params, name)
+    def param(self, name, rows=None):
+        return self._view(self.params, name, rows)
 
-    def grad(self, name):
-        return self._view(self.grads, name)
+    def grad(self, name, rows=None):
+        return self._view(self.grads, name, rows)
 
     @property
     def mlp_params(self):
@@ -163,8 +197,9 @@ class ScaffoldModel:
 
     def adam_groups(self, lrs: Dict[str, float]) -> List[Tuple[int, int, float]]:
         """(offset, count, lr) per Adam group in the reference's order (src/gaussian_model.cpp:632-690)."""
-        out = [(*self.segments["anchor"], lrs["anchor"]), (*self.segments["offset"], lrs["offset"]),
-               (*self.segments["anchor_feat"], lrs["anchor_feat"]), (*self.segments["scaling"], lrs["scaling"])]
+        seg = self.segments
+        out = [(*seg["anchor"], lrs["anchor"]), (*seg["offset"], lrs["offset"]),
+               (*seg["anchor_feat"], lrs["anchor_feat"]), (*seg["scaling"], lrs["scaling"])]
         for m, key in (("mlp_opacity", "mlp_opacity"), ("mlp_cov", "mlp_cov"), ("mlp_color", "mlp_color"),
                        ("mlp_apperance", "appearance"), ("mlp_feature_bank", "mlp_featurebank")):
             names = [n for n in self.mlp_layout if n.startswith(m + ".")]
@@ -179,24 +214,40 @@ class NeuralGaussians:
 
     def __init__(self, model: ScaffoldModel):
         self.model = model
-        A, no, dev = model.A, model.dims.n_offsets, model.device
         self._lib = model._lib
-        f = dict(dtype=torch.float32, device=dev)
-        self.P = A * no
-        self.means3D = torch.zeros((self.P, 3), **f)
-        self.colors = torch.zeros((self.P, 3), **f)
-        self.opacity = torch.zeros((self.P, 1), **f)
-        self.scales = torch.zeros((self.P, 3), **f)
-        self.rotations = torch.zeros((self.P, 4), **f)
-        self.neural_opacity = torch.zeros((self.P, 1), **f)
-        self.temp = torch.empty(self._lib.segs_neural_temp_bytes(C.byref(model._cdims), A), dtype=torch.uint8, device=dev)
+        self._cap = 0
+        self._ensure()
         self._last = None
+
+    @property
+    def P(self):
+        """live candidate slots = A * n_offsets (the leading rows of the capacity-sized buffers)"""
+        return self.model.A * self.model.dims.n_offsets
+
+    def _ensure(self):
+        """(re)allocate the candidate-domain buffers when the model's capacity grew"""
+        model = self.model
+        if model.capacity <= self._cap:
+            return
+        self._cap = model.capacity
+        f = dict(dtype=torch.float32, device=model.device)
+        Pc = self._cap * model.dims.n_offsets
+        self.P_capacity = Pc
+        self.means3D = torch.zeros((Pc, 3), **f)
+        self.colors = torch.zeros((Pc, 3), **f)
+        self.opacity = torch.zeros((Pc, 1), **f)
+        self.scales = torch.zeros((Pc, 3), **f)
+        self.rotations = torch.zeros((Pc, 4), **f)
+        self.neural_opacity = torch.zeros((Pc, 1), **f)
+        self.temp = torch.empty(self._lib.segs_neural_temp_bytes(C.byref(model._cdims), self._cap), dtype=torch.uint8,
+                                device=model.device)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.model.device).cuda_stream)
 
     def forward(self, camera_center: torch.Tensor, pose7: torch.Tensor, visible_radii: Optional[torch.Tensor]):
         m = self.model
+        self._ensure()
         st = self._lib.segs_neural_forward(
             C.byref(m._cdims), m.A, _p(m.param("anchor")), _p(m.param("offset")), _p(m.param("anchor_feat")),
             _p(m.param("scaling")), _p(visible_radii), _p(m.mlp_params), _p(camera_center), _p(pose7), _p(self.means3D),
@@ -208,7 +259,7 @@ class NeuralGaussians:
 
     def mask(self):
         """The reference's `mask` (neural_opacity > 0, src/gaussian_renderer.cpp:279) in the candidate domain."""
-        return self.neural_opacity.view(-1) > 0
+        return self.neural_opacity.view(-1)[:self.P] > 0
 
     def backward(self, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations):
         """Accumulates into model.grads."""
@@ -244,20 +295,41 @@ class ScaffoldTrainerStep:
         dev = model.device
         self._lib = model._lib
         self.neural = NeuralGaussians(model)
-        self.engine = RasterEngine(self.neural.P, width, height, dev, resident=True, skip_nonpositive_opacity=True)
+        self.engine = RasterEngine(self.neural.P_capacity, width, height, dev, resident=True, skip_nonpositive_opacity=True)
         self.loss_fn = FusedL1SSIM(height, width, dev, self.opt.lambda_dssim)
         self.bg = torch.zeros(3, dtype=torch.float32, device=dev)
-        self.visible_radii = torch.zeros(model.A, dtype=torch.int32, device=dev)
-        self.exp_avg = torch.zeros_like(model.params)
-        self.exp_avg_sq = torch.zeros_like(model.params)
+        self.visible_radii = torch.zeros(model.capacity, dtype=torch.int32, device=dev)
         self.spatial_lr_scale = float(spatial_lr_scale)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         self.iteration = 0
+        # torch::optim::Adam keeps one step count per parameter; they only diverge at densification iterations, where
+        # the re-created anchor tensors have no gradient and are skipped by the optimizer (src/gaussian_model.cpp:1677)
+        self.anchor_steps = 0
+        self.mlp_steps = 0
+        self.densifier = None            # densify.AnchorDensifier, see enable_densification()
+        self.densify_generator = None
+
+    def enable_densification(self, densifier, seed: int = 0):
+        """training_statis / adjust_anchor on the schedule of trainForOneIteration (src/gaussian_mapper.cpp:961-968); the
+        random keep masks come from a generator seeded identically on every rank."""
+        self.densifier = densifier
+        self.densify_generator = torch.Generator(device="cpu").manual_seed(seed)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.model.device).cuda_stream)
+
+    def _adam(self, groups, step: int):
+        if not groups:
+            return
+        segs = (_capi.AdamSegment * len(groups))()
+        for i, (o, n, lr) in enumerate(groups):
+            segs[i].offset, segs[i].count, segs[i].lr = o, n, float(lr)
+        m = self.model
+        st = self._lib.segs_adam_step(_p(m.params), _p(m.grads), _p(m.exp_avg), _p(m.exp_avg_sq), segs, len(groups),
+                                      self.opt.beta1, self.opt.beta2, self.opt.eps, step, 1.0 / self.world, 1, self._stream())
+        _capi.check(st, "segs_adam_step")
 
     def learning_rates(self, it: int) -> Dict[str, float]:
         """updateLearningRate (src/gaussian_model.cpp:874-915); anchor/offset scaled by spatial_lr_scale (:637,640)."""
@@ -280,7 +352,7 @@ class ScaffoldTrainerStep:
         (src/gaussian_renderer.cpp:131-199); the result stays on the device."""
         m = self.model
         scales = torch.exp(m.param("scaling")[:, :3]).contiguous()
-        rots = torch.nn.functional.normalize(m.rotation)
+        rots = torch.nn.functional.normalize(m.rotation[:m.A])
         st = self._lib.segs_visible_filter(m.A, 0, self.W, self.H, _p(m.param("anchor")), _p(scales), 1.0, _p(rots), None,
                                            _p(kf.view), _p(kf.proj), float(kf.tanfovx), float(kf.tanfovy), 0,
                                            _p(self.visible_radii), self._stream())
@@ -289,7 +361,12 @@ class ScaffoldTrainerStep:
 
     def render(self, kf: Keyframe) -> torch.Tensor:
         ng = self.neural
+        if self.model.capacity * self.model.dims.n_offsets > self.engine.P:   # the map outgrew the engine's buffers
+            self.engine = RasterEngine(self.model.capacity * self.model.dims.n_offsets, self.W, self.H, self.model.device,
+                                       resident=True, skip_nonpositive_opacity=True)
+            self.visible_radii = torch.zeros(self.model.capacity, dtype=torch.int32, device=self.model.device)
         ng.forward(kf.campos, kf.pose7, self.prefilter_voxel(kf))
+        self.engine.set_active(ng.P)
         return self.engine.forward(self.bg, ng.means3D, ng.colors, ng.opacity, ng.scales, ng.rotations, kf.view, kf.proj,
                                    kf.campos, kf.tanfovx, kf.tanfovy)
 
@@ -313,14 +390,28 @@ class ScaffoldTrainerStep:
             loss = self._forward_backward(keyframes[k], gt_images[k])
         if self.world > 1:
             dist.all_reduce(self.model.grads, group=self.pg)
+        adjusted = False
+        d = self.densifier
+        if d is not None and d.p.start_stat < self.iteration < d.p.update_until:      # gaussian_mapper.cpp:961-968
+            d.training_statis(self.neural, self.visible_radii, self.engine.radii, self.engine.dL_dmean2D)
+            if self.iteration > d.p.update_from and self.iteration % d.p.update_interval == 0:
+                d.adjust_anchor(generator=self.densify_generator)
+                adjusted = True
         groups = self.model.adam_groups(lrs)
-        segs = (_capi.AdamSegment * len(groups))()
-        for i, (o, n, lr) in enumerate(groups):
-            segs[i].offset, segs[i].count, segs[i].lr = o, n, float(lr)
-        st = self._lib.segs_adam_step(_p(self.model.params), _p(self.model.grads), _p(self.exp_avg), _p(self.exp_avg_sq), segs,
-                                      len(groups), self.opt.beta1, self.opt.beta2, self.opt.eps, self.iteration,
-                                      1.0 / self.world, 1, self._stream())
-        _capi.check(st, "segs_adam_step")
+        anchor_groups, mlp_groups = groups[:4], groups[4:]
+        self.mlp_steps += 1
+        if adjusted:
+            # the six anchor tensors were re-created by adjust_anchor: no gradient, skipped by Adam this iteration
+            for name in self.model.widths:
+                self.model.grad(name).zero_()
+            self._adam(mlp_groups, self.mlp_steps)
+        else:
+            self.anchor_steps += 1
+            if self.anchor_steps == self.mlp_steps:
+                self._adam(groups, self.mlp_steps)
+            else:
+                self._adam(anchor_groups, self.anchor_steps)
+                self._adam(mlp_groups, self.mlp_steps)
         return loss
 
 

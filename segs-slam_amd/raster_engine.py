@@ -54,7 +54,8 @@ class RasterEngine:
         self.flags = 1 if skip_nonpositive_opacity else 0
         self.capacity = 0
         self._status_host = None
-        self.P, self.W, self.H = int(P), int(width), int(height)
+        self.P, self.W, self.H = int(P), int(width), int(height)   # P = allocated rows; P_active <= P are rasterized
+        self.P_active = self.P
         self.device = torch.device(device)
         f = dict(dtype=torch.float32, device=self.device)
         self.out_color = torch.zeros((3, self.H, self.W), **f)
@@ -71,6 +72,11 @@ class RasterEngine:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_active(self, P_active: int):
+        """Rasterize only the first P_active rows of the (P-row) inputs: a map that grows inside pre-sized buffers."""
+        assert 0 < P_active <= self.P
+        self.P_active = int(P_active)
 
     # ---- resident mode plumbing
     def _setup_resident(self, R: int):
@@ -109,7 +115,7 @@ class RasterEngine:
         self._lib.segs_raster_set_flags(self.flags)  # per host thread; set on every call
         if self.resident and self.capacity > 0:
             st = self._lib.segs_rasterize_forward_resident(
-                p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P, 0, 0, p(bg), self.W, self.H, p(means3D),
+                p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
                 None, p(colors), p(opacity), p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix),
                 p(campos), float(tanfovx), float(tanfovy), p(self.out_color), p(self.radii), p(self._status), self._stream())
             _capi.check(st, "segs_rasterize_forward_resident")
@@ -124,7 +130,7 @@ class RasterEngine:
         self._last_resident = False
         n = C.c_int(0)
         st = self._lib.segs_rasterize_forward(
-            self.geom.cb, None, self.binning.cb, None, self.img.cb, None, self.P, 0, 0, p(bg), self.W, self.H, p(means3D),
+            self.geom.cb, None, self.binning.cb, None, self.img.cb, None, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
             None, p(colors), p(opacity), p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix),
             p(campos), float(tanfovx), float(tanfovy), 0, p(self.out_color), p(self.radii), self._stream(), C.byref(n))
         _capi.check(st, "segs_rasterize_forward")
@@ -144,7 +150,7 @@ class RasterEngine:
         g = self.grads
         if getattr(self, "_last_resident", False):
             st = self._lib.segs_rasterize_backward_resident(
-                p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P, 0, 0, p(bg), self.W, self.H, p(means3D),
+                p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
                 None, p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix), p(campos),
                 float(tanfovx), float(tanfovy), p(self.radii), p(dL_dout_color), p(self.dL_dmean2D), p(self.dL_dconic),
                 p(g["opacity"]), p(g["colors"]), p(g["means3D"]), p(self.dL_dcov3D), None, p(g["scales"]), p(g["rotations"]),
@@ -152,7 +158,7 @@ class RasterEngine:
             _capi.check(st, "segs_rasterize_backward_resident")
             return g
         st = self._lib.segs_rasterize_backward(
-            self.P, 0, 0, self.R, p(bg), self.W, self.H, p(means3D), None, p(colors), p(scales), float(scale_modifier),
+            self.P_active, 0, 0, self.R, p(bg), self.W, self.H, p(means3D), None, p(colors), p(scales), float(scale_modifier),
             p(rotations), None, p(viewmatrix), p(projmatrix), p(campos), float(tanfovx), float(tanfovy), p(self.radii),
             p(self.geom.tensor), p(self.binning.tensor), p(self.img.tensor), p(dL_dout_color), p(self.dL_dmean2D),
             p(self.dL_dconic), p(g["opacity"]), p(g["colors"]), p(g["means3D"]), p(self.dL_dcov3D), None, p(g["scales"]),

@@ -1,0 +1,142 @@
+"""GPU parity of the anchor statistics / densification (include/segs_densify.h, segs-slam_amd/densify.py) against the
+torch restatement of src/gaussian_model.cpp:1459-1762 (oracle/densify_ref.py).
+
+Integer / index work (which voxels receive an anchor, their order, the per-voxel feature maximum, row compaction) is
+compared exactly; the accumulated gradient norms to 1e-6 relative (sqrt rounding)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import densify_ref, neural_ref  # noqa: E402
+
+DIMS = dict(feat_dim=32, n_offsets=10, appearance_dim=0, use_feat_bank=False)
+
+
+def _model(A, seed, dev, capacity=None):
+    from segs_slam_amd import neural_gaussians as ng
+    rd = neural_ref.NeuralDims(**DIMS)
+    g = torch.Generator().manual_seed(seed)
+    anchor = torch.rand(A, 3, generator=g) - 0.5
+    offset = torch.randn(A, 10, 3, generator=g)
+    offset[::7] = 0.0                                        # candidates that fall into their parent's voxel
+    feat = torch.randn(A, 32, generator=g)
+    scaling_log = torch.log(0.02 + 0.08 * torch.rand(A, 6, generator=g))
+    _, _, _, _, mlp = neural_ref.random_model(rd, 1, seed)
+    model = ng.ScaffoldModel(A, ng.ModelDims(**DIMS), dev, capacity=capacity)
+    model.load(anchor, offset, feat, scaling_log, mlp)
+    return model, (anchor, offset, feat, scaling_log), g
+
+
+def test_training_statis_matches_restatement():
+    from segs_slam_amd import densify, neural_gaussians as ng
+    dev = torch.device("cuda:0")
+    A, no = 900, 10
+    model, _, g = _model(A, 3, dev)
+    dens = densify.AnchorDensifier(model)
+    gen = ng.NeuralGaussians(model)
+    visible = torch.rand(A, generator=g) < 0.6
+    nop = torch.tanh(torch.randn(A * no, generator=g))
+    nop[~visible.repeat_interleave(no)] = 0.0
+    radii = (torch.rand(A * no, generator=g) < 0.5).to(torch.int32) * 4
+    g2d = torch.randn(A * no, 3, generator=g)
+    gen.neural_opacity.copy_(nop.view(-1, 1))
+    vis_radii = visible.to(torch.int32) * 2
+    init = {k: torch.rand_like(v.cpu()) for k, v in dens._stats.items()}
+    for k, v in init.items():
+        dens._stats[k].copy_(v)
+    dens.training_statis(gen, vis_radii.to(dev), radii.to(dev), g2d.to(dev))
+    torch.cuda.synchronize()
+
+    st = densify_ref.DensifyState(params={}, exp_avg={}, exp_avg_sq={}, opacity_accum=init["opacity_accum"].view(-1, 1).clone(),
+                                  anchor_demon=init["anchor_demon"].view(-1, 1).clone(),
+                                  offset_gradient_accum=init["offset_gradient_accum"].view(-1, 1).clone(),
+                                  offset_denom=init["offset_denom"].view(-1, 1).clone())
+    vis_rows = visible.repeat_interleave(no)
+    mask = nop[vis_rows] > 0                                   # offset_selection_mask over the visible anchors' slots
+    full_mask = torch.zeros(A * no, dtype=torch.bool)
+    full_mask[vis_rows] = mask
+    densify_ref.training_statis(st, g2d[full_mask], nop[vis_rows].view(-1, 1), radii[full_mask] > 0, mask, visible)
+    np.testing.assert_array_equal(dens.stat("anchor_demon").cpu().numpy(), st.anchor_demon.numpy())
+    np.testing.assert_array_equal(dens.stat("offset_denom").cpu().numpy(), st.offset_denom.numpy())
+    np.testing.assert_allclose(dens.stat("opacity_accum").cpu().numpy(), st.opacity_accum.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(dens.stat("offset_gradient_accum").cpu().numpy(), st.offset_gradient_accum.numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("A,seed,capacity", [(600, 1, None), (2500, 2, 9000), (40, 5, None)])
+def test_adjust_anchor_matches_restatement(A, seed, capacity):
+    from segs_slam_amd import densify
+    dev = torch.device("cuda:0")
+    no = 10
+    model, (anchor, offset, feat, scaling_log), g = _model(A, seed, dev, capacity)
+    P = densify.DensifyParams(voxel_size=0.01, update_depth=3, update_init_factor=16, update_hierachy_factor=4)
+    dens = densify.AnchorDensifier(model, P)
+    # statistics: about half of the offsets eligible, a third of the anchors old enough to be judged
+    denom = torch.floor(torch.rand(A * no, generator=g) * 100)
+    accum = torch.rand(A * no, generator=g) * denom * 0.0005
+    demon = torch.floor(torch.rand(A, generator=g) * 160)
+    opac = torch.rand(A, generator=g) * demon * 0.01
+    for k, v in (("offset_denom", denom), ("offset_gradient_accum", accum), ("anchor_demon", demon), ("opacity_accum", opac)):
+        dens._stats[k][:v.numel()] = v.to(dev)
+    m_rand = {n: torch.randn(A, w, generator=g) for n, w in model.widths.items()}
+    v_rand = {n: torch.rand(A, w, generator=g) for n, w in model.widths.items()}
+    for n in model.widths:
+        model._view(model.exp_avg, n).copy_(m_rand[n].view(model._view(model.exp_avg, n).shape))
+        model._view(model.exp_avg_sq, n).copy_(v_rand[n].view(model._view(model.exp_avg_sq, n).shape))
+    rands = [torch.rand(A * no, generator=g) for _ in range(3)]
+
+    rot = torch.zeros(A, 4); rot[:, 0] = 1.0
+    ref = densify_ref.DensifyState(
+        params={"anchor": anchor.clone(), "offset": offset.clone(), "anchor_feat": feat.clone(), "opacity": torch.zeros(A, 1),
+                "scaling": scaling_log.clone(), "rotation": rot},
+        exp_avg={"anchor": m_rand["anchor"].clone(), "offset": m_rand["offset"].view(A, no, 3).clone(),
+                 "anchor_feat": m_rand["anchor_feat"].clone(), "scaling": m_rand["scaling"].clone()},
+        exp_avg_sq={"anchor": v_rand["anchor"].clone(), "offset": v_rand["offset"].view(A, no, 3).clone(),
+                    "anchor_feat": v_rand["anchor_feat"].clone(), "scaling": v_rand["scaling"].clone()},
+        opacity_accum=opac.view(-1, 1).clone(), anchor_demon=demon.view(-1, 1).clone(),
+        offset_gradient_accum=accum.view(-1, 1).clone(), offset_denom=denom.view(-1, 1).clone(),
+        voxel_size=0.01, update_depth=3, update_init_factor=16, update_hierachy_factor=4)
+    ref_prune = densify_ref.adjust_anchor(ref, 100, 0.8, 0.0002, 0.005, rands)
+
+    prune = dens.adjust_anchor(100, 0.8, 0.0002, 0.005, rands=[r.to(dev) for r in rands])
+    torch.cuda.synchronize()
+    A1 = ref.params["anchor"].shape[0]
+    grown = ref_prune.shape[0] - A
+    assert grown > 0 and int(ref_prune.sum()) > 0, "the case must exercise both growing and pruning"
+    assert model.A == A1
+    np.testing.assert_array_equal(prune.cpu().numpy(), ref_prune.numpy())
+    eq = lambda a, b, msg: np.testing.assert_array_equal(a.cpu().numpy(), b.numpy(), err_msg=msg)  # noqa: E731
+    eq(model.param("anchor"), ref.params["anchor"], "anchor")
+    eq(model.param("offset"), ref.params["offset"], "offset")
+    eq(model.param("anchor_feat"), ref.params["anchor_feat"], "anchor_feat")
+    np.testing.assert_allclose(model.param("scaling").cpu().numpy(), ref.params["scaling"].numpy(), rtol=0, atol=1e-6)
+    eq(model.rotation[:A1], ref.params["rotation"], "rotation")
+    np.testing.assert_allclose(model.opacity[:A1].cpu().numpy(), ref.params["opacity"].numpy(), atol=1e-6)
+    for n in ("anchor", "offset", "anchor_feat", "scaling"):
+        eq(model._view(model.exp_avg, n), ref.exp_avg[n], "exp_avg " + n)
+        eq(model._view(model.exp_avg_sq, n), ref.exp_avg_sq[n], "exp_avg_sq " + n)
+    for k in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
+        eq(dens.stat(k), getattr(ref, k), k)
+
+
+def test_trainer_keeps_running_through_densification():
+    from segs_slam_amd import densify, neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    cam = scenes.make_camera(320, 240, 300.0, 300.0, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+    model = ng.synthetic_model(3000, ng.ModelDims(), cam, dev, seed=4)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    step = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
+    dens = densify.AnchorDensifier(model, densify.DensifyParams(voxel_size=0.01, start_stat=2, update_from=5, update_interval=10,
+                                                                update_until=1000, densify_grad_threshold=1e-7))
+    step.enable_densification(dens, seed=0)
+    gt = torch.full((3, cam.height, cam.width), 0.4, device=dev)
+    sizes = []
+    for it in range(1, 32):
+        loss = step.training_once([kf], [gt])
+        sizes.append(model.A)
+        assert np.isfinite(float(loss))
+    assert sizes[-1] != 3000, sizes[::5]      # the map changed size and the step kept running
+    assert step.mlp_steps == 31 and step.anchor_steps == 28   # anchor tensors skipped by Adam at the 3 densify iterations
