@@ -231,12 +231,45 @@ __device__ __forceinline__ float fold_rows4(float a, float b, float c, float d) 
 // them into the reference's dL/dmean2D, dL/dconic, dL/dopacity (backward.cu:541-554) with the per-Gaussian conic.
 constexpr int BW_SLOTS = 16;
 constexpr int BW_STRIDE = 65;  // padded row of the transposed tiles: conflict-free in both roles
-struct BwdLds {                  // 10112 B per wave -> 4 workgroups (16 waves) per CU
+struct BwdLds {                  // 10176 B per wave -> 4 workgroups (16 waves) per CU
   float4 rec[BW_SLOTS][3];      // staged records of the current batch: [0] x y a2 b2  [1] c2 o r g  [2] b pos id -
   float wt[BW_SLOTS][BW_STRIDE];
   float at[BW_SLOTS][BW_STRIDE];  // its first 16x12 floats are reused as the moment exchange area `mom`
-  float4 dp[64];                // dL/dpixel (r,g,b) of the quadrant's pixels
+  float4 dp[64 + 4];            // dL/dpixel (r,g,b) of pixel p at [p + (p >> 4)]: the four 16-pixel parts read by the
+                                // Gaussian role in one instruction land in different banks (a 64-dword part stride was 2-way)
 };
+
+
+// Pixel role of the backward kernel over one batch of `nb` staged records (see render_bwd_kernel).  USE_BG = false
+// drops the background term of dL/dalpha (bg . dL/dpixel == 0 for every pixel of the wave: SLAM renders on black).
+template <bool USE_BG>
+__device__ __forceinline__ void pixel_role(BwdLds& L, int nb, int lane, float pxf, float pyf, uint32_t last_contributor,
+                                           float dp0, float dp1, float dp2, float T_final, float bg_dot_dpixel, float& T,
+                                           float& acc0, float& acc1, float& acc2) {
+#ifndef PIX_UNROLL
+#define PIX_UNROLL 2
+#endif
+#pragma unroll PIX_UNROLL
+  for (int sl = 0; sl < nb; sl++) {
+    const float4 q0 = L.rec[sl][0], q1 = L.rec[sl][1];
+    const float2 q2 = *reinterpret_cast<const float2*>(&L.rec[sl][2]);
+    const float dx = q0.x - pxf, dy = q0.y - pyf;
+    const float power2 = dx * (q0.z * dx + q0.w * dy) + (q1.x * dy) * dy;
+    const float ar = q1.y * fast_exp2(power2);  // o * G
+    // alpha = min(0.99, ar) >= 1/255  <=>  ar >= 1/255
+    const bool ok = __float_as_uint(q2.y) < last_contributor && power2 <= 0.0f && ar >= 1.0f / 255.0f;
+    const float aw = ok ? ar : 0.f;      // o * G (the clamp at 0.99 is not differentiated, backward.cu:497); 0 on skipped pairs
+    const float ae = fminf(0.99f, aw);   // alpha; 0 makes every update below a no-op
+    const float rinv = fast_rcp(1.f - ae);
+    T = T * rinv;                        // T / (1 - alpha)
+    const float d0 = q1.z - acc0, d1 = q1.w - acc1, d2 = q2.x - acc2;
+    float dL_dalpha = (d0 * dp0 + d1 * dp1 + d2 * dp2) * T;
+    if (USE_BG) dL_dalpha += (-T_final * rinv) * bg_dot_dpixel;
+    acc0 += ae * d0; acc1 += ae * d1; acc2 += ae * d2;  // alpha*c + (1-alpha)*acc  (backward.cu:513-516)
+    L.wt[sl][lane] = aw * dL_dalpha;     // = dL_dG * G
+    L.at[sl][lane] = ae * T;             // = dchannel_dcolor
+  }
+}
 
 __global__ void __launch_bounds__(256) render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
@@ -261,6 +294,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
   float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
   if (inside) { dp0 = dL_dpix[pix_id]; dp1 = dL_dpix[HW + pix_id]; dp2 = dL_dpix[2 * HW + pix_id]; }
   const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+  const bool use_bg = __ballot(bg_dot_dpixel != 0.f) != 0ull;   // wave-uniform
 
   // Start at the deepest contributor of this 8x8 block (backward.cu:487-488).
   uint32_t wave_last = last_contributor;
@@ -269,7 +303,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
   wave_last = __builtin_amdgcn_readfirstlane(wave_last);
   if (wave_last == 0u) return;
 
-  L.dp[lane] = make_float4(dp0, dp1, dp2, 0.f);
+  L.dp[lane + (lane >> 4)] = make_float4(dp0, dp1, dp2, 0.f);
   float T = T_final, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;  // acc = colour accumulated BEHIND the current Gaussian
 
   // Gaussian-role constants
@@ -293,7 +327,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
     }
   }
   for (int32_t cbase = cfirst; cbase >= 0; cbase -= 64) {
-    const int n = cc.n;
+    const int n = __builtin_amdgcn_readfirstlane(cc.n);
     // current chunk's records stay in registers (one per lane, compacted order); the next chunk's go in flight
     const float4 c0 = r0, c1 = r1;
     const float4 c2 = make_float4(rb, __uint_as_float((uint32_t)cbase + cc.pos), __uint_as_float(cc.val & ID_MASK), 0.f);
@@ -309,35 +343,14 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
     }
     float (*mom)[12] = reinterpret_cast<float (*)[12]>(&L.at[0][0]);
     for (int b0 = 0; b0 < n; b0 += BW_SLOTS) {
-      const int nb = min(BW_SLOTS, n - b0);
+      const int nb = __builtin_amdgcn_readfirstlane(min(BW_SLOTS, n - b0));
       if (lane >= b0 && lane < b0 + nb) {
         L.rec[lane - b0][0] = c0; L.rec[lane - b0][1] = c1; L.rec[lane - b0][2] = c2;
       }
       wave_lds_fence();
       // ---------------- (1) pixel role
-#ifndef PIX_UNROLL
-#define PIX_UNROLL 1
-#endif
-#pragma unroll PIX_UNROLL
-      for (int sl = 0; sl < nb; sl++) {
-        const float4 q0 = L.rec[sl][0], q1 = L.rec[sl][1];
-        const float2 q2 = *reinterpret_cast<const float2*>(&L.rec[sl][2]);
-        const float dx = q0.x - pxf, dy = q0.y - pyf;
-        const float power2 = dx * (q0.z * dx + q0.w * dy) + (q1.x * dy) * dy;
-        const float ar = q1.y * fast_exp2(power2);  // o * G
-        const float alpha = fminf(0.99f, ar);
-        const bool ok = __float_as_uint(q2.y) < last_contributor && power2 <= 0.0f && alpha >= 1.0f / 255.0f;
-        const float ae = ok ? alpha : 0.f;   // skipped pairs: alpha = 0 makes every update below a no-op
-        const float aw = ok ? ar : 0.f;      // o * G (the clamp at 0.99 is not differentiated, backward.cu:497)
-        const float rinv = fast_rcp(1.f - ae);
-        T = T * rinv;                        // T / (1 - alpha)
-        const float d0 = q1.z - acc0, d1 = q1.w - acc1, d2 = q2.x - acc2;
-        float dL_dalpha = (d0 * dp0 + d1 * dp1 + d2 * dp2) * T;
-        dL_dalpha += (-T_final * rinv) * bg_dot_dpixel;
-        acc0 += ae * d0; acc1 += ae * d1; acc2 += ae * d2;  // alpha*c + (1-alpha)*acc  (backward.cu:513-516)
-        L.wt[sl][lane] = aw * dL_dalpha;     // = dL_dG * G
-        L.at[sl][lane] = ae * T;             // = dchannel_dcolor
-      }
+      if (use_bg) pixel_role<true>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, acc0, acc1, acc2);
+      else pixel_role<false>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, acc0, acc1, acc2);
       wave_lds_fence();
       // ---------------- (2) Gaussian role: lane = (part, gs): slot gs, pixels part*16 .. part*16+15
       // Moments are taken about the quadrant pixel NEAREST to the Gaussian's centre (cx, cy in 0..7), not about the
@@ -346,22 +359,27 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
       const float2 gxy = *reinterpret_cast<const float2*>(&L.rec[gs][0]);
       const float gxr = gxy.x - qx0f, gyr = gxy.y - qy0f;
       const float cx = fminf(7.f, fmaxf(0.f, rintf(gxr))), cy = fminf(7.f, fmaxf(0.f, rintf(gyr)));
-      float px8[8];
+      // The six w-moments are separable over the lane's two pixel rows (8 pixels each): per pixel only the row sums
+      // R0 = sum w, R1 = sum w x, R2 = sum w x^2 (3 ops), per row six more; the colour sums need dL/dpixel per pixel.
+      float px8[8], px8q[8];
 #pragma unroll
-      for (int c = 0; c < 8; c++) px8[c] = (float)c - cx;
+      for (int c = 0; c < 8; c++) { px8[c] = (float)c - cx; px8q[c] = px8[c] * px8[c]; }
       const float pyc0 = pyl0 - cy, pyc1 = pyl1 - cy;
-      float S0 = 0.f, S1x = 0.f, S1y = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Sr = 0.f, Sg = 0.f, Sb = 0.f;
+      float S0, S1x, S1y, Sxx, Sxy, Syy, Sr = 0.f, Sg = 0.f, Sb = 0.f;
+      {
+        float R0[2] = {0.f, 0.f}, R1[2] = {0.f, 0.f}, R2[2] = {0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int p = part * 16 + i;
-        const float w = L.wt[gs][p], a = L.at[gs][p];
-        const float4 d = L.dp[p];
-        const float pxl = px8[i & 7];
-        const float pyl = (i >> 3) ? pyc1 : pyc0;
-        const float wx = w * pxl, wy = w * pyl;
-        S0 += w; S1x += wx; S1y += wy;
-        Sxx += wx * pxl; Sxy += wx * pyl; Syy += wy * pyl;
-        Sr += a * d.x; Sg += a * d.y; Sb += a * d.z;
+        for (int i = 0; i < 16; i++) {
+          const int p = part * 16 + i;
+          const float w = L.wt[gs][p], a = L.at[gs][p];
+          const float4 d = L.dp[p + part];   // p >> 4 == part
+          R0[i >> 3] += w; R1[i >> 3] += w * px8[i & 7]; R2[i >> 3] += w * px8q[i & 7];
+          Sr += a * d.x; Sg += a * d.y; Sb += a * d.z;
+        }
+        S0 = R0[0] + R0[1]; S1x = R1[0] + R1[1]; Sxx = R2[0] + R2[1];
+        S1y = pyc0 * R0[0] + pyc1 * R0[1];
+        Sxy = pyc0 * R1[0] + pyc1 * R1[1];
+        Syy = (pyc0 * pyc0) * R0[0] + (pyc1 * pyc1) * R0[1];
       }
       const float g1 = fold_rows4(S0, S1y, S1x, Sxx);   // rows: S0, S1x, S1y, Sxx
       const float g2 = fold_rows4(Sxy, Sr, Syy, Sg);    // rows: Sxy, Syy, Sr, Sg
