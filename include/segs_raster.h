@@ -108,7 +108,7 @@ int segs_project2_image(int P, int D, int M, int width, int height, const float*
 int segs_debug_unpack_geometry(const char* geom_buffer, int P, const int* radii, float* means2D /*P,2*/,
                                float* conic_opacity /*P,4*/, float* depths /*P*/, uint32_t* tiles_touched /*P*/,
                                uint32_t* point_offsets /*P*/, float* rgb /*P,3*/, void* stream);
-int segs_debug_unpack_binning(const char* binning_buffer, int R, int width, int height,
+int segs_debug_unpack_binning(const char* binning_buffer, const char* geom_buffer, int P, int R, int width, int height,
                               uint64_t* keys_sorted /*R*/, uint32_t* point_list /*R*/, void* stream);
 int segs_debug_unpack_image(const char* image_buffer, int width, int height, uint32_t* ranges /*tiles,2*/,
                             float* final_T /*H*W*/, uint32_t* n_contrib /*H*W*/, void* stream);

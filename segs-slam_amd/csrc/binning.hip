@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const BinIn
 constexpr int EMIT_SLOTS = 1024;
 __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec, const uint32_t* __restrict__ order,
-    const uint32_t* __restrict__ incl, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
+    const uint32_t* __restrict__ incl, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
     const uint32_t* __restrict__ n_dev /* resident mode: R lives on the device, `R` is the capacity */) {
   __shared__ uint32_t s_incl[EMIT_SLOTS + 1];
   if (n_dev) R = (int)min(*n_dev, (uint32_t)R);
@@ -179,10 +179,7 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
         if (ellipse_hits_rect(cx, cy, A, B, C, k, x0, x0 + 7.f, y0, y0 + 7.f)) mask |= 1u << qd;
       }
     }
-    uint64_t key = (uint64_t)(ty * gx + tx);
-    key <<= 32;
-    key |= (uint64_t)bb.x;
-    keys[j] = key;
+    keys[j] = ty * gx + tx;   // tile id only: depth order is already the emission order
     vals[j] = s_idx[g] | (mask << ID_BITS);
   }
 }
@@ -198,6 +195,9 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, KeyMap km)
   const uint64_t kc = km.dbits < 0 ? (key >> 32) : (((key >> 32) << km.dbits) | (uint64_t)((uint32_t)key - km.dmin));
   return (uint32_t)(kc >> shift) & 0xFFu;
 }
+// 32-bit keys (the pipeline's own two sorts: depth bits of the P Gaussians, tile ids of the R instances): 20 instead of
+// 32 bytes moved per key and pass.
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, KeyMap km) { return ((key - km.dmin) >> shift) & 0xFFu; }
 
 // Per-lane mask of the lanes (among `valid`) holding the same 8-bit digit: 8 ballots.
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint64_t valid) {
@@ -214,8 +214,9 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {  // number of set bits o
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Count matrix: block_hist[d * nblocks + b] = number of keys of workgroup b's 4096-key tile with digit d.
-__global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const uint64_t* __restrict__ keys, int n, int shift,
+// Count matrix: block_hist[d * nblocks + b] = number of keys of workgroup b's 2048-key tile with digit d.
+template <typename K>
+__global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __restrict__ keys, int n, int shift,
                                                                     uint32_t dmin, int dbits,
                                                                     uint32_t* __restrict__ block_hist, int nblocks,
                                                                     const uint32_t* __restrict__ n_dev) {
@@ -227,11 +228,11 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const uint64_
   __syncthreads();
   const size_t wave_base = (size_t)blockIdx.x * SORT_TILE + (size_t)wv * (SORT_TILE / 4);
   volatile uint32_t* my = cnt[wv];
-  uint64_t kreg[SORT_ITEMS_PER_THREAD];
+  K kreg[SORT_ITEMS_PER_THREAD];
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {  // all loads in flight before the first use
     const size_t i = wave_base + (size_t)r * 64 + lane;
-    kreg[r] = i < (size_t)n ? keys[i] : 0ull;
+    kreg[r] = i < (size_t)n ? keys[i] : (K)0;
   }
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
@@ -277,14 +278,15 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ 
   if (tid == 0) digit_totals[blockIdx.x] = carry_s;
 }
 
-// Stable scatter of one 4096-key tile.
+// Stable scatter of one 2048-key tile (SORT_TILE).
+template <typename K>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
-    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
+    const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, K* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int n, int shift, uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist,
     const uint32_t* __restrict__ digit_totals, int nblocks, const uint32_t* __restrict__ n_dev) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
-  __shared__ uint64_t s_keys[SORT_TILE];
+  __shared__ K s_keys[SORT_TILE];
   __shared__ uint32_t s_vals[SORT_TILE];
   __shared__ uint32_t cnt[4][256];       // per-wave running digit counters, then per-wave bases
   __shared__ uint32_t local_start[256];  // start of digit run inside the tile
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   const size_t wave_base = tile_base + (size_t)wv * (SORT_TILE / 4);
   const int nvalid = (size_t)n > tile_base ? (int)min((size_t)SORT_TILE, (size_t)n - tile_base) : 0;
 
-  uint64_t key[SORT_ITEMS_PER_THREAD];
+  K key[SORT_ITEMS_PER_THREAD];
   uint32_t val[SORT_ITEMS_PER_THREAD];
   uint32_t drank[SORT_ITEMS_PER_THREAD];  // digit | wave-local rank << 8 ; 0xFFFFFFFF = invalid
   volatile uint32_t* my = cnt[wv];
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     const size_t i = wave_base + (size_t)r * 64 + lane;
     const bool valid = i < (size_t)n;
-    key[r] = valid ? keys_in[i] : 0ull;
+    key[r] = valid ? keys_in[i] : (K)0;
     val[r] = valid ? vals_in[i] : 0u;
   }
 #pragma unroll
@@ -370,7 +372,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     const int lp = r * SORT_THREADS + tid;
     if (lp < nvalid) {
-      const uint64_t k = s_keys[lp];
+      const K k = s_keys[lp];
       const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of(k, shift, km)]);
       keys_out[gp] = k;
       vals_out[gp] = s_vals[lp];
@@ -378,17 +380,24 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   }
 }
 
+template __global__ void radix_count_kernel<uint64_t>(const uint64_t*, int, int, uint32_t, int, uint32_t*, int, const uint32_t*);
+template __global__ void radix_count_kernel<uint32_t>(const uint32_t*, int, int, uint32_t, int, uint32_t*, int, const uint32_t*);
+template __global__ void radix_scatter_kernel<uint64_t>(const uint64_t*, const uint32_t*, uint64_t*, uint32_t*, int, int, uint32_t, int,
+                                                        const uint32_t*, const uint32_t*, int, const uint32_t*);
+template __global__ void radix_scatter_kernel<uint32_t>(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, int, int, uint32_t, int,
+                                                        const uint32_t*, const uint32_t*, int, const uint32_t*);
+
 // ---------------------------------------------------------------------------------------------
 // K9 (ranges are zeroed by the caller with hipMemsetAsync, as rasterizer_impl.cu:310 does).
-__global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ keys,
+__global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys,
                                                                    uint2* __restrict__ ranges, const uint32_t* __restrict__ n_dev) {
   if (n_dev) L = (int)min(*n_dev, (uint32_t)L);
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= L) return;
-  const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+  const uint32_t cur = keys[idx];
   if (idx == 0) ranges[cur].x = 0;
   else {
-    const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+    const uint32_t prev = keys[idx - 1];
     if (cur != prev) { ranges[prev].y = idx; ranges[cur].x = idx; }
   }
   if (idx == L - 1) ranges[cur].y = L;
@@ -421,12 +430,12 @@ __global__ void __launch_bounds__(256) unpack_geometry_kernel(
 
 // Depth-sort input: one (depth bits, idx) pair per Gaussian.  Culled Gaussians (no instances) get a 1 in the tile
 // field, i.e. compacted key 1 << dbits, strictly behind every visible one when sorting dbits + 1 bits.
-__global__ void __launch_bounds__(256) make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, uint32_t dmin,
-                                                              uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ void __launch_bounds__(256) make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, uint32_t dcull,
+                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   const uint4 b = reinterpret_cast<const uint4*>(bin)[i];
-  keys[i] = b.w ? (uint64_t)b.x : ((1ull << 32) | (uint64_t)dmin);
+  keys[i] = b.w ? b.x : dcull;   // culled Gaussians sort strictly after every visible one
   vals[i] = (uint32_t)i;
 }
 // Per-workgroup sums of tiles_touched taken in depth order (feeds scan_block_sums_kernel for the emitter).
@@ -475,4 +484,15 @@ __global__ void __launch_bounds__(256) strip_mask_kernel(int n, const uint32_t* 
   if (i < n) out[i] = vals[i] & ID_MASK;
 }
 
+}  // namespace segs
+
+namespace segs {
+// Test support: the reference's sorted 64-bit keys (tile << 32 | depth bits, rasterizer_impl.cu:100-104) rebuilt from the
+// sorted tile ids and the depth of each instance's Gaussian.
+__global__ void __launch_bounds__(256) rebuild_keys_kernel(int R, const uint32_t* __restrict__ tile_keys, const uint32_t* __restrict__ vals,
+                                                           const BinInfo* __restrict__ bin, uint64_t* __restrict__ keys64) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R) return;
+  keys64[i] = ((uint64_t)tile_keys[i] << 32) | (uint64_t)bin[vals[i] & ID_MASK].depth_bits;
+}
 }  // namespace segs

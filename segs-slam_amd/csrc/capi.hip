@@ -83,6 +83,7 @@ uint32_t getHigherMsb(uint32_t n) {
 
 // K8: stable LSD radix sort, 8 bits per pass over key bits [0,end_bit).  Input is expected in side
 // `passes & 1` of the ping-pong pair so that the result lands in side 0.
+template <typename K>
 int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t dmin, int dbits, hipStream_t st,
                const uint32_t* n_dev = nullptr) {
   if (n <= 0) return SEGS_OK;
@@ -91,13 +92,13 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
   uint32_t* block_hist = (uint32_t*)(bin + L.block_hist);
   uint32_t* digit_totals = (uint32_t*)(bin + L.digit_totals);
   for (int p = 0; p < passes; p++) {
-    const uint64_t* kin = (const uint64_t*)(bin + L.keys[side]);
+    const K* kin = (const K*)(bin + L.keys[side]);
     const uint32_t* vin = (const uint32_t*)(bin + L.vals[side]);
-    uint64_t* kout = (uint64_t*)(bin + L.keys[side ^ 1]);
+    K* kout = (K*)(bin + L.keys[side ^ 1]);
     uint32_t* vout = (uint32_t*)(bin + L.vals[side ^ 1]);
     const int shift = 8 * p;
     { PROF(K_RADIX_COUNT);
-    radix_count_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, block_hist, L.nblocks, n_dev);
+    radix_count_kernel<K><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, block_hist, L.nblocks, n_dev);
     }
     LAUNCH_TRY("radix_count_kernel");
     { PROF(K_RADIX_SCAN);
@@ -105,8 +106,8 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     }
     LAUNCH_TRY("radix_scan_kernel");
     { PROF(K_RADIX_SCATTER);
-    radix_scatter_kernel<<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, block_hist, digit_totals, L.nblocks,
-                                                             n_dev);
+    radix_scatter_kernel<K><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, block_hist, digit_totals, L.nblocks,
+                                                              n_dev);
     }
     LAUNCH_TRY("radix_scatter_kernel");
     side ^= 1;
@@ -152,17 +153,18 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
 // `n_cap` is R (host-known) or, in resident mode, the capacity of the instance arrays with the true R in *n_dev.
 // `total_out` (3 device words) receives the instance count produced by the depth-ordered scan.
 int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSortLayout& GS, uint2* ranges, int P, int n_cap,
-                const uint32_t* n_dev, uint32_t dmin, int dbits, uint32_t gx, uint32_t gy, uint32_t* total_out, hipStream_t st) {
+                const uint32_t* n_dev, uint32_t dmin, int dbits, uint32_t dcull, uint32_t gx, uint32_t gy, uint32_t* total_out,
+                hipStream_t st) {
   const int bit = (int)getHigherMsb(gx * gy);
   // (1)
   char* gbin = bin + GS.base;
   const BinningLayout& GL = GS.inner;
-  const int gside = ((dbits + 1 + 7) / 8) & 1;  // dbits depth bits + 1 "culled" bit
+  const int gside = ((dbits + 7) / 8) & 1;  // depth keys in [dmin, dcull], dcull - dmin < 2^dbits; culled Gaussians carry dcull
   { PROF(K_DUPLICATE);
-  make_depth_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), dmin, (uint64_t*)(gbin + GL.keys[gside]), (uint32_t*)(gbin + GL.vals[gside]));
+  make_depth_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), dcull, (uint32_t*)(gbin + GL.keys[gside]), (uint32_t*)(gbin + GL.vals[gside]));
   }
   LAUNCH_TRY("make_depth_keys_kernel");
-  int rc = sort_pairs(gbin, GL, P, dbits + 1, dmin, dbits, st);
+  int rc = sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st);
   if (rc) return rc;
   const uint32_t* order = (const uint32_t*)(gbin + GL.vals[0]);
   // (2)
@@ -183,14 +185,14 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   LAUNCH_TRY("ordered_offsets_kernel");
   { PROF(K_DUPLICATE);
   duplicate_with_keys_kernel<<<(n_cap + 1023) / 1024, 256, 0, st>>>(P, n_cap, G.bin(), G.rec(), order, G.offsets(),
-                                                                    (uint64_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev);
+                                                                    (uint32_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev);
   }
   LAUNCH_TRY("duplicate_with_keys_kernel");
   // (3)
-  rc = sort_pairs(bin, BL, n_cap, bit, 0u, -1, st, n_dev);
+  rc = sort_pairs<uint32_t>(bin, BL, n_cap, bit, 0u, 0, st, n_dev);
   if (rc) return rc;
   { PROF(K_RANGES);
-  identify_tile_ranges_kernel<<<(n_cap + 255) / 256, 256, 0, st>>>(n_cap, (const uint64_t*)(bin + BL.keys[0]), ranges, n_dev);
+  identify_tile_ranges_kernel<<<(n_cap + 255) / 256, 256, 0, st>>>(n_cap, (const uint32_t*)(bin + BL.keys[0]), ranges, n_dev);
   }
   LAUNCH_TRY("identify_tile_ranges_kernel");
   return SEGS_OK;
@@ -272,11 +274,11 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)gx * gy * sizeof(uint2), st));   // rasterizer_impl.cu:310
   }
   if (R > 0) {
-    const uint32_t dmin = ~hdr[1], dspan = hdr[2] - dmin;
+    const uint32_t dmin = ~hdr[1], dspan = hdr[2] - dmin + 1u;   // +1: the key of culled Gaussians, one past the deepest visible
     int dbits = 1;
     while (dbits < 32 && (dspan >> dbits) != 0u) dbits++;
     uint32_t* total_scratch = (uint32_t*)(bin + GS.block_sums) + G.L.nblocks;
-    int rc = run_binning(G, bin, BL, GS, ranges, P, R, nullptr, dmin, dbits, gx, gy, total_scratch, st);
+    int rc = run_binning(G, bin, BL, GS, ranges, P, R, nullptr, dmin, dbits, dmin + dspan, gx, gy, total_scratch, st);
     if (rc) return rc;
   }
   { PROF(K_RENDER_FWD);
@@ -381,15 +383,20 @@ int segs_debug_unpack_geometry(const char* geom_buffer, int P, const int* radii,
   return SEGS_OK;
 }
 
-int segs_debug_unpack_binning(const char* binning_buffer, int R, int width, int height, uint64_t* keys_sorted,
-                              uint32_t* point_list, void* stream) {
+int segs_debug_unpack_binning(const char* binning_buffer, const char* geom_buffer, int P, int R, int width, int height,
+                              uint64_t* keys_sorted, uint32_t* point_list, void* stream) {
   (void)width; (void)height;
   hipStream_t st = (hipStream_t)stream;
   if (R <= 0) return SEGS_OK;
-  if (!binning_buffer) return fail(SEGS_ERR_INVALID_ARGUMENT, "null pointer");
+  if (!binning_buffer || (keys_sorted && (!geom_buffer || P <= 0))) return fail(SEGS_ERR_INVALID_ARGUMENT, "null pointer");
   const BinningLayout BL = binning_layout(R);
   const char* bin = align_ptr(binning_buffer);
-  if (keys_sorted) HIP_TRY(hipMemcpyAsync(keys_sorted, bin + BL.keys[0], (size_t)R * 8, hipMemcpyDeviceToDevice, st));
+  if (keys_sorted) {   // the pipeline sorts 32-bit tile ids; the reference's 64-bit keys are rebuilt for parity checks
+    const Geom G = geom_at(const_cast<char*>(geom_buffer), P);
+    rebuild_keys_kernel<<<(R + 255) / 256, 256, 0, st>>>(R, (const uint32_t*)(bin + BL.keys[0]), (const uint32_t*)(bin + BL.vals[0]),
+                                                        G.bin(), keys_sorted);
+    LAUNCH_TRY("rebuild_keys_kernel");
+  }
   if (point_list) {
     strip_mask_kernel<<<(R + 255) / 256, 256, 0, st>>>(R, (const uint32_t*)(bin + BL.vals[0]), point_list);
     LAUNCH_TRY("strip_mask_kernel");
@@ -441,7 +448,7 @@ int segs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* 
   const int side = passes & 1;
   HIP_TRY(hipMemcpyAsync(bin + BL.keys[side], keys_in, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemcpyAsync(bin + BL.vals[side], vals_in, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-  int rc = sort_pairs(bin, BL, n, end_bit, 0u, 32, st);
+  int rc = sort_pairs<uint64_t>(bin, BL, n, end_bit, 0u, 32, st);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(keys_out, bin + BL.keys[0], (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipMemcpyAsync(vals_out, bin + BL.vals[0], (size_t)n * 4, hipMemcpyDeviceToDevice, st));
@@ -516,8 +523,9 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
   { PROF(K_MEMSET);
   HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)gx * gy * sizeof(uint2), st));
   }
-  // depth keys are sorted on all 32 bits (+1): the exact range is only known on the device
-  rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, 0u, 32, gx, gy, status, st);
+  // depth keys are sorted on all 32 bits (the exact range is only known on the device); positive finite floats stay below
+  // the culled key 0xFFFFFFFF
+  rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, 0u, 32, 0xFFFFFFFFu, gx, gy, status, st);
   if (rc) return rc;
   overflow_flag_kernel<<<1, 1, 0, st>>>(status, (uint32_t)capacity);
   LAUNCH_TRY("overflow_flag_kernel");

@@ -43,16 +43,18 @@ __global__ void ordered_offsets_kernel(int P, const BinInfo* __restrict__ bin, c
                                        const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ incl);
 __global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
-                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
+                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
                                            const uint32_t* __restrict__ n_dev);
-__global__ void radix_count_kernel(const uint64_t* __restrict__ keys, int n, int shift, uint32_t dmin, int dbits,
+template <typename K>   // K = uint32_t (the pipeline's own sorts) or uint64_t (segs_sort_pairs)
+__global__ void radix_count_kernel(const K* __restrict__ keys, int n, int shift, uint32_t dmin, int dbits,
                                    uint32_t* __restrict__ block_hist, int nblocks, const uint32_t* __restrict__ n_dev);
 __global__ void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_totals);
-__global__ void radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
+template <typename K>
+__global__ void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                     K* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
                                      uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_totals, int nblocks,
                                      const uint32_t* __restrict__ n_dev);
-__global__ void identify_tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges,
+__global__ void identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges,
                                             const uint32_t* __restrict__ n_dev);
 
 // ---- render.hip
@@ -70,7 +72,9 @@ __global__ void unpack_geometry_kernel(int P, const float* __restrict__ rec, con
                                        float* __restrict__ conic_opacity, float* __restrict__ depths,
                                        uint32_t* __restrict__ tiles_touched, float* __restrict__ rgb);
 
-__global__ void make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, uint32_t dmin, uint64_t* __restrict__ keys,
+__global__ void rebuild_keys_kernel(int R, const uint32_t* __restrict__ tile_keys, const uint32_t* __restrict__ vals,
+                                    const BinInfo* __restrict__ bin, uint64_t* __restrict__ keys64);
+__global__ void make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, uint32_t dcull, uint32_t* __restrict__ keys,
                                        uint32_t* __restrict__ vals);
 __global__ void ordered_block_sums_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
                                           uint32_t* __restrict__ block_sums);

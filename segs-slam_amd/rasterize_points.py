@@ -209,7 +209,7 @@ def debug_state(P, W, H, R, radii, geomBuffer, binningBuffer, imageBuffer):
                                                      p("depths"), p("tiles_touched"), p("point_offsets"), p("rgb"), st),
                         "segs_debug_unpack_geometry")
         if R:
-            _capi.check(l.segs_debug_unpack_binning(_ptr(binningBuffer), R, W, H, p("keys"), p("point_list"), st),
+            _capi.check(l.segs_debug_unpack_binning(_ptr(binningBuffer), _ptr(geomBuffer), P, R, W, H, p("keys"), p("point_list"), st),
                         "segs_debug_unpack_binning")
         _capi.check(l.segs_debug_unpack_image(_ptr(imageBuffer), W, H, p("ranges"), p("final_T"), p("n_contrib"), st),
                     "segs_debug_unpack_image")
