@@ -161,7 +161,8 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   const BinningLayout& GL = GS.inner;
   const int gside = ((dbits + 7) / 8) & 1;  // depth keys in [dmin, dcull], dcull - dmin < 2^dbits; culled Gaussians carry dcull
   { PROF(K_DUPLICATE);
-  make_depth_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), dcull, (uint32_t*)(gbin + GL.keys[gside]), (uint32_t*)(gbin + GL.vals[gside]));
+  make_depth_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), dcull, (uint32_t*)(gbin + GL.keys[gside]), (uint32_t*)(gbin + GL.vals[gside]),
+                                                      ranges, (int)(gx * gy));
   }
   LAUNCH_TRY("make_depth_keys_kernel");
   int rc = sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st);
@@ -270,8 +271,9 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   char* bin = align_ptr(bin_raw);
 
   uint2* ranges = (uint2*)(img + IL.ranges);
-  { PROF(K_MEMSET);
-  HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)gx * gy * sizeof(uint2), st));   // rasterizer_impl.cu:310
+  if (R == 0) {   // rasterizer_impl.cu:310; with instances run_binning zeroes the table itself
+    PROF(K_MEMSET);
+    HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)gx * gy * sizeof(uint2), st));
   }
   if (R > 0) {
     const uint32_t dmin = ~hdr[1], dspan = hdr[2] - dmin + 1u;   // +1: the key of culled Gaussians, one past the deepest visible
@@ -519,10 +521,7 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
   int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales, scale_modifier,
                           rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M, cam_pos, st);
   if (rc) return rc;
-  uint2* ranges = (uint2*)(img + IL.ranges);
-  { PROF(K_MEMSET);
-  HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)gx * gy * sizeof(uint2), st));
-  }
+  uint2* ranges = (uint2*)(img + IL.ranges);   // zeroed inside run_binning (make_depth_keys_kernel)
   // depth keys are sorted on all 32 bits (the exact range is only known on the device); positive finite floats stay below
   // the culled key 0xFFFFFFFF
   rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, 0u, 32, 0xFFFFFFFFu, gx, gy, status, st);

@@ -75,7 +75,7 @@ __global__ void unpack_geometry_kernel(int P, const float* __restrict__ rec, con
 __global__ void rebuild_keys_kernel(int R, const uint32_t* __restrict__ tile_keys, const uint32_t* __restrict__ vals,
                                     const BinInfo* __restrict__ bin, uint64_t* __restrict__ keys64);
 __global__ void make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, uint32_t dcull, uint32_t* __restrict__ keys,
-                                       uint32_t* __restrict__ vals);
+                                       uint32_t* __restrict__ vals, uint2* __restrict__ ranges, int num_tiles);
 __global__ void ordered_block_sums_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
                                           uint32_t* __restrict__ block_sums);
 __global__ void point_offsets_kernel(int P, const BinInfo* __restrict__ bin, uint32_t* __restrict__ offsets);
