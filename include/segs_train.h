@@ -31,6 +31,15 @@ int segs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                    const segs_adam_segment* segments, int nseg,
                    float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad, void* stream);
 
+/* Same, guarded on the device: if skip_flag is non-NULL and *skip_flag != 0 when the kernel runs, parameters and moments
+ * stay untouched and the gradient bucket is only cleared.  Pass the overflow word of the resident rasterizer
+ * (status + 3, segs_raster.h) so that an iteration whose instance count outgrew the scratch capacity is dropped without a
+ * host synchronisation; the host still counts it as a step (the caller may roll its counter back when it learns of it). */
+int segs_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                           const segs_adam_segment* segments, int nseg,
+                           float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad,
+                           const uint32_t* skip_flag, void* stream);
+
 /* Fused L1 + SSIM loss of the trainer/mapper step and its gradient w.r.t. the rendered image:
  *     loss = (1 - lambda) * mean|img1 - img2| + lambda * (1 - mean(SSIM(img1, img2)))
  * (src/gaussian_trainer.cpp:89-90, src/gaussian_mapper.cpp:924-928 with loss_utils::l1_loss / ssim,

@@ -70,6 +70,7 @@ SYMBOLS = {
     "segs_l1_ssim_temp_bytes": (_sz, [_i, _i]),
     "segs_l1_ssim_loss": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "segs_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, C.c_int64, _f, _i, _vp]),
+    "segs_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, C.c_int64, _f, _i, _vp, _vp]),
     "segs_profile_begin": (_i, [C.c_uint]),
     "segs_profile_end": (_i, []),
     "segs_profile_kernel_count": (_i, []),

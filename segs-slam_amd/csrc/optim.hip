@@ -32,8 +32,11 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
                                                    float* __restrict__ v, SegTable tab, float b1, float b2, float sqrt_bc2,
-                                                   float eps, float gscale, int zero_grad) {
+                                                   float eps, float gscale, int zero_grad, const uint32_t* __restrict__ skip_flag) {
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  // guarded step: the gradients of an iteration the resident rasterizer flagged as overflowed are discarded on the
+  // device (parameters and moments untouched, gradient bucket cleared) without the host having to look first
+  const bool skip = skip_flag != nullptr && *skip_flag != 0u;
   for (int s = 0; s < tab.nseg; s++) {
     const long long off = tab.offset[s], cnt = tab.count[s];
     const float ss = tab.step_size[s];
@@ -44,6 +47,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
     const long long gsz = (long long)gridDim.x * blockDim.x;
     for (long long i = gtid; i < nvec; i += gsz) {
       const long long e = off + head + 4 * i;
+      if (skip) { if (zero_grad) *reinterpret_cast<float4*>(grad + e) = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
       float4 p4 = *reinterpret_cast<float4*>(param + e), g4 = *reinterpret_cast<float4*>(grad + e);
       float4 m4 = *reinterpret_cast<float4*>(m + e), v4 = *reinterpret_cast<float4*>(v + e);
       adam_one(p4.x, g4.x, m4.x, v4.x, b1, b2, omb1, omb2, 0.f, sqrt_bc2, eps, ss, gscale);
@@ -58,6 +62,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
     const long long tail0 = head + 4 * nvec;
     for (long long i = gtid; i < head + (cnt - tail0); i += gsz) {
       const long long e = off + (i < head ? i : tail0 + (i - head));
+      if (skip) { if (zero_grad) grad[e] = 0.f; continue; }
       float p1 = param[e], g1 = grad[e], m1 = m[e], v1 = v[e];
       adam_one(p1, g1, m1, v1, b1, b2, omb1, omb2, 0.f, sqrt_bc2, eps, ss, gscale);
       param[e] = p1; m[e] = m1; v[e] = v1;
@@ -67,9 +72,9 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
 }
 }  // namespace
 
-extern "C" int segs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,
-                              int nseg, float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad,
-                              void* stream) {
+extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,
+                                      int nseg, float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad,
+                                      const uint32_t* skip_flag, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !segments || nseg <= 0 || nseg > MAX_SEG || step <= 0) return SEGS_ERR_INVALID_ARGUMENT;
   SegTable tab{};
   tab.nseg = nseg;
@@ -90,7 +95,14 @@ extern "C" int segs_adam_step(float* param, float* grad, float* exp_avg, float* 
   if (blocks > 256 * 8) blocks = 256 * 8;  // 8 workgroups per CU, grid-stride the rest
   if (blocks < 1) blocks = 1;
   adam_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, tab, beta1, beta2, sqrt_bc2, eps,
-                                                            grad_scale, zero_grad);
+                                                            grad_scale, zero_grad, skip_flag);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : (int)e;
+}
+
+extern "C" int segs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,
+                              int nseg, float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad,
+                              void* stream) {
+  return segs_adam_step_guarded(param, grad, exp_avg, exp_avg_sq, segments, nseg, beta1, beta2, eps, step, grad_scale, zero_grad,
+                                nullptr, stream);
 }

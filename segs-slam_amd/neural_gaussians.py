@@ -327,9 +327,14 @@ class ScaffoldTrainerStep:
         for i, (o, n, lr) in enumerate(groups):
             segs[i].offset, segs[i].count, segs[i].lr = o, n, float(lr)
         m = self.model
-        st = self._lib.segs_adam_step(_p(m.params), _p(m.grads), _p(m.exp_avg), _p(m.exp_avg_sq), segs, len(groups),
-                                      self.opt.beta1, self.opt.beta2, self.opt.eps, step, 1.0 / self.world, 1, self._stream())
-        _capi.check(st, "segs_adam_step")
+        # guarded by the rasterizer's overflow word: an iteration whose instance count outgrew the resident capacity is
+        # dropped on the device; the host learns of it at the next forward (RasterEngine.check) and re-sizes the scratch
+        status = getattr(self.engine, "_status", None)
+        guard = C.c_void_p(status.data_ptr() + 12) if (status is not None and self.world == 1) else None
+        st = self._lib.segs_adam_step_guarded(_p(m.params), _p(m.grads), _p(m.exp_avg), _p(m.exp_avg_sq), segs, len(groups),
+                                              self.opt.beta1, self.opt.beta2, self.opt.eps, step, 1.0 / self.world, 1, guard,
+                                              self._stream())
+        _capi.check(st, "segs_adam_step_guarded")
 
     def learning_rates(self, it: int) -> Dict[str, float]:
         """updateLearningRate (src/gaussian_model.cpp:874-915); anchor/offset scaled by spatial_lr_scale (:637,640)."""
@@ -385,9 +390,12 @@ class ScaffoldTrainerStep:
         lrs = self.learning_rates(self.iteration)
         k = self.keyframe_for(self.iteration - 1, len(keyframes))
         loss = self._forward_backward(keyframes[k], gt_images[k])
-        if not self.engine.check(raise_on_overflow=False):
-            self.model.grads.zero_()                   # the overflowed pass left partial gradients behind
-            loss = self._forward_backward(keyframes[k], gt_images[k])
+        if self.world > 1 or self.densifier is not None:
+            # ranks must agree on whether the step counts, and the densify statistics must not see an invalid pass:
+            # resolve the overflow word on the host (one synchronisation) and redo the pass through the re-sizing path
+            if not self.engine.check(raise_on_overflow=False):
+                self.model.grads.zero_()
+                loss = self._forward_backward(keyframes[k], gt_images[k])
         if self.world > 1:
             dist.all_reduce(self.model.grads, group=self.pg)
         adjusted = False

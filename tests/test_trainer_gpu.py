@@ -55,6 +55,35 @@ def test_fused_adam_bit_exact(sizes):
     assert float(tg.abs().max()) == 0.0  # zero_grad folded in
 
 
+def test_guarded_adam_skips_on_device_flag():
+    """segs_adam_step_guarded: a non-zero device word drops the step (parameters and moments untouched, gradients cleared);
+    a zero word gives exactly segs_adam_step."""
+    from segs_slam_amd import _capi
+    rng = np.random.default_rng(5)
+    n = 10007
+    arrs = [rng.standard_normal(n).astype(np.float32) for _ in range(3)] + [rng.random(n).astype(np.float32)]
+    segs = (_capi.AdamSegment * 1)()
+    segs[0].offset, segs[0].count, segs[0].lr = 0, n, 1e-3
+    ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    for flag in (None, 0, 1):
+        tp, tg, tm, tv = (torch.from_numpy(a.copy()).to(DEV) for a in arrs)
+        word = torch.tensor([flag or 0], dtype=torch.int32, device=DEV)
+        if flag is None:
+            st = _capi.lib().segs_adam_step(ptr(tp), ptr(tg), ptr(tm), ptr(tv), segs, 1, 0.9, 0.999, 1e-15, 3, 1.0, 1, stream)
+        else:
+            st = _capi.lib().segs_adam_step_guarded(ptr(tp), ptr(tg), ptr(tm), ptr(tv), segs, 1, 0.9, 0.999, 1e-15, 3, 1.0, 1,
+                                                    ptr(word), stream)
+        _capi.check(st, "segs_adam_step")
+        torch.cuda.synchronize()
+        out[flag] = [t.cpu().numpy() for t in (tp, tg, tm, tv)]
+    for a, b in zip(out[None], out[0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[1][0], arrs[0]) and np.array_equal(out[1][2], arrs[2]) and np.array_equal(out[1][3], arrs[3])
+    assert float(np.abs(out[1][1]).max()) == 0.0
+
+
 def test_fused_adam_matches_torch_optim():
     """Same step through torch.optim.Adam (different association of the moment update): agreement to 1e-6 rel."""
     from segs_slam_amd.gaussian_trainer import FusedAdam, OptimizationParams
