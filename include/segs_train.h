@@ -8,7 +8,9 @@
  * (the reference's pinned version, README.md:109):
  *     m = m*b1 + g*(1-b1);  v = v*b2 + g*g*(1-b2);
  *     denom = sqrt(v)/sqrt(1 - b2^t) + eps;  p = p - (lr/(1 - b1^t)) * (m/denom)
- * with g = grad * grad_scale (1/world_size for keyframe-parallel averaging).
+ * with g = grad * grad_scale (1/world_size for keyframe-parallel averaging).  Like LibTorch, the hyper-parameters are
+ * doubles: 1-b1, 1-b2, the bias corrections and lr/(1-b1^t) are formed in double and only then rounded to the tensor's
+ * float32 (so 1-b2 is float(0.001), not 1.0f - 0.999f); checked against LibTorch's own C++ Adam (tests/golden/adam_libtorch.npz).
  */
 #ifndef SEGS_TRAIN_H_
 #define SEGS_TRAIN_H_
@@ -21,7 +23,7 @@ extern "C" {
 typedef struct segs_adam_segment {
   int64_t offset;  /* first element of the segment inside the flat bucket */
   int64_t count;   /* number of elements */
-  float lr;        /* learning rate of this parameter group */
+  double lr;       /* learning rate of this parameter group (LibTorch keeps it in double) */
 } segs_adam_segment;
 
 /* One Adam step over `nseg` (<= 16) segments of the flat bucket; `segments` is a HOST array.
@@ -29,7 +31,7 @@ typedef struct segs_adam_segment {
  * gradient bucket is cleared in the same pass (zero_grad of src/gaussian_trainer.cpp:116 folded in). */
 int segs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                    const segs_adam_segment* segments, int nseg,
-                   float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad, void* stream);
+                   double beta1, double beta2, double eps, int64_t step, float grad_scale, int zero_grad, void* stream);
 
 /* Same, guarded on the device: if skip_flag is non-NULL and *skip_flag != 0 when the kernel runs, parameters and moments
  * stay untouched and the gradient bucket is only cleared.  Pass the overflow word of the resident rasterizer
@@ -37,7 +39,7 @@ int segs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
  * host synchronisation; the host still counts it as a step (the caller may roll its counter back when it learns of it). */
 int segs_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                            const segs_adam_segment* segments, int nseg,
-                           float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad,
+                           double beta1, double beta2, double eps, int64_t step, float grad_scale, int zero_grad,
                            const uint32_t* skip_flag, void* stream);
 
 /* Fused L1 + SSIM loss of the trainer/mapper step and its gradient w.r.t. the rendered image:

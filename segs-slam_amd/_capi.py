@@ -25,7 +25,7 @@ class NeuralDims(C.Structure):
 
 class AdamSegment(C.Structure):
     """segs_adam_segment (include/segs_train.h)."""
-    _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("lr", C.c_float)]
+    _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("lr", C.c_double)]
 
 # name -> (restype, argtypes); every symbol include/segs_raster.h declares
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -69,8 +69,8 @@ SYMBOLS = {
     "segs_search_neighborhood_depth": (_i, [_i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "segs_l1_ssim_temp_bytes": (_sz, [_i, _i]),
     "segs_l1_ssim_loss": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
-    "segs_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, C.c_int64, _f, _i, _vp]),
-    "segs_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, C.c_int64, _f, _i, _vp, _vp]),
+    "segs_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_int64, _f, _i, _vp]),
+    "segs_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_int64, _f, _i, _vp, _vp]),
     "segs_profile_begin": (_i, [C.c_uint]),
     "segs_profile_end": (_i, []),
     "segs_profile_kernel_count": (_i, []),

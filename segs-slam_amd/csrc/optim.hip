@@ -31,9 +31,9 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
-                                                   float* __restrict__ v, SegTable tab, float b1, float b2, float sqrt_bc2,
-                                                   float eps, float gscale, int zero_grad, const uint32_t* __restrict__ skip_flag) {
-  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+                                                   float* __restrict__ v, SegTable tab, float b1, float b2, float omb1, float omb2,
+                                                   float sqrt_bc2, float eps, float gscale, int zero_grad,
+                                                   const uint32_t* __restrict__ skip_flag) {
   // guarded step: the gradients of an iteration the resident rasterizer flagged as overflowed are discarded on the
   // device (parameters and moments untouched, gradient bucket cleared) without the host having to look first
   const bool skip = skip_flag != nullptr && *skip_flag != 0u;
@@ -73,20 +73,20 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
 }  // namespace
 
 extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,
-                                      int nseg, float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad,
+                                      int nseg, double beta1, double beta2, double eps, int64_t step, float grad_scale, int zero_grad,
                                       const uint32_t* skip_flag, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !segments || nseg <= 0 || nseg > MAX_SEG || step <= 0) return SEGS_ERR_INVALID_ARGUMENT;
   SegTable tab{};
   tab.nseg = nseg;
   long long total = 0;
   // bias corrections in double on the host, like LibTorch (1 - std::pow(beta, step))
-  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  const double bc1 = 1.0 - std::pow(beta1, (double)step);
+  const double bc2 = 1.0 - std::pow(beta2, (double)step);
   for (int i = 0; i < nseg; i++) {
     if (segments[i].offset < 0 || segments[i].count < 0) return SEGS_ERR_INVALID_ARGUMENT;
     tab.offset[i] = segments[i].offset;
     tab.count[i] = segments[i].count;
-    tab.step_size[i] = (float)((double)segments[i].lr / bc1);
+    tab.step_size[i] = (float)(segments[i].lr / bc1);
     total += segments[i].count;
   }
   if (total == 0) return SEGS_OK;
@@ -94,14 +94,16 @@ extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg,
   long long blocks = (total / 4 + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;  // 8 workgroups per CU, grid-stride the rest
   if (blocks < 1) blocks = 1;
-  adam_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, tab, beta1, beta2, sqrt_bc2, eps,
+  // Scalars cross into the float32 tensor arithmetic the way LibTorch's do: computed in double, rounded once
+  adam_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, tab, (float)beta1, (float)beta2,
+                                                            (float)(1.0 - beta1), (float)(1.0 - beta2), sqrt_bc2, (float)eps,
                                                             grad_scale, zero_grad, skip_flag);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : (int)e;
 }
 
 extern "C" int segs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,
-                              int nseg, float beta1, float beta2, float eps, int64_t step, float grad_scale, int zero_grad,
+                              int nseg, double beta1, double beta2, double eps, int64_t step, float grad_scale, int zero_grad,
                               void* stream) {
   return segs_adam_step_guarded(param, grad, exp_avg, exp_avg_sq, segments, nseg, beta1, beta2, eps, step, grad_scale, zero_grad,
                                 nullptr, stream);

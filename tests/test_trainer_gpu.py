@@ -10,15 +10,16 @@ DEV = "cuda:0"
 
 
 def adam_reference(p, g, m, v, lr, b1, b2, eps, step, gscale):
-    """float32 restatement of LibTorch 2.0.1's C++ Adam step, one rounding per operation."""
+    """float32 restatement of LibTorch's C++ Adam step, one rounding per operation; hyper-parameters
+    are doubles and every scalar is formed in double before it is rounded into the float32 tensor arithmetic."""
     f = np.float32
-    bc1 = 1.0 - float(f(b1)) ** step  # betas cross the C ABI as float32; corrections are formed in double
-    bc2 = 1.0 - float(f(b2)) ** step
-    step_size = f(float(f(lr)) / bc1)  # the C ABI takes lr as float32
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    step_size = f(lr / bc1)
     sqrt_bc2 = f(np.sqrt(bc2))
     gr = g * f(gscale)
-    m = m * f(b1) + gr * (f(1.0) - f(b1))
-    v = v * f(b2) + gr * gr * (f(1.0) - f(b2))
+    m = m * f(b1) + gr * f(1.0 - b1)
+    v = v * f(b2) + gr * gr * f(1.0 - b2)
     denom = np.sqrt(v) / sqrt_bc2 + f(eps)
     p = p - step_size * (m / denom)
     return p.astype(f), m.astype(f), v.astype(f)
@@ -55,6 +56,33 @@ def test_fused_adam_bit_exact(sizes):
     assert float(tg.abs().max()) == 0.0  # zero_grad folded in
 
 
+def test_fused_adam_matches_libtorch_cpp_adam_fixture():
+    """Five steps of the fused kernel against LibTorch's C++ torch::optim::Adam configured as src/gaussian_model.cpp:632-640
+    does (tests/golden/adam_libtorch.npz, made by tests/golden/make_adam_golden.py with LibTorch 2.10 CPU; the reference
+    pins 2.0.1).  LibTorch's CPU kernels may fuse multiply-adds, the HIP kernel is built without contraction: a few ulp."""
+    import os
+    from segs_slam_amd import _capi
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "adam_libtorch.npz"))
+    n = g["p0"].size
+    tp = torch.from_numpy(g["p0"].copy()).to(DEV)
+    tm, tv = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    segs = (_capi.AdamSegment * 1)()
+    segs[0].offset, segs[0].count, segs[0].lr = 0, n, float(g["lr"])
+    ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for s in range(g["grads"].shape[0]):
+        tg = torch.from_numpy(g["grads"][s].copy()).to(DEV)
+        st = _capi.lib().segs_adam_step(ptr(tp), ptr(tg), ptr(tm), ptr(tv), segs, 1, 0.9, 0.999, 1e-15, s + 1, 1.0, 1,
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _capi.check(st, "segs_adam_step")
+    torch.cuda.synchronize()
+    gmax = np.abs(g["grads"]).max(axis=0)          # exp_avg sums signed terms: rounding scales with the operands
+    assert np.all(np.abs(tm.cpu().numpy() - g["exp_avg"]) <= 2e-6 * np.abs(g["exp_avg"]) + 1e-7 * gmax)
+    np.testing.assert_allclose(tv.cpu().numpy(), g["exp_avg_sq"], rtol=2e-6, atol=1e-20)
+    np.testing.assert_allclose(tp.cpu().numpy(), g["p"], rtol=0, atol=2e-6 * float(g["lr"]) * 5 + 1e-7)
+    moved = np.abs(g["p"] - g["p0"]) > 0
+    assert moved.sum() > 0.9 * n * 16 / 17 and not moved[::17].any()
+
+
 def test_guarded_adam_skips_on_device_flag():
     """segs_adam_step_guarded: a non-zero device word drops the step (parameters and moments untouched, gradients cleared);
     a zero word gives exactly segs_adam_step."""
@@ -85,7 +113,8 @@ def test_guarded_adam_skips_on_device_flag():
 
 
 def test_fused_adam_matches_torch_optim():
-    """Same step through torch.optim.Adam (different association of the moment update): agreement to 1e-6 rel."""
+    """Same step through torch.optim.Adam (the Python front end updates exp_avg with lerp_, a different association):
+    agreement to a few ulp of the parameter (|p| ~ 1) -- 2e-6 relative + 5e-7 absolute."""
     from segs_slam_amd.gaussian_trainer import FusedAdam, OptimizationParams
     from segs_slam_amd.raster_engine import FIELDS, FLOATS_PER_GAUSSIAN
     P = 777
@@ -109,7 +138,7 @@ def test_fused_adam_matches_torch_optim():
         topt.step()
         adam.step(pg, g.to(DEV), lrs, P, 1.0)
     ref = torch.cat([q.detach() for q in ref_params])
-    assert torch.allclose(pg.cpu(), ref, rtol=2e-6, atol=1e-9)
+    assert torch.allclose(pg.cpu(), ref, rtol=2e-6, atol=5e-7)
 
 
 def test_trainer_step_reduces_loss():
