@@ -65,13 +65,18 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
  * dL_d{means3D,colors,opacity,scales,rotations}: candidate-domain gradients as produced by the rasterizer backward;
  * slots with neural opacity <= 0 are ignored (the reference's mask index passes no gradient to them).
  * Gradients are ACCUMULATED (+=) into dL_danchor (A,3), dL_doffset (A,n_offsets,3), dL_dfeat (A,32),
- * dL_dscaling_log (A,6) and dL_dmlp_params (flat block): the caller zeroes them (segs_adam_step's zero_grad does). */
+ * dL_dscaling_log (A,6) and dL_dmlp_params (flat block): the caller zeroes them (segs_adam_step's zero_grad does).
+ * scaling_reg_weight != 0 adds the mapper's scaling regulariser to the loss being differentiated,
+ *     scaling_reg_weight * mean over the kept Gaussians of prod(scaling)      (src/gaussian_mapper.cpp:926-928, weight 0.01),
+ * i.e. scaling_reg_weight / P * prod / scaling_c on top of dL_dscales; scaling_reg_out (1 device float or NULL) receives
+ * the value of that term. */
 int segs_neural_backward(const segs_neural_dims* dims, int A, const float* anchor, const float* offset,
                          const float* anchor_feat, const float* scaling_log, const float* mlp_params,
                          const float* camera_center, const float* pose7, const float* dL_dmeans3D,
                          const float* dL_dcolors, const float* dL_dopacity, const float* dL_dscales,
                          const float* dL_drotations, float* dL_danchor, float* dL_doffset, float* dL_dfeat,
-                         float* dL_dscaling_log, float* dL_dmlp_params, char* temp, void* stream);
+                         float* dL_dscaling_log, float* dL_dmlp_params, float scaling_reg_weight, float* scaling_reg_out,
+                         char* temp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ SYMBOLS = {
     "segs_neural_param_layout": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "segs_neural_temp_bytes": (_sz, [_vp, _i]),
     "segs_neural_forward": (_i, [_vp, _i] + [_vp] * 16),
-    "segs_neural_backward": (_i, [_vp, _i] + [_vp] * 19),
+    "segs_neural_backward": (_i, [_vp, _i] + [_vp] * 17 + [_f, _vp, _vp, _vp]),
     "segs_geometry_bytes": (_sz, [_i]),
     "segs_image_bytes": (_sz, [_i, _i]),
     "segs_binning_bytes": (_sz, [_i]),

@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
     const float* __restrict__ offset, const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
     const float* __restrict__ g_img, const Small* __restrict__ g_small, const float* __restrict__ campos,
     float* __restrict__ means3D, float* __restrict__ colors, float* __restrict__ opacity, float* __restrict__ scales,
-    float* __restrict__ rotations, float* __restrict__ neural_opacity) {
+    float* __restrict__ rotations, float* __restrict__ neural_opacity, uint32_t* __restrict__ n_kept) {
   extern __shared__ __align__(16) float lds_dyn[];
   float* img = lds_dyn;
   Small& S = *reinterpret_cast<Small*>(lds_dyn + N_IMG_FWD * 64);
@@ -401,6 +401,7 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
     anchor_lane(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
     const size_t c0 = (size_t)a * NO + 5 * h;     // first candidate of this lane half
     f32x16 hp;
+    uint32_t kept = 0;   // candidates of this lane with neural opacity > 0: P of the reference's compacted tensors
 #pragma unroll 1
     for (int tile = 0; tile < N_TILES; tile++) {
       if (tile <= 2) hp = layer1(img, S, tile_mlp(tile), lane, h, st.xo);
@@ -409,7 +410,7 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
       if (tile == 0) {
         float op[5];
 #pragma unroll
-        for (int r = 0; r < 5; r++) op[r] = fast_tanh(o[r]);
+        for (int r = 0; r < 5; r++) { op[r] = fast_tanh(o[r]); kept += op[r] > 0.f ? 1u : 0u; }
         stn<5>(neural_opacity + c0, op);
         stn<5>(opacity + c0, op);
       } else if (tile == 1) {
@@ -438,6 +439,10 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
         }
       }
     }
+    kept = valid ? kept : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += (uint32_t)__shfl_xor((int)kept, off, 64);
+    if (lane == 0 && kept) atomicAdd(n_kept, kept);
   }
 }
 
@@ -471,7 +476,8 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
     const float* __restrict__ g_img, const Small* __restrict__ g_small, const float* __restrict__ campos,
     const float* __restrict__ g_means, const float* __restrict__ g_colors, const float* __restrict__ g_opacity,
     const float* __restrict__ g_scales, const float* __restrict__ g_rot, float* __restrict__ d_anchor,
-    float* __restrict__ d_offset, float* __restrict__ d_feat, float* __restrict__ d_scaling_log, float* __restrict__ rows) {
+    float* __restrict__ d_offset, float* __restrict__ d_feat, float* __restrict__ d_scaling_log, float* __restrict__ rows,
+    float reg_weight, float* __restrict__ reg_sum) {
   extern __shared__ __align__(16) float lds_dyn[];
   float* img = lds_dyn;
   Small& S = *reinterpret_cast<Small*>(lds_dyn + N_IMG_BWD * 64);
@@ -494,6 +500,10 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
     for (int r = 0; r < 16; r++) dx[r] = 0.f;
     float dtail[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t keep = 0;   // bit r: candidate 5h + r has neural opacity > 0 (the reference's mask, :279)
+    // scaling regulariser of the mapper loss, reg_weight * mean_P(prod(scaling)) (src/gaussian_mapper.cpp:926-928):
+    // every kept candidate adds reg_weight / P * prod / s_c to dL/dscaling_c
+    const float reg_w = reg_weight != 0.f ? reg_weight / (float)max(count[1], 1u) : 0.f;
+    float reg_acc = 0.f;
     float dgs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, danc[3] = {0.f, 0.f, 0.f};
     f32x16 hp, dh;
 #pragma unroll 1
@@ -542,6 +552,12 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
             ldn<3>(g_scales + (c0 + cc) * 3, gsc);
             ldn<3>(g_means + (c0 + cc) * 3, gm);
             ldn<3>(offset + (c0 + cc) * 3, off);
+            if (reg_w != 0.f) {
+              const float s0 = st.gs[3] * sigmoidf(o[7 * cl]), s1 = st.gs[4] * sigmoidf(o[7 * cl + 1]),
+                          s2 = st.gs[5] * sigmoidf(o[7 * cl + 2]);
+              gsc[0] += reg_w * (s1 * s2); gsc[1] += reg_w * (s0 * s2); gsc[2] += reg_w * (s0 * s1);
+              reg_acc += s0 * s1 * s2;
+            }
 #pragma unroll
             for (int c = 0; c < 3; c++) {
               const float sg = sigmoidf(o[7 * cl + c]);
@@ -585,6 +601,12 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
         for (int s = 0; s < 16; s++) dh = __builtin_amdgcn_mfma_f32_32x32x2f32(im[s * 64], o[s], dh, 0, 0, 0);
       }
       if (tile != 2 && tile != 3) finish_mlp(img, S, m, lane, h, hp, dh, dx, dtail, row, valid);
+    }
+    if (reg_sum != nullptr && reg_w != 0.f) {   // sum of prod(scaling) over the kept candidates, for the loss value
+      reg_acc = valid ? reg_acc : 0.f;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) reg_acc += __shfl_xor(reg_acc, off, 64);
+      if (lane == 0 && reg_acc != 0.f) atomicAdd(reg_sum, reg_acc);
     }
     // ---- combine the lane halves
 #pragma unroll
@@ -822,6 +844,10 @@ __global__ void __launch_bounds__(64) appearance_finish_kernel(Layout L, const f
   }
 }
 
+__global__ void reg_finish_kernel(const uint32_t* count, const float* reg_sum, float w, float* out) {
+  *out = w * (*reg_sum) / (float)max(count[1], 1u);   // reg_weight * mean(prod(scaling))
+}
+
 WJobs make_jobs(const Layout& L) {
   WJobs J;
   const int nstored[3] = {16, 72, 32};          // opacity, cov, colour: stored (padded) output columns
@@ -868,14 +894,14 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
     return SEGS_ERR_INVALID_ARGUMENT;
   Temp T;
   temp_carve(A, L.total, temp, &T);
-  hipError_t e = hipMemsetAsync(T.count, 0, sizeof(uint32_t), st);
+  hipError_t e = hipMemsetAsync(T.count, 0, 2 * sizeof(uint32_t), st);   // [0] visible anchors, [1] kept candidates
   if (e != hipSuccess) return (int)e;
   const int nb = (A + 255) / 256;
   compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity);
   static_assert(N_IMG_BWD == 262 && sizeof(Small) <= 8192, "temp_carve sizes");
   pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small);
   neural_fwd_kernel<<<NEURAL_GRID, 256, N_IMG_FWD * 64 * sizeof(float) + sizeof(Small), st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
-                                        camera_center, means3D, colors, opacity, scales, rotations, neural_opacity);
+                                        camera_center, means3D, colors, opacity, scales, rotations, neural_opacity, T.count + 1);
   e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : (int)e;
 }
@@ -884,7 +910,8 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
                          const float* scaling_log, const float* mlp_params, const float* camera_center, const float* pose7,
                          const float* dL_dmeans3D, const float* dL_dcolors, const float* dL_dopacity, const float* dL_dscales,
                          const float* dL_drotations, float* dL_danchor, float* dL_doffset, float* dL_dfeat,
-                         float* dL_dscaling_log, float* dL_dmlp_params, char* temp, void* stream) {
+                         float* dL_dscaling_log, float* dL_dmlp_params, float scaling_reg_weight, float* scaling_reg_out, char* temp,
+                         void* stream) {
   hipStream_t st = (hipStream_t)stream;
   Layout L;
   int rc = make_layout(dims, &L, nullptr, nullptr, nullptr);
@@ -901,9 +928,14 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
   if (attr_rc != hipSuccess) return (int)attr_rc;
+  {
+    const hipError_t me = hipMemsetAsync(T.gsum + L.total + 8, 0, sizeof(float), st);
+    if (me != hipSuccess) return (int)me;
+  }
   neural_bwd_kernel<<<NEURAL_GRID, 256, bwd_lds, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
                                         camera_center, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor,
-                                        dL_doffset, dL_dfeat, dL_dscaling_log, T.rows);
+                                        dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, scaling_reg_weight, T.gsum + L.total + 8);
+  if (scaling_reg_out) reg_finish_kernel<<<1, 1, 0, st>>>(T.count, T.gsum + L.total + 8, scaling_reg_weight, scaling_reg_out);
   const WJobs J = make_jobs(L);
   wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), 64, 0, st>>>(J, T.count, T.rows, T.partial);
   wgrad_reduce_kernel<<<dim3((37 * 72 + 63) / 64, WG_JOBS), 256, 0, st>>>(J, T.partial, T.gsum, dL_dmlp_params);

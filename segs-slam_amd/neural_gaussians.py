@@ -261,15 +261,19 @@ class NeuralGaussians:
         """The reference's `mask` (neural_opacity > 0, src/gaussian_renderer.cpp:279) in the candidate domain."""
         return self.neural_opacity.view(-1)[:self.P] > 0
 
-    def backward(self, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations):
-        """Accumulates into model.grads."""
+    def backward(self, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, scaling_reg_weight: float = 0.0):
+        """Accumulates into model.grads.  scaling_reg_weight adds the mapper's 0.01 * mean(prod(scaling)) term
+        (src/gaussian_mapper.cpp:926-928); its value lands in self.scaling_reg."""
+        if not hasattr(self, "scaling_reg"):
+            self.scaling_reg = torch.zeros(1, dtype=torch.float32, device=self.model.device)
         m = self.model
         camera_center, pose7 = self._last
         st = self._lib.segs_neural_backward(
             C.byref(m._cdims), m.A, _p(m.param("anchor")), _p(m.param("offset")), _p(m.param("anchor_feat")),
             _p(m.param("scaling")), _p(m.mlp_params), _p(camera_center), _p(pose7), _p(dL_dmeans3D), _p(dL_dcolors),
             _p(dL_dopacity), _p(dL_dscales), _p(dL_drotations), _p(m.grad("anchor")), _p(m.grad("offset")),
-            _p(m.grad("anchor_feat")), _p(m.grad("scaling")), _p(m.mlp_grads), _p(self.temp), self._stream())
+            _p(m.grad("anchor_feat")), _p(m.grad("scaling")), _p(m.mlp_grads), float(scaling_reg_weight),
+            _p(self.scaling_reg) if scaling_reg_weight else None, _p(self.temp), self._stream())
         _capi.check(st, "segs_neural_backward")
 
 
@@ -289,7 +293,10 @@ class ScaffoldTrainerStep:
     all on the device without a host synchronisation in steady state."""
 
     def __init__(self, model: ScaffoldModel, width: int, height: int, opt: Optional[ScaffoldOptimizationParams] = None,
-                 spatial_lr_scale: float = 1.0, process_group=None):
+                 spatial_lr_scale: float = 1.0, process_group=None, scaling_reg_weight: float = 0.0):
+        # scaling_reg_weight = 0.01 gives the mapper's loss (src/gaussian_mapper.cpp:926-928), 0 the trainer's (:89-90 of
+        # src/gaussian_trainer.cpp); the mapper's FFT regularisers (:930-945) are not built
+        self.scaling_reg_weight = float(scaling_reg_weight)
         self.model, self.opt = model, opt or ScaffoldOptimizationParams()
         self.W, self.H = int(width), int(height)
         dev = model.device
@@ -379,7 +386,7 @@ class ScaffoldTrainerStep:
         image = self.render(kf)
         loss, dL = self.loss_fn(image, gt)
         g = self.engine.backward(dL)
-        self.neural.backward(g["means3D"], g["colors"], g["opacity"], g["scales"], g["rotations"])
+        self.neural.backward(g["means3D"], g["colors"], g["opacity"], g["scales"], g["rotations"], self.scaling_reg_weight)
         return loss
 
     def keyframe_for(self, step: int, n_keyframes: int) -> int:

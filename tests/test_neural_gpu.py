@@ -77,12 +77,16 @@ def test_forward_and_backward_match_restatement(case, A):
     # ---- backward: random candidate-domain gradients; the reference sees them through its compaction
     P = A * 10
     gm, gc, go, gs, gr = (torch.randn(P, n, generator=g) for n in (3, 3, 1, 3, 4))
+    reg_w = 0.01 if case % 2 == 0 else 0.0       # the mapper's scaling regulariser (src/gaussian_mapper.cpp:926-928)
+    reg = reg_w * scaling.prod(1).mean()
     loss = ((xyz * gm[dmask].double()).sum() + (color * gc[dmask].double()).sum() + (opacity * go[dmask].double()).sum()
-            + (scaling * gs[dmask].double()).sum() + (rot * gr[dmask].double()).sum())
+            + (scaling * gs[dmask].double()).sum() + (rot * gr[dmask].double()).sum()) + 1e4 * reg
     loss.backward()
     model.grads.zero_()
-    gen.backward(gm.to(dev), gc.to(dev), go.to(dev), gs.to(dev), gr.to(dev))
+    gen.backward(gm.to(dev), gc.to(dev), go.to(dev), gs.to(dev), gr.to(dev), scaling_reg_weight=1e4 * reg_w)
     torch.cuda.synchronize()
+    if reg_w:
+        assert abs(gen.scaling_reg.item() - 1e4 * reg.item()) <= 1e-5 * 1e4 * reg.item()
 
     def close(name, ours, ref):
         ref = ref if ref is not None else torch.zeros_like(ours, dtype=torch.float64)
@@ -98,7 +102,7 @@ def test_forward_and_backward_match_restatement(case, A):
         close(n, model.grad(n), r_mlp[n].grad)
 
     # gradients accumulate: a second backward doubles them
-    gen.backward(gm.to(dev), gc.to(dev), go.to(dev), gs.to(dev), gr.to(dev))
+    gen.backward(gm.to(dev), gc.to(dev), go.to(dev), gs.to(dev), gr.to(dev), scaling_reg_weight=1e4 * reg_w)
     torch.cuda.synchronize()
     close("anchor_feat x2", model.grad("anchor_feat"), 2 * r_feat.grad)
     close("mlp_cov.2.weight x2", model.grad("mlp_cov.2.weight"), 2 * r_mlp["mlp_cov.2.weight"].grad)
