@@ -56,6 +56,10 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the resident fwd+bwd from a captured hipGraph (N=1 only); the "
                     "dominant kernel's live HIP-event timing is then taken from the eager warm-up pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank path)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="all ranks use cuda:0 (with --backend gloo): exercises the N > 1 code path on a one-GPU box; not a measurement")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     args = ap.parse_args()
 
@@ -73,11 +77,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP extension has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # ---- workload: same Gaussians on every rank, one keyframe (camera pose) per rank
     sc = scenes.make_config_scene(args.workload, keyframe=rank)
@@ -90,7 +99,7 @@ def main():
 
     if args.mode == "scaffold":
         from segs_slam_amd import neural_gaussians as ng
-        model = ng.synthetic_model(args.anchors, ng.ModelDims(), cam, dev, seed=rank)
+        model = ng.synthetic_model(args.anchors, ng.ModelDims(), cam, dev, seed=0)   # replicas must be identical; the keyframe differs per rank
         tstep = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
         eng = tstep.engine
         kfs = [ng.Keyframe(view, proj, campos, torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)]
