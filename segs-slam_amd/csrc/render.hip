@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(
   bool alive = true;  // wave-uniform: some pixel of this 8x8 block still accumulates
   for (uint32_t base = range.x; base < range.y && alive; base += 64) {
     // stage chunk c's records for broadcast reads
-    const int n = cc.n;
+    const int n = __builtin_amdgcn_readfirstlane(cc.n);
     if (lane < n) {
       s_rec[wv][lane][0] = r0;
       s_rec[wv][lane][1] = r1;
@@ -170,19 +170,17 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(
       float w = ae * T;
       float test_T = T - w;
       const bool stop = test_T < thr;  // forward.cu:420-425; never true for dead pixels (thr = -1)
-      bool upd = ok;
       if (__ballot(stop) != 0ull) {    // rare: some pixel saturates at this Gaussian
         Tfin = stop ? T : Tfin;
-        lastfin = stop ? last : lastfin;
-        thr = stop ? -1.f : thr;
+        lastfin = stop ? last : lastfin;   // `last` before this Gaussian: a dead pixel reports lastfin, so the
+        thr = stop ? -1.f : thr;           // unconditional update of `last` below is harmless for it
         w = stop ? 0.f : w;
         test_T = stop ? 0.f : test_T;
-        upd = ok && !stop;
         alive = __ballot(thr > 0.f) != 0ull;
       }
       T = test_T;
       C0 += q1.z * w; C1 += q1.w * w; C2 += q2.x * w;
-      last = upd ? __float_as_uint(q2.y) : last;
+      last = ok ? __float_as_uint(q2.y) : last;
       if (!alive) break;
     }
   }
@@ -229,14 +227,18 @@ __device__ __forceinline__ float fold_rows4(float a, float b, float c, float d) 
 //      float-atomic wave instruction per 4 Gaussians (36 contiguous bytes per Gaussian).
 // The accumulated row holds raw moments (Mx, My, Mxx, Mxy, Myy, S0, Sr, Sg, Sb); preprocess_bwd_kernel turns
 // them into the reference's dL/dmean2D, dL/dconic, dL/dopacity (backward.cu:541-554) with the per-Gaussian conic.
+// acc += a * (value of `v` in lane I of this lane's 16-lane row): the DPP row broadcast rides on the FMA itself, so the
+// Gaussian role gets dL/dpixel of pixel 16*part + I straight from the pixel lanes' registers -- no LDS read.
+template <int I>
+__device__ __forceinline__ void fmac_row_bcast(float& acc, float v, float a) {
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(v), "v"(a), "n"(I));
+}
 constexpr int BW_SLOTS = 16;
 constexpr int BW_STRIDE = 65;  // padded row of the transposed tiles: conflict-free in both roles
-struct BwdLds {                  // 10176 B per wave -> 4 workgroups (16 waves) per CU
+struct BwdLds {                  // 9088 B per wave -> 4 workgroups (16 waves) per CU
   float4 rec[BW_SLOTS][3];      // staged records of the current batch: [0] x y a2 b2  [1] c2 o r g  [2] b pos id -
   float wt[BW_SLOTS][BW_STRIDE];
   float at[BW_SLOTS][BW_STRIDE];  // its first 16x12 floats are reused as the moment exchange area `mom`
-  float4 dp[64 + 4];            // dL/dpixel (r,g,b) of pixel p at [p + (p >> 4)]: the four 16-pixel parts read by the
-                                // Gaussian role in one instruction land in different banks (a 64-dword part stride was 2-way)
 };
 
 
@@ -303,7 +305,6 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
   wave_last = __builtin_amdgcn_readfirstlane(wave_last);
   if (wave_last == 0u) return;
 
-  L.dp[lane + (lane >> 4)] = make_float4(dp0, dp1, dp2, 0.f);
   float T = T_final, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;  // acc = colour accumulated BEHIND the current Gaussian
 
   // Gaussian-role constants
@@ -368,14 +369,17 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
       float S0, S1x, S1y, Sxx, Sxy, Syy, Sr = 0.f, Sg = 0.f, Sb = 0.f;
       {
         float R0[2] = {0.f, 0.f}, R1[2] = {0.f, 0.f}, R2[2] = {0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const int p = part * 16 + i;
-          const float w = L.wt[gs][p], a = L.at[gs][p];
-          const float4 d = L.dp[p + part];   // p >> 4 == part
-          R0[i >> 3] += w; R1[i >> 3] += w * px8[i & 7]; R2[i >> 3] += w * px8q[i & 7];
-          Sr += a * d.x; Sg += a * d.y; Sb += a * d.z;
+        const float* wrow = &L.wt[gs][part * 16];
+        const float* arow = &L.at[gs][part * 16];
+#define GAUSS_STEP(i)                                                                         \
+        {                                                                                     \
+          const float w = wrow[i], a = arow[i];                                               \
+          R0[(i) >> 3] += w; R1[(i) >> 3] += w * px8[(i) & 7]; R2[(i) >> 3] += w * px8q[(i) & 7]; \
+          fmac_row_bcast<(i)>(Sr, dp0, a); fmac_row_bcast<(i)>(Sg, dp1, a); fmac_row_bcast<(i)>(Sb, dp2, a); \
         }
+        GAUSS_STEP(0) GAUSS_STEP(1) GAUSS_STEP(2) GAUSS_STEP(3) GAUSS_STEP(4) GAUSS_STEP(5) GAUSS_STEP(6) GAUSS_STEP(7)
+        GAUSS_STEP(8) GAUSS_STEP(9) GAUSS_STEP(10) GAUSS_STEP(11) GAUSS_STEP(12) GAUSS_STEP(13) GAUSS_STEP(14) GAUSS_STEP(15)
+#undef GAUSS_STEP
         S0 = R0[0] + R0[1]; S1x = R1[0] + R1[1]; Sxx = R2[0] + R2[1];
         S1y = pyc0 * R0[0] + pyc1 * R0[1];
         Sxy = pyc0 * R1[0] + pyc1 * R1[1];
