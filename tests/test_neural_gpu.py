@@ -176,3 +176,29 @@ def test_scaffold_trainer_reduces_loss():
     losses = [float(step.training_once([kf], [gt])) for _ in range(40)]
     assert np.isfinite(losses).all()
     assert losses[-1] < 0.8 * losses[0], losses[::8]
+
+
+def test_model_io_round_trip(tmp_path):
+    """save_ply writes the reference's property list (src/gaussian_model.cpp:1179-1261) and reads back bit-exactly;
+    the MLP text files have the reference's names and `%.5f` rows."""
+    from segs_slam_amd import model_io
+    dev = torch.device("cuda:0")
+    _, model, (anchor, offset, feat, scaling_log, mlp) = _setup(CASES[0], 37, 9, dev)
+    p = str(tmp_path / "point_cloud.ply")
+    model_io.save_ply(model, p)
+    head = open(p, "rb").read(4096).split(b"end_header\n")[0].decode()
+    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex 37\nproperty float x\n")
+    back = model_io.load_ply(p)
+    assert back["names"] == model_io.ply_property_names(32, 10)
+    assert back["names"][6] == "anchor_feat_0" and back["names"][38] == "offset_0" and back["names"][68] == "opacity"
+    np.testing.assert_array_equal(back["anchor"], anchor.numpy())
+    np.testing.assert_array_equal(back["offset"], offset.numpy())
+    np.testing.assert_array_equal(back["anchor_feat"], feat.numpy())
+    np.testing.assert_array_equal(back["scaling"], scaling_log.numpy())
+    np.testing.assert_array_equal(back["rotation"][:, 0], np.ones(37, np.float32))
+    model_io.save_mlp_checkpoints(model, str(tmp_path / "mlp"))
+    rows = open(tmp_path / "mlp" / "cov_weight2.txt").read().strip().split("\n")
+    assert len(rows) == 70 and len(rows[0].split(" ")) == 32
+    assert rows[3].split(" ")[5] == f"{float(mlp['mlp_cov.2.weight'][3, 5]):.5f}"
+    for fn in ("opacity_weight1.txt", "opacity_bias2.txt", "color_bias1.txt", "feat_weight2.txt"):
+        assert (tmp_path / "mlp" / fn).exists()
