@@ -119,6 +119,28 @@ __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const BinIn
 // A Gaussian covering thousands of tiles is thereby spread over many workgroups instead of serialising one wave,
 // and all 12-byte pairs leave as coalesced stores.
 constexpr int EMIT_SLOTS = 1024;
+// First index g in [0, n) with a[g] > key (STRICT) or a[g] >= key, n if none; `a` ascending.  64-ary search by one wave:
+// every round the 64 lanes probe 64 evenly spaced elements at once and a ballot picks the segment (4 rounds of one
+// parallel load for n = 500 k instead of 19 dependent loads: the emitter workgroups were latency-bound on this search).
+template <bool STRICT>
+__device__ __forceinline__ int wave_lower_bound(const uint32_t* __restrict__ a, int n, uint32_t key) {
+  const int lane = threadIdx.x & 63;
+  int lo = 0, hi = n;                      // answer in [lo, hi]
+  while (hi - lo > 64) {
+    const int step = (hi - lo + 63) / 64;
+    const int p = min(lo + (lane + 1) * step - 1, hi - 1);
+    const uint32_t v = a[p];
+    const uint64_t m = __ballot(STRICT ? v > key : v >= key);
+    if (m == 0ull) return hi;              // even the last element fails
+    const int f = __ffsll((long long)m) - 1;
+    hi = min(hi, lo + (f + 1) * step - 1); // probe f satisfies the predicate: the answer is at most its index
+    lo = lo + f * step;                    // probe f-1 (index lo + f*step - 1) does not
+  }
+  const int p = lo + lane;
+  const bool ok = p < hi && (STRICT ? a[p] > key : a[p] >= key);
+  const uint64_t m = __ballot(ok);
+  return m ? lo + __ffsll((long long)m) - 1 : hi;
+}
 __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ incl, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
@@ -132,11 +154,8 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
   const uint32_t s0 = blockIdx.x * EMIT_SLOTS, s1 = min((uint32_t)R, s0 + EMIT_SLOTS);
   if (s0 >= (uint32_t)R) return;
   // first owner: first g with incl[g] > s0; last owner: first g with incl[g] >= s1   (wave-uniform searches)
-  int lo = 0, hi = P;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (incl[mid] > s0) hi = mid; else lo = mid + 1; }
-  const int g_lo = lo;
-  lo = g_lo; hi = P;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (incl[mid] >= s1) hi = mid; else lo = mid + 1; }
+  const int g_lo = wave_lower_bound<true>(incl, P, s0);
+  const int lo = wave_lower_bound<false>(incl, P, s1);
   const int n_own = min(lo, P - 1) - g_lo + 1;  // <= EMIT_SLOTS: every owner has at least one instance in range
   const uint32_t excl0 = g_lo == 0 ? 0u : incl[g_lo - 1];
   for (int k = tid; k < n_own; k += 256) {
