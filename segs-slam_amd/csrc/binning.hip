@@ -267,34 +267,38 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
 }
 
 // Row d of the count matrix -> exclusive scan in place; row total -> digit_totals[d].  Grid = 256 workgroups.
+// Eight consecutive entries per thread and round (2048 per round: one round up to R = 4 M instances), one barrier pair
+// per round -- the previous one-entry-per-thread loop spent 6 us per launch on barriers.
 __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks,
                                                          uint32_t* __restrict__ digit_totals) {
+  constexpr int ITEMS = 8;
   __shared__ uint32_t wave_tot[4];
-  __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   uint32_t* row = block_hist + (size_t)blockIdx.x * nblocks;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < nblocks; base += 256) {
-    const int i = base + tid;
-    const uint32_t v = i < nblocks ? row[i] : 0u;
-    uint32_t x = v;
+  uint32_t carry = 0;
+  for (int base = 0; base < nblocks; base += 256 * ITEMS) {
+    const int i0 = base + tid * ITEMS;
+    uint32_t v[ITEMS], sum = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) { v[q] = (i0 + q < nblocks) ? row[i0 + q] : 0u; sum += v[q]; }
+    uint32_t x = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      uint32_t y = __shfl_up(x, off, 64);
+      const uint32_t y = __shfl_up(x, off, 64);
       if (lane >= off) x += y;
     }
     if (lane == 63) wave_tot[wv] = x;
     __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wv; w++) wbase += wave_tot[w];
-    const uint32_t carry = carry_s;
-    if (i < nblocks) row[i] = carry + wbase + x - v;
-    __syncthreads();
-    if (tid == 255) carry_s = carry + wbase + x;
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint32_t t = wave_tot[w]; if (w < wv) wbase += t; total += t; }
+    uint32_t run = carry + wbase + x - sum;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) { if (i0 + q < nblocks) row[i0 + q] = run; run += v[q]; }
+    carry += total;
     __syncthreads();
   }
-  if (tid == 0) digit_totals[blockIdx.x] = carry_s;
+  if (tid == 0) digit_totals[blockIdx.x] = carry;
 }
 
 // Stable scatter of one 2048-key tile (SORT_TILE).
