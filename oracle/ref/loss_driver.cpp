@@ -29,3 +29,31 @@ extern "C" int ref_l1_ssim(const float* img1, const float* img2, int H, int W, f
     return 1;
   }
 }
+
+// The reference's frequency-domain losses (include/loss_utils.h:126-213) and their autograd gradients on the CPU.
+// multi_scale_loss (:216-237) cannot be driven here: it calls high_frequency_loss with its default device (kCUDA).
+extern "C" int ref_freq_losses(const float* img1, const float* img2, int H, int W, float* out2 /*high, low*/, float* dL_high,
+                               float* dL_low) {
+  try {
+    auto opts = torch::TensorOptions().dtype(torch::kFloat32);
+    torch::Tensor b = torch::from_blob(const_cast<float*>(img2), {3, H, W}, opts).clone();
+    {
+      torch::Tensor a = torch::from_blob(const_cast<float*>(img1), {3, H, W}, opts).clone().requires_grad_(true);
+      auto l = loss_utils::high_frequency_loss(a, b, 0.4, torch::kCPU);
+      l.backward();
+      out2[0] = l.item<float>();
+      std::memcpy(dL_high, a.grad().contiguous().data_ptr<float>(), sizeof(float) * 3 * (size_t)H * W);
+    }
+    {
+      torch::Tensor a = torch::from_blob(const_cast<float*>(img1), {3, H, W}, opts).clone().requires_grad_(true);
+      auto l = loss_utils::low_freq_loss(a, b, 0.2, torch::kCPU);
+      l.backward();
+      out2[1] = l.item<float>();
+      std::memcpy(dL_low, a.grad().contiguous().data_ptr<float>(), sizeof(float) * 3 * (size_t)H * W);
+    }
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "ref_freq_losses: %s\n", e.what());
+    return 1;
+  }
+}

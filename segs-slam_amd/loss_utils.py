@@ -56,3 +56,56 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
     if key not in _window_cache:
         _window_cache[key] = create_window(window_size, channel, img1.device).to(img1.dtype)
     return _ssim(img1, img2, _window_cache[key], window_size, channel, size_average)
+
+
+# ---- frequency-domain regularisers of the mapper loss (src/gaussian_mapper.cpp:930-948) -------------------------------
+# Tensor-op mirrors of include/loss_utils.h:126-237 (torch.fft runs on the device through hipFFT; autograd gives
+# dL/dimage).  Not fused HIP kernels: the FFTs are library calls in the reference too.  Pinned by the reference's own
+# functions through tests/golden/loss_reference.npz (high_frequency_loss, low_freq_loss).
+def _centre_box(H: int, W: int, cutoff_ratio: float):
+    """The two slices of loss_utils.h:139-140 / :180-181.  NB the reference applies them with
+    `mask.index_put_({Slice(crow-r, crow+r), Slice(ccol-r, ccol+r)}, v)` to the (3, H, W) spectrum, i.e. to dimensions 0
+    (channel) and 1 (rows), not to rows and columns: for any real image size the channel slice is empty, so the
+    "high-pass" mask stays all ones and the "low-pass" mask all zeros.  Mirrored as is (checked against the reference's
+    compiled code, tests/golden/loss_reference.npz): the drop-in must give the reference's numbers, not the intended ones."""
+    crow, ccol = H // 2, W // 2
+    r = int(cutoff_ratio * min(H, W) / 2)
+    return slice(crow - r, crow + r), slice(ccol - r, ccol + r)
+
+
+def high_pass_filter(img: torch.Tensor, cutoff_ratio: float) -> torch.Tensor:  # loss_utils.h:126-145
+    f = torch.fft.fftshift(torch.fft.fft2(img))          # fftshift over ALL dims, channel included, as the reference does
+    mask = torch.ones_like(f)
+    rs, cs = _centre_box(img.shape[1], img.shape[2], cutoff_ratio)
+    mask[rs, cs] = 0          # dimensions (0, 1), see _centre_box
+    return f * mask
+
+
+def high_frequency_loss(img1: torch.Tensor, img2: torch.Tensor, cutoff_ratio: float = 0.4) -> torch.Tensor:  # :147-165
+    return torch.mean(torch.abs(torch.abs(high_pass_filter(img1, cutoff_ratio)) - torch.abs(high_pass_filter(img2, cutoff_ratio))))
+
+
+def low_pass_filter(img: torch.Tensor, cutoff_ratio: float) -> torch.Tensor:  # :167-186
+    f = torch.fft.fftshift(torch.fft.fft2(img))
+    mask = torch.zeros_like(f)
+    rs, cs = _centre_box(img.shape[1], img.shape[2], cutoff_ratio)
+    mask[rs, cs] = 1          # dimensions (0, 1), see _centre_box
+    return f * mask
+
+
+def low_freq_loss(img1: torch.Tensor, img2: torch.Tensor, cutoff_ratio: float = 0.2) -> torch.Tensor:  # :188-213
+    norm = float(img1.shape[0] * img1.shape[1] * img1.shape[2])
+    a, b = low_pass_filter(img1, cutoff_ratio), low_pass_filter(img2, cutoff_ratio)
+    loss_la = torch.sum(torch.abs(torch.abs(a) - torch.abs(b))) / norm
+    loss_lp = torch.sum(torch.abs(torch.angle(a) - torch.angle(b))) / norm
+    return loss_la + loss_lp
+
+
+def multi_scale_loss(gen_img: torch.Tensor, target_img: torch.Tensor, scales) -> torch.Tensor:  # :216-237
+    loss = torch.zeros((), device=gen_img.device)
+    for scale in scales:
+        kw = dict(scale_factor=(float(scale), float(scale)), mode="bilinear", align_corners=False, recompute_scale_factor=True)
+        g = F.interpolate(gen_img.unsqueeze(0), **kw).squeeze(0)
+        t = F.interpolate(target_img.unsqueeze(0), **kw).squeeze(0)
+        loss = loss + scale * high_frequency_loss(g, t)
+    return loss

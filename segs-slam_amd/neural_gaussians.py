@@ -297,6 +297,7 @@ class ScaffoldTrainerStep:
         # scaling_reg_weight = 0.01 gives the mapper's loss (src/gaussian_mapper.cpp:926-928), 0 the trainer's (:89-90 of
         # src/gaussian_trainer.cpp); the mapper's FFT regularisers (:930-945) are not built
         self.scaling_reg_weight = float(scaling_reg_weight)
+        self.freq_reg = None             # see enable_frequency_regularization()
         self.model, self.opt = model, opt or ScaffoldOptimizationParams()
         self.W, self.H = int(width), int(height)
         dev = model.device
@@ -317,6 +318,29 @@ class ScaffoldTrainerStep:
         self.mlp_steps = 0
         self.densifier = None            # densify.AnchorDensifier, see enable_densification()
         self.densify_generator = None
+
+    def enable_frequency_regularization(self, lambda_high: float = 0.01, lambda_low: float = 0.0, scales=(1.0, 0.5, 0.25),
+                                        start: int = 5000, until: int = 25500, multi_resolution: bool = True):
+        """The mapper's FFT regularisers (src/gaussian_mapper.cpp:930-945, Mapper.* keys of the Replica cfg :140-146).  Their
+        gradient is taken with torch.fft + autograd (hipFFT library calls, as in the reference) and added to dL/dimage."""
+        self.freq_reg = dict(lambda_high=lambda_high, lambda_low=lambda_low, scales=tuple(scales), start=start, until=until,
+                             multi=multi_resolution)
+
+    def _freq_grad(self, image: torch.Tensor, gt: torch.Tensor):
+        from . import loss_utils
+        fr, it = self.freq_reg, self.iteration
+        terms = []
+        img = image.detach().requires_grad_(True)
+        if it < fr["until"] and fr["lambda_low"] != 0.0:
+            terms.append(fr["lambda_low"] * loss_utils.low_freq_loss(img, gt))
+        if fr["start"] < it < fr["until"] and fr["lambda_high"] != 0.0:
+            hf = loss_utils.multi_scale_loss(img, gt, fr["scales"]) if fr["multi"] else loss_utils.high_frequency_loss(img, gt)
+            terms.append(fr["lambda_high"] * hf)
+        if not terms:
+            return None, None
+        total = sum(terms)
+        (g,) = torch.autograd.grad(total, img)
+        return total.detach(), g
 
     def enable_densification(self, densifier, seed: int = 0):
         """training_statis / adjust_anchor on the schedule of trainForOneIteration (src/gaussian_mapper.cpp:961-968); the
@@ -385,6 +409,11 @@ class ScaffoldTrainerStep:
     def _forward_backward(self, kf: Keyframe, gt: torch.Tensor):
         image = self.render(kf)
         loss, dL = self.loss_fn(image, gt)
+        if self.freq_reg is not None:
+            floss, fg = self._freq_grad(image, gt)
+            if fg is not None:
+                dL = dL + fg
+                loss = loss + floss
         g = self.engine.backward(dL)
         self.neural.backward(g["means3D"], g["colors"], g["opacity"], g["scales"], g["rotations"], self.scaling_reg_weight)
         return loss

@@ -17,6 +17,8 @@ import torch  # noqa: E402,F401  (loads libtorch before the driver)
 lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libloss_ref.so"))
 lib.ref_l1_ssim.restype = C.c_int
 lib.ref_l1_ssim.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+lib.ref_freq_losses.restype = C.c_int
+lib.ref_freq_losses.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 
 out = {}
 cases = [(16, 16, 0.2, 1), (48, 64, 0.2, 2), (37, 53, 0.2, 3), (60, 90, 0.35, 4)]
@@ -32,5 +34,10 @@ for n, (H, W, lam, seed) in enumerate(cases):
     assert rc == 0
     out[f"case{n}_img"], out[f"case{n}_gt"], out[f"case{n}_lambda"] = img, gt, np.float32(lam)
     out[f"case{n}_loss_l1_ssim"], out[f"case{n}_dL_dimg"] = res, dL
-    print(H, W, lam, res)
+    # frequency-domain losses of the mapper (high_frequency_loss cutoff 0.4, low_freq_loss cutoff 0.2) and their gradients
+    fr = np.zeros(2, np.float32)
+    dH, dLo = np.zeros((3, H, W), np.float32), np.zeros((3, H, W), np.float32)
+    assert lib.ref_freq_losses(img.ctypes.data, gt.ctypes.data, H, W, fr.ctypes.data, dH.ctypes.data, dLo.ctypes.data) == 0
+    out[f"case{n}_freq_high_low"], out[f"case{n}_dL_high"], out[f"case{n}_dL_low"] = fr, dH, dLo
+    print(H, W, lam, res, fr)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "loss_reference.npz"), **out)

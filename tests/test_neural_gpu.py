@@ -162,6 +162,22 @@ def test_scaffold_render_equals_compacted_render():
         assert float(g[k][~mask].abs().max()) == 0.0, k
 
 
+def test_scaffold_trainer_with_mapper_loss_terms_runs():
+    """Scaling regulariser + FFT high-frequency regulariser (the mapper's loss, src/gaussian_mapper.cpp:924-945) wired in."""
+    from segs_slam_amd import neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    rd, model, _ = _setup(CASES[0], 3000, 23, dev)
+    cam = scenes.make_camera(320, 240, 300.0, 300.0, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.1, 0.2, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    step = ng.ScaffoldTrainerStep(model, cam.width, cam.height, scaling_reg_weight=0.01)
+    step.enable_frequency_regularization(start=0)
+    gt = torch.rand((3, cam.height, cam.width), device=dev)
+    losses = [float(step.training_once([kf], [gt])) for _ in range(5)]
+    assert np.isfinite(losses).all() and float(step.neural.scaling_reg) > 0
+
+
 def test_scaffold_trainer_reduces_loss():
     from segs_slam_amd import neural_gaussians as ng, scenes
     dev = torch.device("cuda:0")
