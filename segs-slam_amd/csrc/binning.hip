@@ -5,16 +5,17 @@
 //   radix_{count,scan,scatter}    K8  reference: cub::DeviceRadixSort::SortPairs rasterizer_impl.cu:303-308
 //   identify_tile_ranges_kernel   K9  reference: identifyTileRanges              rasterizer_impl.cu:116-138
 //
-// Integer/byte work, HBM-bound.  The sort is a stable LSD radix sort, 8 bits per pass over the key bits
-// [0, 32+bit) exactly as the reference asks of CUB, written for wave64:
-//  * a wave ranks 64 keys at a time with 8 ballots (one per digit bit) -> per-lane peer mask, rank =
-//    mbcnt(peers), so equal digits cost no LDS-atomic serialisation (the depth exponent byte and the
-//    tile bytes are extremely skewed);
-//  * each workgroup owns 4096 consecutive keys (16 per lane), reorders them by digit in LDS and writes
-//    every digit run with consecutive lanes on consecutive addresses;
-//  * per-pass global offsets come from a digit-major [256][nblocks] count matrix scanned by 256
-//    independent workgroups (no inter-workgroup hand-off inside a launch, so no cross-XCD visibility
-//    protocol is needed).
+// Integer/byte work.  The reference sorts R 64-bit (tile | depth) keys in ceil((32+bit)/8) byte passes; here the order is
+// produced by a TWO-LEVEL sort with the same result (capi.hip run_binning): the P Gaussians are sorted by their 32 depth
+// bits once (4 passes over P keys), instances are emitted in that order by a slot-parallel emitter, and the R instances are
+// then sorted by their tile id alone (2 passes at <= 65 536 tiles).  Both use this stable LSD radix sort, 8 bits per
+// pass, 32-bit keys (segs_sort_pairs exposes the 64-bit instantiation), written for wave64:
+//  * a wave ranks 64 keys at a time with 8 ballots (one per digit bit) -> per-lane peer mask, rank = mbcnt(peers), so
+//    equal digits cost no LDS-atomic serialisation (the depth exponent byte and the tile bytes are extremely skewed);
+//  * each workgroup owns 2048 consecutive keys (8 per lane), reorders them by digit in LDS and writes every digit run with
+//    consecutive lanes on consecutive addresses;
+//  * per-pass global offsets come from a digit-major [256][nblocks] count matrix scanned by 256 independent workgroups
+//    (no inter-workgroup hand-off inside a launch, so no cross-XCD visibility protocol is needed).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "gs_layout.h"
@@ -204,11 +205,9 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// K8 helpers.  The sort runs on a compacted image of the key, k' = (tile << dbits) | (depth_bits - dmin), where
-// [dmin, dmin + 2^dbits) covers every depth present (depth bits of positive floats are monotone, so the order,
-// ties included, is exactly that of the reference's 32+bit-bit key); the stored keys stay untouched.  A Replica-like
-// depth range (0.2 m .. 6 m) needs 26 of the 32 depth bits, i.e. 5 byte passes instead of 6 at 1080p.
-// dbits < 0 selects the tile id alone (key >> 32): used for the second, instance-level sort (see capi.hip).
+// K8 helpers.  64-bit keys (segs_sort_pairs): the digit is taken from k' = (hi32 << dbits) | (lo32 - dmin), or from hi32
+// alone when dbits < 0.  32-bit keys (the pipeline): digit of (key - dmin).  Depth bits of positive floats are monotone
+// in the depth, so sorting on them (ties included) gives exactly the reference's order.
 struct KeyMap { uint32_t dmin; int dbits; };
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, KeyMap km) {
   const uint64_t kc = km.dbits < 0 ? (key >> 32) : (((key >> 32) << km.dbits) | (uint64_t)((uint32_t)key - km.dmin));

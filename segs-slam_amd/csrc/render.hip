@@ -3,24 +3,25 @@
 //   render_fwd_kernel  K10  reference: renderCUDA forward   cuda_rasterizer/forward.cu:339-452
 //   render_bwd_kernel  K11  reference: renderCUDA backward  cuda_rasterizer/backward.cu:399-557
 //
-// These two kernels are VALU-bound, not HBM-bound (~25 / ~80 vector ops per (pixel, Gaussian) pair
-// against 64 B of record per 64 pairs).  MI355X mapping:
-//  * workgroup = one 16x16 tile (the binning unit, fixed by the reference's key format) = 4 wave64;
-//    each wave owns an 8x8 pixel quadrant and walks the tile's list on its own: no LDS staging, no
-//    workgroup barrier.
-//  * the list is read 64 entries at a time with one coalesced vector load; each entry carries a 4-bit
-//    "quadrants this instance can touch" mask (gs_layout.h), so one ballot yields the 64-bit set of entries
-//    this wave must evaluate and everything else is skipped with scalar bit-scans (s_ff1 / s_flbit).
-//  * the per-Gaussian operands are wave-uniform: the 64-byte record is fetched with scalar (SMEM) loads
-//    straight into SGPRs and used as the scalar operand of the VALU instructions -- no LDS broadcast
-//    reads (which would be LDS-issue bound at 4 waves per CU-cycle).
-//  * early termination is per wave (8x8 block) instead of per 16x16 tile.
+// Neither kernel is HBM-bound: per (Gaussian, 8x8 quadrant) the forward issues ~22 vector instructions, the backward ~39,
+// against 64 B of record; the forward is VALU-issue bound, the backward VALU- and LDS-bound at once.
+// MI355X mapping:
+//  * workgroup = one 16x16 tile (the binning unit, fixed by the reference's key format) = 4 wave64; each wave owns an
+//    8x8 pixel quadrant and walks the tile's list on its own: no workgroup barrier anywhere.
+//  * the list is read 64 entries at a time with one coalesced vector load; each entry carries a 4-bit "quadrants this
+//    instance can reach" mask (gs_layout.h); the entries of this wave's quadrant are compacted to the low lanes with
+//    ds_permute, their 64-byte records gathered one per lane (two chunks in flight ahead of the one being evaluated).
+//  * the per-Gaussian operands are wave-uniform: the batch's records are staged in LDS and read as broadcasts
+//    (scalar loads of the records, the first design, were issue- and latency-bound; operands by DPP row broadcast cost as
+//    much VALU issue as the LDS time they save -- both measured).
+//  * early termination is per wave (8x8 block) instead of per 16x16 tile; a terminated pixel keeps T = 0 and a negative
+//    threshold, which makes later Gaussians arithmetic no-ops for it without per-lane branches.
 //  * exp(power) = exp2(log2e * power) with log2e folded into the stored conic (v_exp_f32).
-//  * backward: the 9 partial sums of FOUR Gaussians are reduced together: v_permlane32_swap and
-//    v_permlane16_swap fold 4x(64 lanes) into 4 rows of 16 lanes in 5 adds, four DPP row steps finish all
-//    four at once (10 cross-lane ops per quantity per 4 Gaussians instead of 24), and the 4x9 sums leave as
-//    ONE float-atomic wave instruction (one 36-byte segment of a 64-byte gradient row per Gaussian) instead
-//    of the reference's 9 atomics per (pixel, Gaussian) pair.
+//  * backward: two roles alternate inside each wave, 16 list entries at a time (see render_bwd_kernel): pixel lanes
+//    emit w = dL/dG * G and alpha*T into LDS tiles, Gaussian lanes read them transposed and accumulate nine moment sums
+//    with FMAs (dL/dpixel arrives by DPP row broadcast fused into those FMAs); 4 row partials are folded with
+//    v_permlane32/16_swap and the sums of 4 Gaussians leave as ONE float-atomic wave instruction (36 contiguous bytes per
+//    Gaussian) instead of the reference's 9 atomics per (pixel, Gaussian) pair.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "gs_layout.h"
