@@ -44,6 +44,12 @@ const char* segs_last_error(void);
 #define SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY 1u
 uint32_t segs_raster_set_flags(uint32_t flags);
 
+/* Resident mode only, per host thread; returns the previous pointer.  When set, segs_rasterize_forward_resident also
+ * stores status[0] (R) and status[3] (overflow) into this HOST-MAPPED, device-accessible array of 4 words (pinned memory:
+ * hipHostMalloc / a pinned torch tensor) from inside its last binning kernel, so the host can learn them after an event
+ * wait without a device-to-host copy being enqueued in the stream every iteration. */
+uint32_t* segs_raster_set_status_mirror(uint32_t* host_mapped_status);
+
 /* Scratch sizes (reference: CudaRasterizer::required<GeometryState|ImageState|BinningState>,
  * cuda_rasterizer/rasterizer_impl.h:66-72).  segs_binning_bytes(n) is also the temp size of segs_sort_pairs(n); the
  * forward's own binning request (through the callback) additionally covers a P-sized depth sort. */

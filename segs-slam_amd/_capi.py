@@ -32,6 +32,7 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
     "segs_last_error": (C.c_char_p, []),
     "segs_raster_set_flags": (C.c_uint, [C.c_uint]),
+    "segs_raster_set_status_mirror": (_vp, [_vp]),
     "segs_training_statis": (_i, [_i, _i] + [_vp] * 9),
     "segs_anchor_growing_temp_bytes": (_sz, [_i, _i]),
     "segs_anchor_growing_level": (_i, [_i, _i, _i, _i] + [_vp] * 7 + [_f, _f, _f, _i] + [_vp] * 5),

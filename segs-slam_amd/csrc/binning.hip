@@ -413,9 +413,18 @@ template __global__ void radix_scatter_kernel<uint32_t>(const uint32_t*, const u
 // (rasterizer_impl.cu:310 uses a memset).  A per-tile binary search over the sorted ids instead of this R-sized pass was
 // tried and is slower (44 dependent loads per tile: 17 us vs 9 us at R = 3.7 M).
 __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys,
-                                                                   uint2* __restrict__ ranges, const uint32_t* __restrict__ n_dev) {
-  if (n_dev) L = (int)min(*n_dev, (uint32_t)L);
+                                                                   uint2* __restrict__ ranges, const uint32_t* __restrict__ n_dev,
+                                                                   uint32_t* __restrict__ status, uint32_t* __restrict__ status_mirror) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (n_dev) {
+    const uint32_t n = *n_dev;
+    if (idx == 0 && status) {   // resident mode: overflow word, and the status words mirrored into host-mapped memory
+      const uint32_t over = n > (uint32_t)L ? 1u : 0u;
+      status[3] = over;
+      if (status_mirror) { status_mirror[0] = n; status_mirror[3] = over; }
+    }
+    L = (int)min(n, (uint32_t)L);
+  }
   if (idx >= L) return;
   const uint32_t cur = keys[idx];
   if (idx == 0) ranges[cur].x = 0;

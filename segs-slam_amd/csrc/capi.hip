@@ -19,6 +19,7 @@ namespace {
 
 thread_local std::string g_err;
 thread_local uint32_t g_flags = 0u;   // segs_raster_set_flags
+thread_local uint32_t* g_status_mirror = nullptr;   // segs_raster_set_status_mirror
 
 int fail(int code, const char* what) {
   g_err = what;
@@ -132,7 +133,8 @@ Geom geom_at(char* p, int P) { return Geom{geom_layout(P), align_ptr(p)}; }
 int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, const float* colors, const float* opac,
                    const float* scales, float mod, const float* rots, const float* cov3D_precomp, const float* view,
                    const float* proj, float tan_fovx, float tan_fovy, int* radii, const float* shs, int D, int M,
-                   const float* cam_pos, hipStream_t st) {
+                   const float* cam_pos, hipStream_t st, uint32_t* depth_keys = nullptr, uint32_t* depth_vals = nullptr,
+                   uint2* ranges = nullptr) {
   const float focal_y = H / (2.0f * tan_fovy);   // rasterizer_impl.cu:221-222
   const float focal_x = W / (2.0f * tan_fovx);
   const uint32_t gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
@@ -140,7 +142,7 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
   preprocess_fwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, scales, mod, rots, opac, colors, cov3D_precomp, view,
                                                      proj, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, radii,
                                                      G.rec(), G.bin(), G.block_sums(), G.block_sums() + (G.L.nblocks + 1), shs, D, M, cam_pos,
-                                                     G.clamped(), g_flags);
+                                                     G.clamped(), g_flags, depth_keys, depth_vals, ranges, (int)(gx * gy));
   }
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
@@ -154,13 +156,13 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
 // `total_out` (3 device words) receives the instance count produced by the depth-ordered scan.
 int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSortLayout& GS, uint2* ranges, int P, int n_cap,
                 const uint32_t* n_dev, uint32_t dmin, int dbits, uint32_t dcull, uint32_t gx, uint32_t gy, uint32_t* total_out,
-                hipStream_t st) {
+                hipStream_t st, bool depth_keys_ready = false) {
   const int bit = (int)getHigherMsb(gx * gy);
   // (1)
   char* gbin = bin + GS.base;
   const BinningLayout& GL = GS.inner;
   const int gside = ((dbits + 7) / 8) & 1;  // depth keys in [dmin, dcull], dcull - dmin < 2^dbits; culled Gaussians carry dcull
-  { PROF(K_DUPLICATE);
+  if (!depth_keys_ready) { PROF(K_DUPLICATE);
   make_depth_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), dcull, (uint32_t*)(gbin + GL.keys[gside]), (uint32_t*)(gbin + GL.vals[gside]),
                                                       ranges, (int)(gx * gy));
   }
@@ -193,19 +195,24 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   rc = sort_pairs<uint32_t>(bin, BL, n_cap, bit, 0u, 0, st, n_dev);
   if (rc) return rc;
   { PROF(K_RANGES);
-  identify_tile_ranges_kernel<<<(n_cap + 255) / 256, 256, 0, st>>>(n_cap, (const uint32_t*)(bin + BL.keys[0]), ranges, n_dev);
+  identify_tile_ranges_kernel<<<(n_cap + 255) / 256, 256, 0, st>>>(n_cap, (const uint32_t*)(bin + BL.keys[0]), ranges, n_dev,
+                                                                   n_dev ? total_out : nullptr, n_dev ? g_status_mirror : nullptr);
   }
   LAUNCH_TRY("identify_tile_ranges_kernel");
   return SEGS_OK;
 }
-
-__global__ void overflow_flag_kernel(uint32_t* status, uint32_t capacity) { status[3] = status[0] > capacity ? 1u : 0u; }
 
 }  // namespace
 
 extern "C" {
 
 const char* segs_last_error(void) { return g_err.c_str(); }
+
+uint32_t* segs_raster_set_status_mirror(uint32_t* host_mapped_status) {
+  uint32_t* old = g_status_mirror;
+  g_status_mirror = host_mapped_status;
+  return old;
+}
 
 uint32_t segs_raster_set_flags(uint32_t flags) {
   const uint32_t old = g_flags;
@@ -518,16 +525,18 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
   const BinningLayout BL = binning_layout(capacity);
   const GaussSortLayout GS = gauss_sort_layout(capacity, P);
   if (!radii) radii = G.radii_internal();
+  uint2* ranges = (uint2*)(img + IL.ranges);
+  // The depth keys are sorted on all 32 bits (the exact range is only known on the device; positive finite floats stay
+  // below the culled key 0xFFFFFFFF), so K1 can write them -- and zero the range table -- itself: one launch less.
+  char* gbin = bin + GS.base;
+  const int gside = (4 & 1);   // 32 key bits = 4 byte passes: the sort starts from side 0 (see sort_pairs)
   int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales, scale_modifier,
-                          rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M, cam_pos, st);
+                          rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M, cam_pos, st,
+                          (uint32_t*)(gbin + GS.inner.keys[gside]), (uint32_t*)(gbin + GS.inner.vals[gside]), ranges);
   if (rc) return rc;
-  uint2* ranges = (uint2*)(img + IL.ranges);   // zeroed inside run_binning (make_depth_keys_kernel)
-  // depth keys are sorted on all 32 bits (the exact range is only known on the device); positive finite floats stay below
-  // the culled key 0xFFFFFFFF
-  rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, 0u, 32, 0xFFFFFFFFu, gx, gy, status, st);
+  rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, 0u, 32, 0xFFFFFFFFu, gx, gy, status, st, true);
   if (rc) return rc;
-  overflow_flag_kernel<<<1, 1, 0, st>>>(status, (uint32_t)capacity);
-  LAUNCH_TRY("overflow_flag_kernel");
+  // status[3] (overflow) and the host mirror are written by identify_tile_ranges_kernel at the end of run_binning
   { PROF(K_RENDER_FWD);
   render_fwd_kernel<<<dim3(gx, gy), 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(), background,
                                                   (float*)(img + IL.final_T), (uint32_t*)(img + IL.n_contrib), out_color);

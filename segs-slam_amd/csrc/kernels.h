@@ -14,7 +14,8 @@ __global__ void preprocess_fwd_kernel(
     int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy,
     int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
     uint32_t* __restrict__ depth_range, const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos,
-    uint32_t* __restrict__ clamped, uint32_t flags);
+    uint32_t* __restrict__ clamped, uint32_t flags, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ depth_vals,
+    uint2* __restrict__ ranges, int num_tiles);
 
 __global__ void visible_filter_kernel(
     int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
@@ -55,7 +56,8 @@ __global__ void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32
                                      uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_totals, int nblocks,
                                      const uint32_t* __restrict__ n_dev);
 __global__ void identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges,
-                                            const uint32_t* __restrict__ n_dev);
+                                            const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ status,
+                                            uint32_t* __restrict__ status_mirror);
 
 // ---- render.hip
 __global__ void render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,

@@ -299,7 +299,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
     uint32_t* __restrict__ depth_range /* per workgroup: [b] = max(depth_bits), [nblocks + b] = max(~depth_bits), visible only */,
     const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, uint32_t* __restrict__ clamped,
-    uint32_t flags) {
+    uint32_t flags, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ depth_vals, uint2* __restrict__ ranges,
+    int num_tiles) {
   __shared__ float lds[768];
   __shared__ uint32_t wave_sums[4], wave_dmax[4], wave_dnmin[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -344,7 +345,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     }
     radii[idx] = g.radius;
     reinterpret_cast<uint4*>(bin)[idx] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
+    if (depth_keys) {   // resident mode: what make_depth_keys_kernel would write (32-bit depth keys, culled = 0xFFFFFFFF)
+      depth_keys[idx] = b.tiles_touched ? b.depth_bits : 0xFFFFFFFFu;
+      depth_vals[idx] = (uint32_t)idx;
+    }
   }
+  if (ranges)
+    for (int t = idx; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // rasterizer_impl.cu:310
   // workgroup sum of tiles_touched -> block_sums[blockIdx] (feeds the prefix sum, K5); depth range for the sort
   uint32_t s = touched;
   uint32_t dmax = touched ? dbits_mine : 0u, dnmin = touched ? ~dbits_mine : 0u;

@@ -114,13 +114,14 @@ class RasterEngine:
             self.check(raise_on_overflow=False)  # an overflow noticed here was already handled by the caller's own check
         self._lib.segs_raster_set_flags(self.flags)  # per host thread; set on every call
         if self.resident and self.capacity > 0:
+            self._lib.segs_raster_set_status_mirror(C.c_void_p(self._status_host.data_ptr()))
             st = self._lib.segs_rasterize_forward_resident(
                 p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
                 None, p(colors), p(opacity), p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix),
                 p(campos), float(tanfovx), float(tanfovy), p(self.out_color), p(self.radii), p(self._status), self._stream())
             _capi.check(st, "segs_rasterize_forward_resident")
             if not torch.cuda.is_current_stream_capturing():
-                self._status_host.copy_(self._status, non_blocking=True)
+                # R and the overflow word were stored into the pinned host words by the last binning kernel
                 self._status_event.record(torch.cuda.current_stream(self.device))
                 self._status_pending = True
             self._last = (bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
