@@ -388,11 +388,14 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
   extern __shared__ __align__(16) float lds_dyn[];
   float* img = lds_dyn;
   Small& S = *reinterpret_cast<Small*>(lds_dyn + N_IMG_FWD * 64);
+  __shared__ uint32_t blk_kept;
   const uint32_t n = *count;
   if (blockIdx.x * 128u >= n) return;
+  if (threadIdx.x == 0) blk_kept = 0u;
   stage_tables(img, S, N_IMG_FWD, g_img, g_small);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
+  uint32_t kept_total = 0;
   for (uint32_t g0 = (blockIdx.x * 4u + wv) * 32u; g0 < n; g0 += gridDim.x * 128u) {
     const uint32_t t = g0 + col;
     const bool valid = t < n;
@@ -439,11 +442,14 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
         }
       }
     }
-    kept = valid ? kept : 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) kept += (uint32_t)__shfl_xor((int)kept, off, 64);
-    if (lane == 0 && kept) atomicAdd(n_kept, kept);
+    kept_total += valid ? kept : 0u;
   }
+  // one global atomic per workgroup (one per wave on a single word serialised ~1500 atomics: +10 us)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) kept_total += (uint32_t)__shfl_xor((int)kept_total, off, 64);
+  if (lane == 0) atomicAdd(&blk_kept, kept_total);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_kept) atomicAdd(n_kept, blk_kept);
 }
 
 // End of one MLP in the backward pass: relu mask on dH = W2^T dOUT (accumulated tile by tile), H and dHpre to the
@@ -783,13 +789,16 @@ __global__ void __launch_bounds__(64) wgrad_mfma_kernel(WJobs jobs, const uint32
 
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WJobs jobs, const float* __restrict__ partial, float* __restrict__ gsum,
                                                            float* __restrict__ dparams) {
-  __shared__ float part[4][64];
+  // 16 elements x 16 slices of the partial waves per workgroup: every thread has its 16 loads in flight at once (the sum over
+  // 256 per-wave partials was a latency-bound chain of load batches: 20 us; the data is only ~10 MB)
+  constexpr int SLICES = 16, PER = WG_WAVES / SLICES;
+  __shared__ float part[SLICES][16];
   const WJob job = jobs.j[blockIdx.y];
   if (!job.active) return;
   const int nelem = (job.M + 1) * job.N;   // weight entries + one bias row
-  if (blockIdx.x * 64 >= nelem) return;
-  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;   // element of this workgroup, slice of the partial waves
-  const int e = blockIdx.x * 64 + el;
+  if (blockIdx.x * 16 >= nelem) return;
+  const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
   float s = 0.f;
   int dst = 0;
   bool live = false;
@@ -802,17 +811,22 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WJobs jobs, const flo
     if (job.b_half > 0) { const int hh = j / job.b_half, r = j - hh * job.b_half; o = r < job.b_real ? job.b_real * hh + r : -1; }
     live = o >= 0;
     dst = i < job.M ? job.w_off + o * job.ldw + i : job.bias_off + o;
-    const float* p = partial + ((size_t)blockIdx.y * WG_WAVES + q * (WG_WAVES / 4)) * WG_TILE + slot;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int w = 0; w < WG_WAVES / 4; w += 8)
+    const float* p = partial + ((size_t)blockIdx.y * WG_WAVES + q * PER) * WG_TILE + slot;
+    float acc[PER];
 #pragma unroll
-      for (int u = 0; u < 8; u++) acc[u] += p[(size_t)(w + u) * WG_TILE];
-    s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (int u = 0; u < PER; u++) acc[u] = p[(size_t)u * WG_TILE];
+#pragma unroll
+    for (int st = PER / 2; st > 0; st >>= 1)
+#pragma unroll
+      for (int u = 0; u < st; u++) acc[u] += acc[u + st];
+    s = acc[0];
   }
   part[q][el] = s;
   __syncthreads();
   if (q == 0 && live) {
-    const float t = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < SLICES; k++) t += part[k][el];
     gsum[dst] = t;
     dparams[dst] += t;
   }
@@ -938,7 +952,7 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   if (scaling_reg_out) reg_finish_kernel<<<1, 1, 0, st>>>(T.count, T.gsum + L.total + 8, scaling_reg_weight, scaling_reg_out);
   const WJobs J = make_jobs(L);
   wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), 64, 0, st>>>(J, T.count, T.rows, T.partial);
-  wgrad_reduce_kernel<<<dim3((37 * 72 + 63) / 64, WG_JOBS), 256, 0, st>>>(J, T.partial, T.gsum, dL_dmlp_params);
+  wgrad_reduce_kernel<<<dim3((37 * 72 + 15) / 16, WG_JOBS), 256, 0, st>>>(J, T.partial, T.gsum, dL_dmlp_params);
   if (L.app > 0) appearance_finish_kernel<<<1, 64, 0, st>>>(L, mlp_params, pose7, T.gsum, dL_dmlp_params);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : (int)e;
