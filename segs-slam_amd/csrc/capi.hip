@@ -16,19 +16,25 @@
 using namespace segs;
 
 namespace {
-
-thread_local std::string g_err;
-thread_local uint32_t g_flags = 0u;   // segs_raster_set_flags
-thread_local uint32_t* g_status_mirror = nullptr;   // segs_raster_set_status_mirror
-
-int fail(int code, const char* what) {
+thread_local std::string g_err;   // segs_last_error(): message of the last failing entry point on this host thread
+}
+// Shared by every translation unit of the library (kernels.h): record the message, return the status code.
+int segs::set_error(int code, const char* what) {
   g_err = what;
   return code;
 }
-int hip_fail(hipError_t e, const char* where) {
+int segs::set_hip_error(hipError_t e, const char* where) {
   g_err = std::string(where) + ": " + hipGetErrorString(e);
   return (int)e > 0 ? (int)e : 1;
 }
+
+namespace {
+
+thread_local uint32_t g_flags = 0u;   // segs_raster_set_flags
+thread_local uint32_t* g_status_mirror = nullptr;   // segs_raster_set_status_mirror
+
+int fail(int code, const char* what) { return segs::set_error(code, what); }
+int hip_fail(hipError_t e, const char* where) { return segs::set_hip_error(e, where); }
 #define HIP_TRY(expr)                                   \
   do {                                                  \
     hipError_t _e = (expr);                             \

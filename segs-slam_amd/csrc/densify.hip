@@ -15,6 +15,7 @@
 #include <cstdint>
 #include "../../include/segs_densify.h"
 #include "../../include/segs_raster.h"
+#include "kernels.h"
 
 namespace {
 
@@ -205,14 +206,14 @@ extern "C" {
 int segs_training_statis(int A, int n_offsets, const float* neural_opacity, const int* visible_radii, const int* radii,
                          const float* dL_dmean2D, float* opacity_accum, float* anchor_demon, float* offset_gradient_accum,
                          float* offset_denom, void* stream) {
-  if (A < 0 || n_offsets <= 0) return SEGS_ERR_INVALID_ARGUMENT;
+  if (A < 0 || n_offsets <= 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   if (A == 0) return SEGS_OK;
   if (!neural_opacity || !radii || !dL_dmean2D || !opacity_accum || !anchor_demon || !offset_gradient_accum || !offset_denom)
-    return SEGS_ERR_INVALID_ARGUMENT;
+    return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   stats_kernel<<<(A + 255) / 256, 256, 0, (hipStream_t)stream>>>(A, n_offsets, neural_opacity, visible_radii, radii, dL_dmean2D,
                                                                  opacity_accum, anchor_demon, offset_gradient_accum, offset_denom);
   const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? SEGS_OK : (int)e;
+  return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }
 
 size_t segs_anchor_growing_temp_bytes(int A, int n_candidates) {
@@ -225,26 +226,26 @@ int segs_anchor_growing_level(int A, int A_init, int n_offsets, int feat_dim, co
                               const float* rnd, float threshold, float rand_threshold, float cur_size, int max_new,
                               float* new_anchor, float* new_feat, int* n_new, char* temp, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (feat_dim != 32) return SEGS_ERR_UNSUPPORTED;
-  if (A <= 0 || A_init <= 0 || A_init > A || n_offsets <= 0 || max_new < 0 || !(cur_size > 0.f)) return SEGS_ERR_INVALID_ARGUMENT;
+  if (feat_dim != 32) return segs::set_error(SEGS_ERR_UNSUPPORTED, "unsupported configuration (feat_dim must be 32, n_offsets 10, appearance_dim <= 64)");
+  if (A <= 0 || A_init <= 0 || A_init > A || n_offsets <= 0 || max_new < 0 || !(cur_size > 0.f)) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   if (!anchor || !offset || !scaling_log || !anchor_feat || !grads || !offset_mask || !rnd || !new_anchor || !new_feat || !n_new || !temp)
-    return SEGS_ERR_INVALID_ARGUMENT;
+    return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   const int n_slots = A_init * n_offsets;
   GrowTemp T;
   grow_carve(A, n_slots, temp, &T);
   hipError_t e = hipMemsetAsync(T.count, 0, 8, st);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) return segs::set_hip_error(e, __func__);
   e = hipMemsetAsync(n_new, 0, sizeof(int), st);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) return segs::set_hip_error(e, __func__);
   select_candidates_kernel<<<(n_slots + 255) / 256, 256, 0, st>>>(n_slots, n_offsets, anchor, offset, scaling_log, grads, offset_mask,
                                                                    rnd, threshold, rand_threshold, cur_size, T.count, T.ckeys_in,
                                                                    T.cvals_in);
   anchor_keys_kernel<<<(A + 255) / 256, 256, 0, st>>>(A, anchor, cur_size, T.akeys_in, T.avals_in);
   uint32_t n_cand = 0;   // the one host synchronisation of this (rare) call: the sort and the launches are sized by it
   e = hipMemcpyAsync(&n_cand, T.count, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) return segs::set_hip_error(e, __func__);
   e = hipStreamSynchronize(st);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) return segs::set_hip_error(e, __func__);
   if (n_cand == 0) return SEGS_OK;
   const int n = (int)n_cand;
   int rc = segs_sort_pairs(T.ckeys_in, T.cvals_in, T.ckeys, T.cvals, n, 63, T.sort_temp, stream);
@@ -262,7 +263,7 @@ int segs_anchor_growing_level(int A, int A_init, int n_offsets, int feat_dim, co
     emit_new_anchors_kernel<<<(cap + 7) / 8, 256, 0, st>>>(n, n_new, max_new, T.head_pos, T.ckeys, T.cvals, anchor_feat, cur_size,
                                                            new_anchor, new_feat);
   e = hipGetLastError();
-  return e == hipSuccess ? SEGS_OK : (int)e;
+  return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }
 
 }  // extern "C"

@@ -6,6 +6,11 @@
 
 namespace segs {
 
+// ---- capi.hip: error text behind segs_last_error(), shared by all translation units
+int set_error(int code, const char* what);
+int set_hip_error(hipError_t e, const char* where);
+
+
 // ---- preprocess.hip
 __global__ void preprocess_fwd_kernel(
     int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,

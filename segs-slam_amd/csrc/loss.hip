@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include "../../include/segs_raster.h"
+#include "kernels.h"
 #include "../../include/segs_train.h"
 
 namespace {
@@ -166,7 +167,7 @@ size_t segs_l1_ssim_temp_bytes(int H, int W) { return (size_t)3 * 3 * H * W * si
 int segs_l1_ssim_loss(const float* img1, const float* img2, int H, int W, float lambda_dssim, float* loss_out, float* dL_dimg1,
                       char* temp, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (!img1 || !img2 || !loss_out || !dL_dimg1 || !temp || H <= 0 || W <= 0) return SEGS_ERR_INVALID_ARGUMENT;
+  if (!img1 || !img2 || !loss_out || !dL_dimg1 || !temp || H <= 0 || W <= 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   Win win;
   float sum = 0.f;
   for (int x = 0; x < 11; ++x) {  // loss_utils.h:51-64: integer offsets, float arithmetic
@@ -186,7 +187,7 @@ int segs_l1_ssim_loss(const float* img1, const float* img2, int H, int W, float 
   finish_loss_kernel<<<1, 1024, 0, st>>>(partial, (int)(grid.x * grid.y * grid.z), inv_n, lambda_dssim, loss_out);
   ssim_bwd_kernel<<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, (1.f - lambda_dssim) * inv_n, lambda_dssim * inv_n, dL_dimg1);
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? SEGS_OK : (int)e;
+  return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }
 
 }  // extern "C"

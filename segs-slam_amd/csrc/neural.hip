@@ -24,6 +24,7 @@
 #include <cstdint>
 #include "../../include/segs_neural.h"
 #include "../../include/segs_raster.h"
+#include "kernels.h"
 
 namespace {
 
@@ -58,7 +59,7 @@ struct Layout {           // float offsets into the flat parameter block
 
 int make_layout(const segs_neural_dims* d, Layout* L, int64_t* offsets, int64_t* counts, int* ntensors) {
   if (!d || d->feat_dim != FD || d->n_offsets != NO || d->appearance_dim < 0 || d->appearance_dim > MAX_APP)
-    return SEGS_ERR_UNSUPPORTED;
+    return segs::set_error(SEGS_ERR_UNSUPPORTED, "unsupported configuration (feat_dim must be 32, n_offsets 10, appearance_dim <= 64)");
   int pos = 0, n = 0;
   auto add = [&](int count) {
     if (offsets) offsets[n] = pos;
@@ -901,15 +902,15 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
   Layout L;
   int rc = make_layout(dims, &L, nullptr, nullptr, nullptr);
   if (rc != SEGS_OK) return rc;
-  if (A < 0) return SEGS_ERR_INVALID_ARGUMENT;
+  if (A < 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   if (A == 0) return SEGS_OK;
   if (!anchor || !offset || !anchor_feat || !scaling_log || !mlp_params || !camera_center || !means3D || !colors || !opacity ||
       !scales || !rotations || !neural_opacity || !temp || (L.app > 0 && !pose7))
-    return SEGS_ERR_INVALID_ARGUMENT;
+    return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   Temp T;
   temp_carve(A, L.total, temp, &T);
   hipError_t e = hipMemsetAsync(T.count, 0, 2 * sizeof(uint32_t), st);   // [0] visible anchors, [1] kept candidates
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) return segs::set_hip_error(e, __func__);
   const int nb = (A + 255) / 256;
   compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity);
   static_assert(N_IMG_BWD == 262 && sizeof(Small) <= 8192, "temp_carve sizes");
@@ -917,7 +918,7 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
   neural_fwd_kernel<<<NEURAL_GRID, 256, N_IMG_FWD * 64 * sizeof(float) + sizeof(Small), st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
                                         camera_center, means3D, colors, opacity, scales, rotations, neural_opacity, T.count + 1);
   e = hipGetLastError();
-  return e == hipSuccess ? SEGS_OK : (int)e;
+  return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }
 
 int segs_neural_backward(const segs_neural_dims* dims, int A, const float* anchor, const float* offset, const float* anchor_feat,
@@ -930,21 +931,21 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   Layout L;
   int rc = make_layout(dims, &L, nullptr, nullptr, nullptr);
   if (rc != SEGS_OK) return rc;
-  if (A < 0) return SEGS_ERR_INVALID_ARGUMENT;
+  if (A < 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   if (A == 0) return SEGS_OK;
   if (!anchor || !offset || !anchor_feat || !scaling_log || !mlp_params || !camera_center || !dL_dmeans3D || !dL_dcolors ||
       !dL_dopacity || !dL_dscales || !dL_drotations || !dL_danchor || !dL_doffset || !dL_dfeat || !dL_dscaling_log ||
       !dL_dmlp_params || !temp || (L.app > 0 && !pose7))
-    return SEGS_ERR_INVALID_ARGUMENT;
+    return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   Temp T;
   temp_carve(A, L.total, temp, &T);
   constexpr size_t bwd_lds = N_IMG_BWD * 64 * sizeof(float) + sizeof(Small);   // > 64 KB: needs the opt-in below
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
-  if (attr_rc != hipSuccess) return (int)attr_rc;
+  if (attr_rc != hipSuccess) return segs::set_hip_error(attr_rc, __func__);
   {
     const hipError_t me = hipMemsetAsync(T.gsum + L.total + 8, 0, sizeof(float), st);
-    if (me != hipSuccess) return (int)me;
+    if (me != hipSuccess) return segs::set_hip_error(me, __func__);
   }
   neural_bwd_kernel<<<NEURAL_GRID, 256, bwd_lds, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
                                         camera_center, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor,
@@ -955,7 +956,7 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   wgrad_reduce_kernel<<<dim3((37 * 72 + 15) / 16, WG_JOBS), 256, 0, st>>>(J, T.partial, T.gsum, dL_dmlp_params);
   if (L.app > 0) appearance_finish_kernel<<<1, 64, 0, st>>>(L, mlp_params, pose7, T.gsum, dL_dmlp_params);
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? SEGS_OK : (int)e;
+  return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }
 
 }  // extern "C"

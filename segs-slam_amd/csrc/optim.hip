@@ -7,6 +7,7 @@
 #include <cmath>
 #include <string>
 #include "../../include/segs_raster.h"
+#include "kernels.h"
 #include "../../include/segs_train.h"
 
 #pragma clang fp contract(off)
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
 extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,
                                       int nseg, double beta1, double beta2, double eps, int64_t step, float grad_scale, int zero_grad,
                                       const uint32_t* skip_flag, void* stream) {
-  if (!param || !grad || !exp_avg || !exp_avg_sq || !segments || nseg <= 0 || nseg > MAX_SEG || step <= 0) return SEGS_ERR_INVALID_ARGUMENT;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !segments || nseg <= 0 || nseg > MAX_SEG || step <= 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   SegTable tab{};
   tab.nseg = nseg;
   long long total = 0;
@@ -83,7 +84,7 @@ extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg,
   const double bc1 = 1.0 - std::pow(beta1, (double)step);
   const double bc2 = 1.0 - std::pow(beta2, (double)step);
   for (int i = 0; i < nseg; i++) {
-    if (segments[i].offset < 0 || segments[i].count < 0) return SEGS_ERR_INVALID_ARGUMENT;
+    if (segments[i].offset < 0 || segments[i].count < 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
     tab.offset[i] = segments[i].offset;
     tab.count[i] = segments[i].count;
     tab.step_size[i] = (float)(segments[i].lr / bc1);
@@ -99,7 +100,7 @@ extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg,
                                                             (float)(1.0 - beta1), (float)(1.0 - beta2), sqrt_bc2, (float)eps,
                                                             grad_scale, zero_grad, skip_flag);
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? SEGS_OK : (int)e;
+  return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }
 
 extern "C" int segs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,

@@ -112,7 +112,18 @@ class RasterEngine:
             assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
         if self.resident and self.capacity > 0:
             self.check(raise_on_overflow=False)  # an overflow noticed here was already handled by the caller's own check
-        self._lib.segs_raster_set_flags(self.flags)  # per host thread; set on every call
+        # the two switches are per-host-thread state of the library: set for this call only, restored afterwards, so that
+        # the reference-shaped wrappers (rasterize_points.py) keep the reference's behaviour on the same thread
+        old_flags = self._lib.segs_raster_set_flags(self.flags)
+        try:
+            return self._forward(p, bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos, tanfovx,
+                                 tanfovy, scale_modifier)
+        finally:
+            self._lib.segs_raster_set_flags(old_flags)
+            self._lib.segs_raster_set_status_mirror(None)
+
+    def _forward(self, p, bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+                 scale_modifier):
         if self.resident and self.capacity > 0:
             self._lib.segs_raster_set_status_mirror(C.c_void_p(self._status_host.data_ptr()))
             st = self._lib.segs_rasterize_forward_resident(
