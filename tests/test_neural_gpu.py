@@ -218,3 +218,40 @@ def test_model_io_round_trip(tmp_path):
     assert rows[3].split(" ")[5] == f"{float(mlp['mlp_cov.2.weight'][3, 5]):.5f}"
     for fn in ("opacity_weight1.txt", "opacity_bias2.txt", "color_bias1.txt", "feat_weight2.txt"):
         assert (tmp_path / "mlp" / fn).exists()
+
+
+def test_second_slab_of_persistent_workgroups_is_consistent():
+    """A = 70 001 anchors exceed 512 workgroups x 128 anchors, so the persistent workgroups loop over a second slab.  Checked
+    by consistency (no float64 reference at this size): the same anchors processed as two smaller models give bit-identical
+    per-anchor outputs and gradients (the arithmetic of an anchor does not depend on the wave that carries it) and MLP weight
+    gradients that add up (different summation order: 1e-5 of the largest entry)."""
+    from segs_slam_amd import neural_gaussians as ng
+    dev = torch.device("cuda:0")
+    A, A1 = 70001, 35000
+    rd = neural_ref.NeuralDims(**CASES[0])
+    md = ng.ModelDims(**CASES[0])
+    anchor, offset, feat, scaling_log, mlp = neural_ref.random_model(rd, A, 77)
+    campos = torch.tensor([0.1, -0.2, -0.5], device=dev)
+    pose7 = torch.tensor([0.3, -0.1, 0.2, 0.9, 0.1, -0.3, 0.2], device=dev)
+    g = torch.Generator().manual_seed(3)
+    grads = [torch.randn(A * 10, n, generator=g).to(dev) for n in (3, 3, 1, 3, 4)]
+
+    def run(lo, hi):
+        m = ng.ScaffoldModel(hi - lo, md, dev)
+        m.load(anchor[lo:hi], offset[lo:hi], feat[lo:hi], scaling_log[lo:hi], mlp)
+        gen = ng.NeuralGaussians(m)
+        gen.forward(campos, pose7, None)
+        outs = [t.clone() for t in (gen.means3D, gen.colors, gen.opacity, gen.scales, gen.rotations)]
+        gen.backward(*[x[lo * 10:hi * 10].contiguous() for x in grads])
+        torch.cuda.synchronize()
+        return m, outs
+
+    big, ob = run(0, A)
+    s1, o1 = run(0, A1)
+    s2, o2 = run(A1, A)
+    for tb, t1, t2 in zip(ob, o1, o2):
+        assert torch.equal(tb, torch.cat([t1, t2], dim=0))
+    for name in ("anchor", "offset", "anchor_feat", "scaling"):
+        assert torch.equal(big.grad(name), torch.cat([s1.grad(name), s2.grad(name)], dim=0)), name
+    ref = s1.mlp_grads + s2.mlp_grads
+    assert float((big.mlp_grads - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
