@@ -82,3 +82,17 @@ def test_backward_is_linear_at_full_size():
         tol = 1e-4 * np.abs(want) + 1e-5 * np.abs(want).max()
         assert np.all(np.abs(g12[k] - want) <= tol), (k, float(np.abs(g12[k] - want).max()), float(np.abs(want).max()))
         assert np.isfinite(g12[k]).all()
+
+
+@pytest.mark.parametrize("workload", ["c2_1080p", "c2", "1080p_3m"])
+def test_full_size_parity_against_oracle(workload):
+    """BASELINE.json's configurations themselves (the headline: 500 k Gaussians, 1920x1080, R = 3.7 M; the largest: 3 M
+    Gaussians, R = 10.5 M) against the CPU oracle: integer/index outputs bit-exact, image and all gradients within the
+    stated tolerances.  The OpenMP oracle needs seconds per pass on the GPU box's host cores (the run bench.py times as
+    cpu_baseline)."""
+    from segs_slam_amd import scenes
+    from test_raster_gpu import run_parity
+    sc = scenes.make_config_scene(workload)
+    o, g = run_parity(sc, backward=True)
+    if workload == "c2_1080p":
+        assert o.R == 3744721 and int((g["radii"] > 0).sum()) == 356695      # the numbers quoted with every bench line
