@@ -209,6 +209,10 @@ def main():
                        "kernel_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
                        "radix_sort_ms": round(sum(per_step.get(k, 0.0) for k in sort_names), 4)},
         }
+        try:   # the tile kernels are reported in (pixel, Gaussian) pairs per second next to the byte figure
+            out["raster"].update(pair_rates(eng, cam, per_step))
+        except Exception as e:  # noqa: BLE001  (measurement garnish only; never fail the bench line over it)
+            out["raster"]["pairs_error"] = str(e)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc)
         if args.breakdown:
@@ -217,6 +221,29 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pair_rates(eng, cam, per_step):
+    """Upper bound sum_tiles len(tile) * 256 and exact count sum(n_contrib) of (pixel, Gaussian) pairs of the last forward,
+    and the two tile kernels' rates on the upper bound (what they iterate over before masks and early termination)."""
+    import ctypes as C
+    import torch
+    from segs_slam_amd import _capi
+    img = eng._img_r if getattr(eng, "_last_resident", False) else eng.img.tensor
+    tiles = ((cam.width + 15) // 16) * ((cam.height + 15) // 16)
+    ranges = torch.zeros((tiles, 2), dtype=torch.int32, device=eng.device)
+    ncontrib = torch.zeros((cam.height, cam.width), dtype=torch.int32, device=eng.device)
+    st = _capi.lib().segs_debug_unpack_image(C.c_void_p(img.data_ptr()), cam.width, cam.height, C.c_void_p(ranges.data_ptr()), None,
+                                             C.c_void_p(ncontrib.data_ptr()), C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream))
+    _capi.check(st, "segs_debug_unpack_image")
+    torch.cuda.synchronize()
+    upper = int((ranges[:, 1] - ranges[:, 0]).to(torch.int64).sum().item()) * 256
+    exact = int(ncontrib.to(torch.int64).sum().item())
+    out = {"pairs_upper_bound": upper, "pairs_exact_sum_n_contrib": exact}
+    for k in ("render_fwd_kernel", "render_bwd_kernel"):
+        if k in per_step and per_step[k] > 0:
+            out[k.replace("_kernel", "") + "_Gpairs_per_s"] = round(upper / (per_step[k] * 1e-3) / 1e9, 1)
+    return out
 
 
 def pmc_traffic(workload, kernel):
