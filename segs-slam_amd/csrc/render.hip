@@ -248,7 +248,7 @@ struct BwdLds {                  // 9088 B per wave -> 4 workgroups (16 waves) p
 template <bool USE_BG>
 __device__ __forceinline__ void pixel_role(BwdLds& L, int nb, int lane, float pxf, float pyf, uint32_t last_contributor,
                                            float dp0, float dp1, float dp2, float T_final, float bg_dot_dpixel, float& T,
-                                           float& acc0, float& acc1, float& acc2) {
+                                           float& accd) {
 #ifndef PIX_UNROLL
 #define PIX_UNROLL 2
 #endif
@@ -265,10 +265,13 @@ __device__ __forceinline__ void pixel_role(BwdLds& L, int nb, int lane, float px
     const float ae = fminf(0.99f, aw);   // alpha; 0 makes every update below a no-op
     const float rinv = fast_rcp(1.f - ae);
     T = T * rinv;                        // T / (1 - alpha)
-    const float d0 = q1.z - acc0, d1 = q1.w - acc1, d2 = q2.x - acc2;
-    float dL_dalpha = (d0 * dp0 + d1 * dp1 + d2 * dp2) * T;
+    // The colour accumulated behind this Gaussian enters only through its dot product with dL/dpixel, so ONE running
+    // scalar accd = sum_ch accum_ch * g_ch replaces the three accumulators of backward.cu:513-516:
+    //   sum_ch (c_ch - accum_ch) g_ch = c.g - accd;   accum' = accum + alpha (c - accum)  =>  accd' = accd + alpha (c.g - accd)
+    const float diff = (q1.z * dp0 + q1.w * dp1 + q2.x * dp2) - accd;
+    float dL_dalpha = diff * T;
     if (USE_BG) dL_dalpha += (-T_final * rinv) * bg_dot_dpixel;
-    acc0 += ae * d0; acc1 += ae * d1; acc2 += ae * d2;  // alpha*c + (1-alpha)*acc  (backward.cu:513-516)
+    accd += ae * diff;
     L.wt[sl][lane] = aw * dL_dalpha;     // = dL_dG * G
     L.at[sl][lane] = ae * T;             // = dchannel_dcolor
   }
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
   wave_last = __builtin_amdgcn_readfirstlane(wave_last);
   if (wave_last == 0u) return;
 
-  float T = T_final, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;  // acc = colour accumulated BEHIND the current Gaussian
+  float T = T_final, accd = 0.f;  // accd = (colour accumulated BEHIND the current Gaussian) . dL/dpixel
 
   // Gaussian-role constants
   const int gs = lane & 15, part = lane >> 4;
@@ -351,8 +354,8 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
       }
       wave_lds_fence();
       // ---------------- (1) pixel role
-      if (use_bg) pixel_role<true>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, acc0, acc1, acc2);
-      else pixel_role<false>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, acc0, acc1, acc2);
+      if (use_bg) pixel_role<true>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, accd);
+      else pixel_role<false>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, accd);
       wave_lds_fence();
       // ---------------- (2) Gaussian role: lane = (part, gs): slot gs, pixels part*16 .. part*16+15
       // Moments are taken about the quadrant pixel NEAREST to the Gaussian's centre (cx, cy in 0..7), not about the
