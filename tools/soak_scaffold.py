@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Soak run of the anchor-level mapper step with densification (run on the GPU box): tools/soak_scaffold.py [iters] [anchors]."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from segs_slam_amd import densify, neural_gaussians as ng, scenes  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+A = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+dev = torch.device("cuda:0")
+sc = scenes.make_config_scene("c2")
+cam = sc.camera
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+kfs, gts = [], []
+for k in range(8):                      # 8 keyframes on a small orbit, targets = a smooth pattern per keyframe
+    camk = scenes.make_config_scene("c2", keyframe=k).camera
+    kfs.append(ng.Keyframe(t(camk.world_view_transform), t(camk.full_proj_transform), t(camk.camera_center),
+                           torch.tensor([0.01 * k, 0.0, 0.0, 1.0, 0.0, 0.01 * k, 0.0], device=dev), camk.tanfovx, camk.tanfovy))
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, cam.height, device=dev), torch.linspace(0, 1, cam.width, device=dev), indexing="ij")
+    gts.append(torch.stack([0.5 + 0.4 * torch.sin(6 * xx + k), 0.5 + 0.4 * torch.cos(5 * yy), 0.3 + 0.2 * xx * yy]).contiguous())
+model = ng.synthetic_model(A, ng.ModelDims(), cam, dev, seed=1)
+step = ng.ScaffoldTrainerStep(model, cam.width, cam.height, scaling_reg_weight=0.01)
+dens = densify.AnchorDensifier(model, densify.DensifyParams(voxel_size=0.01, start_stat=100, update_from=300, update_interval=100,
+                                                            update_until=iters, densify_grad_threshold=0.0002))
+step.enable_densification(dens, seed=0)
+t0 = time.perf_counter()
+for it in range(1, iters + 1):
+    loss = step.training_once(kfs, gts)
+    if it % 100 == 0:
+        torch.cuda.synchronize()
+        l = float(loss)
+        assert np.isfinite(l), (it, l)
+        print(f"it {it:5d} loss {l:.5f} anchors {model.A:7d} capacity {model.capacity:7d} R {step.engine.R:8d} "
+              f"mem {torch.cuda.memory_allocated() / 2**20:7.0f} MiB  {1e3 * (time.perf_counter() - t0) / it:.3f} ms/it", flush=True)
+assert torch.isfinite(model.params).all()
+print("soak ok")
