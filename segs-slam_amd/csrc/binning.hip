@@ -97,9 +97,17 @@ __device__ __forceinline__ bool ellipse_hits_rect(float cx, float cy, float A, f
 // Inclusive offsets of tiles_touched in DEPTH order (one per sorted slot): block prefix from scan_block_sums_kernel
 // plus an in-workgroup scan.
 __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
-                                                              const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ incl) {
-  __shared__ uint32_t wave_tot[4];
+                                                              const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ incl,
+                                                              uint32_t* __restrict__ total_out) {
+  // Every workgroup sums the (unscanned) sums of the workgroups before it on its own -- P/256 values, a few loads per
+  // thread -- instead of a separate single-workgroup scan kernel between the two passes (one launch less).
+  __shared__ uint32_t wave_tot[4], red[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint32_t before = 0;
+  for (int b = tid; b < (int)blockIdx.x; b += 256) before += block_sums[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
+  if (lane == 0) red[wv] = before;
   const int slot = blockIdx.x * 256 + tid;
   uint32_t x = slot < P ? bin[order[slot]].tiles_touched : 0u;
 #pragma unroll
@@ -109,9 +117,10 @@ __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const BinIn
   }
   if (lane == 63) wave_tot[wv] = x;
   __syncthreads();
-  uint32_t base = block_offsets[blockIdx.x];
+  uint32_t base = red[0] + red[1] + red[2] + red[3];
   for (int w = 0; w < wv; w++) base += wave_tot[w];
   if (slot < P) incl[slot] = base + x;
+  if (total_out && blockIdx.x == gridDim.x - 1 && tid == 255) total_out[0] = base + x;   // R = inclusive total
 }
 
 // The emitter is parallel over OUTPUT slots, not over Gaussians: workgroup b owns instances [b*1024, (b+1)*1024) of the

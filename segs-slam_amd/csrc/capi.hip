@@ -182,14 +182,10 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2);
   }
   LAUNCH_TRY("ordered_block_sums_kernel");
-  { PROF(K_SCAN);
-  scan_block_sums_kernel<<<1, 1024, 0, st>>>(sums2, G.L.nblocks, G.block_sums() + (G.L.nblocks + 1), total_out);
-  }
-  LAUNCH_TRY("scan_block_sums_kernel");
   const int tpasses = (bit + 7) / 8;
   const int side = tpasses & 1;
   { PROF(K_SCAN);
-  ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2, G.offsets());
+  ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2, G.offsets(), total_out);
   }
   LAUNCH_TRY("ordered_offsets_kernel");
   { PROF(K_DUPLICATE);

@@ -46,7 +46,8 @@ __global__ void preprocess_bwd_kernel(
 __global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, const uint32_t* __restrict__ depth_range,
                                        uint32_t* __restrict__ total);
 __global__ void ordered_offsets_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
-                                       const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ incl);
+                                       const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ incl,
+                                       uint32_t* __restrict__ total_out);
 __global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
