@@ -293,7 +293,7 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
     if (rc) return rc;
   }
   { PROF(K_RENDER_FWD);
-  render_fwd_kernel<<<dim3(gx, gy), 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(),
+  render_fwd_kernel<<<gx * gy, 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(),
                                                   background, (float*)(img + IL.final_T), (uint32_t*)(img + IL.n_contrib), out_color);
   }
   LAUNCH_TRY("render_fwd_kernel");
@@ -333,7 +333,7 @@ int segs_rasterize_backward(int P, int D, int M, int R, const float* background,
   }
   if (R > 0) {
     { PROF(K_RENDER_BWD);
-    render_bwd_kernel<<<dim3(gx, gy), 256, 0, st>>>((const uint2*)(img + IL.ranges), (const uint32_t*)(bin + BL.vals[0]), width,
+    render_bwd_kernel<<<gx * gy, 256, 0, st>>>((const uint2*)(img + IL.ranges), (const uint32_t*)(bin + BL.vals[0]), width,
                                                     height, G.rec(), background, (const float*)(img + IL.final_T),
                                                     (const uint32_t*)(img + IL.n_contrib), dL_dpix, G.gacc());
     }
@@ -540,7 +540,7 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
   if (rc) return rc;
   // status[3] (overflow) and the host mirror are written by identify_tile_ranges_kernel at the end of run_binning
   { PROF(K_RENDER_FWD);
-  render_fwd_kernel<<<dim3(gx, gy), 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(), background,
+  render_fwd_kernel<<<gx * gy, 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(), background,
                                                   (float*)(img + IL.final_T), (uint32_t*)(img + IL.n_contrib), out_color);
   }
   LAUNCH_TRY("render_fwd_kernel");

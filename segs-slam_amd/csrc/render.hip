@@ -31,6 +31,17 @@ namespace segs {
 
 struct RecS { float x, y, a2, b2, c2, o, r, g, b, ca, cb, cc; };
 
+// XCD-aware workgroup -> tile mapping.  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so with
+// the identity mapping horizontally adjacent tiles -- which share most of their Gaussians -- land on 8 different L2s and
+// every record is fetched up to 8 times.  Here each group of 64 consecutive tiles is cut into 8 runs of 8 adjacent tiles,
+// one run per XCD: neighbours share an L2, while the work stays interleaved finely enough for load balance.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t wg, uint32_t num_tiles) {
+  const uint32_t full = num_tiles & ~63u;
+  if (wg >= full) return wg;                       // ragged tail: identity
+  const uint32_t xcd = wg & 7u, local = wg >> 3;   // local = index among this XCD's workgroups
+  return (local >> 3) * 64u + xcd * 8u + (local & 7u);
+}
+
 __device__ __forceinline__ RecS load_rec(const float* __restrict__ rec, uint32_t id) {
   const float4* p = reinterpret_cast<const float4*>(rec + (size_t)id * REC_DWORDS);
   const float4 q0 = p[0], q1 = p[1], q2 = p[2];
@@ -103,11 +114,13 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(
     const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color) {
   __shared__ float4 s_rec[4][64][FWD_REC / 4];
-  const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const uint32_t tiles_x = (W + TILE_X - 1) / TILE_X;
+  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t px = blockIdx.x * TILE_X + (wv & 1) * 8 + (lane & 7);
-  const uint32_t py = blockIdx.y * TILE_Y + (wv >> 1) * 8 + (lane >> 3);
+  const uint32_t px = tile_x * TILE_X + (wv & 1) * 8 + (lane & 7);
+  const uint32_t py = tile_y * TILE_Y + (wv >> 1) * 8 + (lane >> 3);
   const bool inside = px < (uint32_t)W && py < (uint32_t)H;
   const float pxf = (float)px, pyf = (float)py;
   const uint32_t qbit = 1u << (ID_BITS + wv);
@@ -282,11 +295,13 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
     const float* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ gacc) {
   __shared__ BwdLds lds_all[4];
-  const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const uint32_t tiles_x = (W + TILE_X - 1) / TILE_X;
+  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   BwdLds& L = lds_all[wv];
-  const uint32_t qx0 = blockIdx.x * TILE_X + (wv & 1) * 8, qy0 = blockIdx.y * TILE_Y + (wv >> 1) * 8;
+  const uint32_t qx0 = tile_x * TILE_X + (wv & 1) * 8, qy0 = tile_y * TILE_Y + (wv >> 1) * 8;
   const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const bool inside = px < (uint32_t)W && py < (uint32_t)H;
   const float pxf = (float)px, pyf = (float)py;

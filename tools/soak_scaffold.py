@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Soak run of the anchor-level mapper step with densification (run on the GPU box): tools/soak_scaffold.py [iters] [anchors]."""
+"""Soak run of the anchor-level mapper step with densification (run on the GPU box), SURVEY.md 8d config 3 in spirit:
+   tools/soak_scaffold.py [iters] [anchors] [densify_grad_threshold] [stop_at_anchors]
+A low threshold makes the map grow quickly (capacity growth, Adam-state extension, pruning all exercised)."""
 import os
 import sys
 import time
@@ -13,6 +15,8 @@ from segs_slam_amd import densify, neural_gaussians as ng, scenes  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 A = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+thr = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0002
+stop_at = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dev = torch.device("cuda:0")
 sc = scenes.make_config_scene("c2")
 cam = sc.camera
@@ -27,7 +31,7 @@ for k in range(8):                      # 8 keyframes on a small orbit, targets 
 model = ng.synthetic_model(A, ng.ModelDims(), cam, dev, seed=1)
 step = ng.ScaffoldTrainerStep(model, cam.width, cam.height, scaling_reg_weight=0.01)
 dens = densify.AnchorDensifier(model, densify.DensifyParams(voxel_size=0.01, start_stat=100, update_from=300, update_interval=100,
-                                                            update_until=iters, densify_grad_threshold=0.0002))
+                                                            update_until=iters, densify_grad_threshold=thr))
 step.enable_densification(dens, seed=0)
 t0 = time.perf_counter()
 for it in range(1, iters + 1):
@@ -38,5 +42,7 @@ for it in range(1, iters + 1):
         assert np.isfinite(l), (it, l)
         print(f"it {it:5d} loss {l:.5f} anchors {model.A:7d} capacity {model.capacity:7d} R {step.engine.R:8d} "
               f"mem {torch.cuda.memory_allocated() / 2**20:7.0f} MiB  {1e3 * (time.perf_counter() - t0) / it:.3f} ms/it", flush=True)
+        if stop_at and model.A >= stop_at:
+            break
 assert torch.isfinite(model.params).all()
 print("soak ok")
