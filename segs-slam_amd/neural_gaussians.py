@@ -407,6 +407,10 @@ class ScaffoldTrainerStep:
                                    kf.campos, kf.tanfovx, kf.tanfovy)
 
     def _forward_backward(self, kf: Keyframe, gt: torch.Tensor):
+        if self.model.A == 0:
+            # every anchor was pruned: the reference's rasterizer short-circuits P == 0 to a zero image
+            # (src/rasterize_points.cu:81) and nothing receives a gradient
+            return self.loss_fn(torch.zeros(3, self.H, self.W, device=self.model.device), gt)[0]
         image = self.render(kf)
         loss, dL = self.loss_fn(image, gt)
         if self.freq_reg is not None:
@@ -426,7 +430,7 @@ class ScaffoldTrainerStep:
         lrs = self.learning_rates(self.iteration)
         k = self.keyframe_for(self.iteration - 1, len(keyframes))
         loss = self._forward_backward(keyframes[k], gt_images[k])
-        if self.world > 1 or self.densifier is not None:
+        if (self.world > 1 or self.densifier is not None) and self.model.A > 0:
             # ranks must agree on whether the step counts, and the densify statistics must not see an invalid pass:
             # resolve the overflow word on the host (one synchronisation) and redo the pass through the re-sizing path
             if not self.engine.check(raise_on_overflow=False):
@@ -436,7 +440,7 @@ class ScaffoldTrainerStep:
             dist.all_reduce(self.model.grads, group=self.pg)
         adjusted = False
         d = self.densifier
-        if d is not None and d.p.start_stat < self.iteration < d.p.update_until:      # gaussian_mapper.cpp:961-968
+        if d is not None and self.model.A > 0 and d.p.start_stat < self.iteration < d.p.update_until:  # gaussian_mapper.cpp:961-968
             d.training_statis(self.neural, self.visible_radii, self.engine.radii, self.engine.dL_dmean2D)
             if self.iteration > d.p.update_from and self.iteration % d.p.update_interval == 0:
                 d.adjust_anchor(generator=self.densify_generator)

@@ -140,3 +140,27 @@ def test_trainer_keeps_running_through_densification():
         assert np.isfinite(float(loss))
     assert sizes[-1] != 3000, sizes[::5]      # the map changed size and the step kept running
     assert step.mlp_steps == 31 and step.anchor_steps == 28   # anchor tensors skipped by Adam at the 3 densify iterations
+
+
+def test_trainer_survives_a_map_pruned_to_nothing():
+    """All anchors pruned: the reference's rasterizer short-circuits P == 0 to a zero image (src/rasterize_points.cu:81);
+    the step must keep running (loss against the zero image, no gradient) rather than fault."""
+    from segs_slam_amd import densify, neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    cam = scenes.make_camera(96, 64, 90.0, 90.0, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+    model = ng.synthetic_model(200, ng.ModelDims(), cam, dev, seed=5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    step = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
+    dens = densify.AnchorDensifier(model, densify.DensifyParams(voxel_size=0.01, start_stat=2, update_from=5, update_interval=10,
+                                                                update_until=1000))
+    step.enable_densification(dens, seed=0)
+    gt = torch.full((3, cam.height, cam.width), 0.4, device=dev)
+    step.training_once([kf], [gt])
+    dens.prune_anchor(torch.ones(model.A, dtype=torch.bool, device=dev))
+    assert model.A == 0
+    for _ in range(12):                      # crosses a densify iteration with A == 0
+        loss = step.training_once([kf], [gt])
+    torch.cuda.synchronize()
+    assert abs(float(loss) - (0.8 * 0.4 + 0.2 * 1.0)) < 0.05      # L1 = 0.4 against zeros, SSIM ~ 0
