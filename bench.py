@@ -60,8 +60,16 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank path)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="all ranks use cuda:0 (with --backend gloo): exercises the N > 1 code path on a one-GPU box; not a measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the collectives even with one rank (exercises the RCCL calls on a one-GPU box)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: libraries that print there (RCCL writes its version banner to stdout when the
+    # first communicator is created) are sent to stderr for the whole run, the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -81,8 +89,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -119,11 +129,11 @@ def main():
             return
         eng.forward(bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy)
         eng.backward(dL)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(eng.grads_flat)  # sum of per-keyframe parameter gradients over xGMI (RCCL)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -158,7 +168,7 @@ def main():
         elapsed = time.perf_counter() - t0
     if graph is not None:
         prof_dom.result = {dominant: breakdown[dominant]}
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -218,8 +228,8 @@ def main():
         if args.breakdown:
             for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]):
                 print(f"  {k:32s} {v:8.4f} ms/step", file=sys.stderr)
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), file=json_out, flush=True)
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -32,3 +32,16 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_stdout_stays_one_json_line_with_rccl_initialised():
+    """RCCL prints a version banner to stdout when its first communicator is created; the driver parses stdout."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c1", "--steps", "3", "--warmup", "1",
+                          "--force-dist", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
