@@ -305,7 +305,7 @@ class ScaffoldTrainerStep:
         self.neural = NeuralGaussians(model)
         self.engine = RasterEngine(self.neural.P_capacity, width, height, dev, resident=True, skip_nonpositive_opacity=True)
         self.loss_fn = FusedL1SSIM(height, width, dev, self.opt.lambda_dssim)
-        self.bg = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.bg = torch.zeros(3, dtype=torch.float32, device=dev)      # Model.white_background: set_background(True)
         self.visible_radii = torch.zeros(model.capacity, dtype=torch.int32, device=dev)
         self.spatial_lr_scale = float(spatial_lr_scale)
         self.pg = process_group
@@ -318,6 +318,15 @@ class ScaffoldTrainerStep:
         self.mlp_steps = 0
         self.densifier = None            # densify.AnchorDensifier, see enable_densification()
         self.densify_generator = None
+        # the mapper (not the trainer) multiplies rendering and target by mask_rgb = (gt != 0).any(-1): gt is (3,H,W), so this
+        # is a per-(channel, row) mask of shape (3,H,1) that blanks rows whose target is entirely zero
+        # (src/gaussian_mapper.cpp:917-922).  Off by default (trainer semantics); mapper_config.make_mapper_step turns it on.
+        self.row_mask = False
+        self._row_mask_cache = {}
+
+    def set_background(self, white: bool):
+        """bg_color of GaussianMapper's constructor (src/gaussian_mapper.cpp:61-67)."""
+        self.bg.fill_(1.0 if white else 0.0)
 
     def enable_frequency_regularization(self, lambda_high: float = 0.01, lambda_low: float = 0.0, scales=(1.0, 0.5, 0.25),
                                         start: int = 5000, until: int = 25500, multi_resolution: bool = True):
@@ -412,15 +421,35 @@ class ScaffoldTrainerStep:
             # (src/rasterize_points.cu:81) and nothing receives a gradient
             return self.loss_fn(torch.zeros(3, self.H, self.W, device=self.model.device), gt)[0]
         image = self.render(kf)
+        mask = None
+        if self.row_mask:
+            mask, gt = self._row_mask_of(gt)
+            if mask is not None:
+                image = image * mask
         loss, dL = self.loss_fn(image, gt)
         if self.freq_reg is not None:
             floss, fg = self._freq_grad(image, gt)
             if fg is not None:
                 dL = dL + fg
                 loss = loss + floss
+        if mask is not None:
+            dL = dL * mask
         g = self.engine.backward(dL)
         self.neural.backward(g["means3D"], g["colors"], g["opacity"], g["scales"], g["rotations"], self.scaling_reg_weight)
         return loss
+
+    def _row_mask_of(self, gt: torch.Tensor):
+        """(mask or None, masked target).  Evaluated once per target tensor (one host read); targets without an all-zero
+        row -- the normal case -- take the unmasked fast path."""
+        key = (gt.data_ptr(), gt._version)
+        hit = self._row_mask_cache.get(key)
+        if hit is None:
+            mask = (gt != 0).any(-1).to(torch.float32).unsqueeze(-1)
+            hit = (None, gt) if bool(mask.all()) else (mask, (gt * mask).contiguous())
+            if len(self._row_mask_cache) > 4096:
+                self._row_mask_cache.clear()
+            self._row_mask_cache[key] = hit
+        return hit
 
     def keyframe_for(self, step: int, n_keyframes: int) -> int:
         return (step * self.world + self.rank) % n_keyframes
