@@ -16,123 +16,223 @@
 #include "../../include/segs_train.h"
 
 namespace {
-constexpr int TS = 16;          // output tile
+// Tiling (both kernels): a 256-thread workgroup produces a 32 x 32 output tile from a 42 x 42 input tile (halo 5).
+//  * horizontal pass: a thread owns one input row and a PAIR of adjacent output columns, reads its 12 inputs as six
+//    ds_read_b64 (16 lanes cover one contiguous 128-B row segment -> no bank conflicts) and forms the products once per
+//    input, not once per tap;
+//  * vertical pass: a thread owns one column and FOUR adjacent output rows, so the 14 rows it needs are read once for
+//    4 x 11 taps (half-waves read contiguous 128-B rows -> no bank conflicts).
+// The first version (16 x 16 tiles, one output per thread, odd LDS pitches) spent 43 % of its LDS cycles in bank
+// conflicts and 2.3x the VALU instructions on index arithmetic and per-tap products: 45 + 35 us at 1200x680.
+// Small images (640x480: 900 tiles of 32 x 32 on 256 CUs) use 32 x 16 tiles instead (template parameter TY).
+constexpr int TX = 32;              // output tile width; height TY = 32 or 16
 constexpr int HALO = 5;
-constexpr int TW = TS + 2 * HALO;  // 26
+constexpr int IW = TX + 2 * HALO;   // 42 input columns
+constexpr int SP = 44;              // input pitch in floats: even (b64 reads), 44 mod 32 = 12 keeps row pairs apart
 struct Win { float g[11]; };
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  const int tid = threadIdx.y * TS + threadIdx.x;
+  const int tid = threadIdx.x;
   if ((tid & 63) == 0) red[tid >> 6] = v;
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// Stage the IH x IW windows of N planes at (y0 - HALO, x0 - HALO) into dst[n][IH][SP], zero outside the image.  All
+// N * 12 loads of a thread are issued before the first LDS store: a rolled loop here costs one global round trip per
+// iteration (18 in the backward), which at 3 workgroups per CU was most of the kernel time.
+template <int N, int IH>
+__device__ __forceinline__ void load_tiles(float (*dst)[IH][SP], const float* const (&src)[N], int H, int W, int x0, int y0) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  constexpr int RI = (IH + 7) / 8;   // 6 row rounds
+  float v[N][RI][2];
+#pragma unroll
+  for (int i = 0; i < RI; i++) {
+    const int r = ty + 8 * i;
+    const int gy = y0 + r - HALO;
+    const bool row_in = r < IH && gy >= 0 && gy < H;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int c = tx + 32 * j;
+      const int gx = x0 + c - HALO;
+      const bool in = row_in && c < IW && gx >= 0 && gx < W;
+      const size_t o = in ? (size_t)gy * W + gx : 0;
+#pragma unroll
+      for (int n = 0; n < N; n++) { const float t = src[n][o]; v[n][i][j] = in ? t : 0.f; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RI; i++) {
+    const int r = ty + 8 * i;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int c = tx + 32 * j;
+      if (r < IH && c < IW) {
+#pragma unroll
+        for (int n = 0; n < N; n++) dst[n][r][c] = v[n][i][j];
+      }
+    }
+  }
+}
+
+template <int TY>
 __global__ void __launch_bounds__(256) ssim_fwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
                                                        Win win, float* __restrict__ Dm, float* __restrict__ D11,
                                                        float* __restrict__ D12, float2* __restrict__ partial /* per workgroup: (sum|d|, sum S) */) {
-  __shared__ float s1[TW][TW + 1], s2[TW][TW + 1];
-  __shared__ float h[5][TW][TS + 1];
+  constexpr int IH = TY + 2 * HALO;   // input rows
+  constexpr int RPT = TY / 8;         // output rows per thread in the vertical pass (8 thread rows of 32 columns)
+  __shared__ __attribute__((aligned(16))) float sin[2][IH][SP];
+  float (*s1)[SP] = sin[0];
+  float (*s2)[SP] = sin[1];
+  __shared__ __attribute__((aligned(16))) float h[5][IH][TX];
   __shared__ float red[4];
   const int ch = blockIdx.z;
   const size_t plane = (size_t)ch * H * W;
-  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
-  const int tid = threadIdx.y * TS + threadIdx.x;
-  for (int i = tid; i < TW * TW; i += 256) {
-    const int ly = i / TW, lx = i - ly * TW;
-    const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    s1[ly][lx] = in ? img1[plane + (size_t)gy * W + gx] : 0.f;
-    s2[ly][lx] = in ? img2[plane + (size_t)gy * W + gx] : 0.f;
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int tid = threadIdx.x;
+  {
+    const float* const src[2] = {img1 + plane, img2 + plane};
+    load_tiles<2, IH>(sin, src, H, W, x0, y0);
   }
   __syncthreads();
-  for (int i = tid; i < TW * TS; i += 256) {  // horizontal pass: 26 rows x 16 columns
-    const int ly = i / TS, lx = i - ly * TS;
-    float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+  {  // horizontal pass
+    const int p = tid & 15;
+    for (int r = tid >> 4; r < IH; r += 16) {
+      float u[12], v[12];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float u = s1[ly][lx + k], v = s2[ly][lx + k], g = win.g[k];
-      a += g * u; b += g * v; aa += g * (u * u); bb += g * (v * v); ab += g * (u * v);
+      for (int k = 0; k < 6; k++) {
+        const float2 a = *reinterpret_cast<const float2*>(&s1[r][2 * p + 2 * k]);
+        const float2 b = *reinterpret_cast<const float2*>(&s2[r][2 * p + 2 * k]);
+        u[2 * k] = a.x; u[2 * k + 1] = a.y; v[2 * k] = b.x; v[2 * k + 1] = b.y;
+      }
+      float uu[12], vv[12], uv[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) { uu[k] = u[k] * u[k]; vv[k] = v[k] * v[k]; uv[k] = u[k] * v[k]; }
+      float o[5][2];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+          const float g = win.g[k];
+          a += g * u[e + k]; b += g * v[e + k]; aa += g * uu[e + k]; bb += g * vv[e + k]; ab += g * uv[e + k];
+        }
+        o[0][e] = a; o[1][e] = b; o[2][e] = aa; o[3][e] = bb; o[4][e] = ab;
+      }
+#pragma unroll
+      for (int m = 0; m < 5; m++) *reinterpret_cast<float2*>(&h[m][r][2 * p]) = make_float2(o[m][0], o[m][1]);
     }
-    h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = aa; h[3][ly][lx] = bb; h[4][ly][lx] = ab;
   }
   __syncthreads();
-  const int lx = threadIdx.x, ly = threadIdx.y;
-  float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  const int lx = tid & 31, ly = (tid >> 5) * RPT;
+  float acc[5][RPT];
 #pragma unroll
-  for (int k = 0; k < 11; k++) {
-    const float g = win.g[k];
-    mu1 += g * h[0][ly + k][lx]; mu2 += g * h[1][ly + k][lx];
-    e11 += g * h[2][ly + k][lx]; e22 += g * h[3][ly + k][lx]; e12 += g * h[4][ly + k][lx];
+  for (int m = 0; m < 5; m++) {
+    float col[RPT + 10];
+#pragma unroll
+    for (int j = 0; j < RPT + 10; j++) col[j] = h[m][ly + j][lx];
+#pragma unroll
+    for (int e = 0; e < RPT; e++) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) a += win.g[k] * col[e + k];
+      acc[m][e] = a;
+    }
   }
-  const int gx = x0 + lx, gy = y0 + ly;
-  float l1 = 0.f, S = 0.f;
-  if (gx < W && gy < H) {
-    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-    const float s11 = e11 - mu1_sq, s22 = e22 - mu2_sq, s12 = e12 - mu12;
-    const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s11 + s22 + C2;
-    const float inv = 1.f / (B1 * B2);
-    S = A1 * A2 * inv;
-    const float d11 = -S / B2;                 // dS/ds11 = -(A1 A2)/(B1 B2^2)
-    const float d12 = 2.f * A1 * inv;          // dS/ds12
-    const float dmu = 2.f * mu2 * A2 * inv - 2.f * mu1 * S / B1 - 2.f * mu1 * d11 - mu2 * d12;
-    const size_t o = plane + (size_t)gy * W + gx;
-    Dm[o] = dmu; D11[o] = d11; D12[o] = d12;
-    l1 = fabsf(s1[ly + HALO][lx + HALO] - s2[ly + HALO][lx + HALO]);
+  const int gx = x0 + lx;
+  float l1 = 0.f, Ssum = 0.f;
+#pragma unroll
+  for (int e = 0; e < RPT; e++) {
+    const int gy = y0 + ly + e;
+    if (gx < W && gy < H) {
+      const float mu1 = acc[0][e], mu2 = acc[1][e], e11 = acc[2][e], e22 = acc[3][e], e12 = acc[4][e];
+      const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+      const float s11 = e11 - mu1_sq, s22 = e22 - mu2_sq, s12 = e12 - mu12;
+      const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s11 + s22 + C2;
+      const float inv = 1.f / (B1 * B2);
+      const float S = A1 * A2 * inv;
+      const float d11 = -S / B2;                 // dS/ds11 = -(A1 A2)/(B1 B2^2)
+      const float d12 = 2.f * A1 * inv;          // dS/ds12
+      const float dmu = 2.f * mu2 * A2 * inv - 2.f * mu1 * S / B1 - 2.f * mu1 * d11 - mu2 * d12;
+      const size_t o = plane + (size_t)gy * W + gx;
+      Dm[o] = dmu; D11[o] = d11; D12[o] = d12;
+      Ssum += S;
+      l1 += fabsf(s1[ly + e + HALO][lx + HALO] - s2[ly + e + HALO][lx + HALO]);
+    }
   }
   const float t1 = block_sum(l1, red);
   __syncthreads();
-  const float t2 = block_sum(S, red);
+  const float t2 = block_sum(Ssum, red);
   // one slot per workgroup (a same-address float atomic from ~10^4 workgroups serialises: 0.25 ms at 1200x680)
   if (tid == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_float2(t1, t2);
 }
 
+template <int TY>
 __global__ void __launch_bounds__(256) ssim_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
                                                        Win win, const float* __restrict__ Dm, const float* __restrict__ D11,
                                                        const float* __restrict__ D12, float w_l1, float w_ssim,
                                                        float* __restrict__ dL) {
-  __shared__ float s[3][TW][TW + 1];
-  __shared__ float h[3][TW][TS + 1];
+  constexpr int IH = TY + 2 * HALO;
+  constexpr int RPT = TY / 8;
+  __shared__ __attribute__((aligned(16))) float s[3][IH][SP];
+  __shared__ __attribute__((aligned(16))) float h[3][IH][TX];
   const int ch = blockIdx.z;
   const size_t plane = (size_t)ch * H * W;
-  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
-  const int tid = threadIdx.y * TS + threadIdx.x;
-  for (int i = tid; i < TW * TW; i += 256) {
-    const int ly = i / TW, lx = i - ly * TW;
-    const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const size_t o = plane + (size_t)gy * W + gx;
-    s[0][ly][lx] = in ? Dm[o] : 0.f; s[1][ly][lx] = in ? D11[o] : 0.f; s[2][ly][lx] = in ? D12[o] : 0.f;
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int tid = threadIdx.x;
+  {
+    const float* const src[3] = {Dm + plane, D11 + plane, D12 + plane};
+    load_tiles<3, IH>(s, src, H, W, x0, y0);
   }
   __syncthreads();
-  for (int i = tid; i < TW * TS; i += 256) {
-    const int ly = i / TS, lx = i - ly * TS;
-    float a = 0.f, b = 0.f, c = 0.f;
+  {
+    const int p = tid & 15;
+    for (int r = tid >> 4; r < IH; r += 16) {
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float g = win.g[k];
-      a += g * s[0][ly][lx + k]; b += g * s[1][ly][lx + k]; c += g * s[2][ly][lx + k];
+      for (int m = 0; m < 3; m++) {
+        float u[12];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const float2 a = *reinterpret_cast<const float2*>(&s[m][r][2 * p + 2 * k]);
+          u[2 * k] = a.x; u[2 * k + 1] = a.y;
+        }
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) { o0 += win.g[k] * u[k]; o1 += win.g[k] * u[k + 1]; }
+        *reinterpret_cast<float2*>(&h[m][r][2 * p]) = make_float2(o0, o1);
+      }
     }
-    h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = c;
   }
   __syncthreads();
-  const int lx = threadIdx.x, ly = threadIdx.y;
-  float a = 0.f, b = 0.f, c = 0.f;
+  const int lx = tid & 31, ly = (tid >> 5) * RPT;
+  float acc[3][RPT];
 #pragma unroll
-  for (int k = 0; k < 11; k++) {
-    const float g = win.g[k];
-    a += g * h[0][ly + k][lx]; b += g * h[1][ly + k][lx]; c += g * h[2][ly + k][lx];
+  for (int m = 0; m < 3; m++) {
+    float col[RPT + 10];
+#pragma unroll
+    for (int j = 0; j < RPT + 10; j++) col[j] = h[m][ly + j][lx];
+#pragma unroll
+    for (int e = 0; e < RPT; e++) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) a += win.g[k] * col[e + k];
+      acc[m][e] = a;
+    }
   }
-  const int gx = x0 + lx, gy = y0 + ly;
-  if (gx < W && gy < H) {
-    const size_t o = plane + (size_t)gy * W + gx;
-    const float u = img1[o], v = img2[o];
-    const float d = u - v;
-    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);  // torch: d|x|/dx = sign(x), 0 at 0
-    dL[o] = w_l1 * sgn - w_ssim * (a + 2.f * u * b + v * c);
+  const int gx = x0 + lx;
+#pragma unroll
+  for (int e = 0; e < RPT; e++) {
+    const int gy = y0 + ly + e;
+    if (gx < W && gy < H) {
+      const size_t o = plane + (size_t)gy * W + gx;
+      const float u = img1[o], v = img2[o];
+      const float d = u - v;
+      const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);  // torch: d|x|/dx = sign(x), 0 at 0
+      dL[o] = w_l1 * sgn - w_ssim * (acc[0][e] + 2.f * u * acc[1][e] + v * acc[2][e]);
+    }
   }
 }
 
@@ -158,8 +258,11 @@ __global__ void __launch_bounds__(1024) finish_loss_kernel(const float2* __restr
 
 extern "C" {
 
+static int tile_rows(int H, int W) {   // 32-row tiles once they fill the chip about twice over
+  return (size_t)3 * ((W + TX - 1) / TX) * ((H + 31) / 32) >= 1536 ? 32 : 16;
+}
 static size_t partial_bytes(int H, int W) {
-  const size_t nblk = (size_t)3 * ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
+  const size_t nblk = (size_t)3 * ((W + TX - 1) / TX) * ((H + 15) / 16);   // sized for the smaller tile
   return (nblk * sizeof(float2) + 255) & ~(size_t)255;
 }
 size_t segs_l1_ssim_temp_bytes(int H, int W) { return (size_t)3 * 3 * H * W * sizeof(float) + partial_bytes(H, W); }
@@ -181,11 +284,14 @@ int segs_l1_ssim_loss(const float* img1, const float* img2, int H, int W, float 
   float* Dm = reinterpret_cast<float*>(temp + partial_bytes(H, W));
   float* D11 = Dm + plane3;
   float* D12 = D11 + plane3;
-  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, 3), block(TS, TS);
-  ssim_fwd_kernel<<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, partial);
+  const int ty = tile_rows(H, W);
+  const dim3 grid((W + TX - 1) / TX, (H + ty - 1) / ty, 3), block(256);
+  if (ty == 32) ssim_fwd_kernel<32><<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, partial);
+  else ssim_fwd_kernel<16><<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, partial);
   const float inv_n = 1.0f / (float)plane3;
   finish_loss_kernel<<<1, 1024, 0, st>>>(partial, (int)(grid.x * grid.y * grid.z), inv_n, lambda_dssim, loss_out);
-  ssim_bwd_kernel<<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, (1.f - lambda_dssim) * inv_n, lambda_dssim * inv_n, dL_dimg1);
+  if (ty == 32) ssim_bwd_kernel<32><<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, (1.f - lambda_dssim) * inv_n, lambda_dssim * inv_n, dL_dimg1);
+  else ssim_bwd_kernel<16><<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, (1.f - lambda_dssim) * inv_n, lambda_dssim * inv_n, dL_dimg1);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }

@@ -158,7 +158,11 @@ __device__ __forceinline__ int out_row(int tile, int h, int r) {
 // Built once per forward call by one small kernel into the caller's scratch (global), then copied into LDS by every
 // workgroup with coalesced float4 loads (gathering the images per workgroup cost 25-45 us of dependent loads).
 __global__ void __launch_bounds__(256) pack_tables_kernel(Layout L, const float* __restrict__ P, const float* __restrict__ pose7,
-                                                          float* __restrict__ img, Small* __restrict__ Sg) {
+                                                          float* __restrict__ img, Small* __restrict__ Sg,
+                                                          uint32_t* __restrict__ count, float* __restrict__ reg_sum) {
+  // first kernel of the forward: also clears the two counters and the regulariser sum (a hipMemsetAsync of 8 bytes is a
+  // 5 us kernel of its own)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { count[0] = 0u; count[1] = 0u; *reg_sum = 0.f; }
   __shared__ float app[MAX_APP];
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int a = tid; a < MAX_APP; a += nt) {
@@ -859,8 +863,9 @@ __global__ void __launch_bounds__(64) appearance_finish_kernel(Layout L, const f
   }
 }
 
-__global__ void reg_finish_kernel(const uint32_t* count, const float* reg_sum, float w, float* out) {
+__global__ void reg_finish_kernel(const uint32_t* count, float* reg_sum, float w, float* out) {
   *out = w * (*reg_sum) / (float)max(count[1], 1u);   // reg_weight * mean(prod(scaling))
+  *reg_sum = 0.f;                                      // a second backward on the same forward state starts from zero again
 }
 
 WJobs make_jobs(const Layout& L) {
@@ -909,15 +914,14 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
     return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   Temp T;
   temp_carve(A, L.total, temp, &T);
-  hipError_t e = hipMemsetAsync(T.count, 0, 2 * sizeof(uint32_t), st);   // [0] visible anchors, [1] kept candidates
-  if (e != hipSuccess) return segs::set_hip_error(e, __func__);
+  static_assert(N_IMG_BWD == 262 && sizeof(Small) <= 8192, "temp_carve sizes");
+  // T.count: [0] visible anchors, [1] kept candidates; cleared (with the regulariser sum) by pack_tables_kernel
+  pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small, T.count, T.gsum + L.total + 8);
   const int nb = (A + 255) / 256;
   compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity);
-  static_assert(N_IMG_BWD == 262 && sizeof(Small) <= 8192, "temp_carve sizes");
-  pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small);
   neural_fwd_kernel<<<NEURAL_GRID, 256, N_IMG_FWD * 64 * sizeof(float) + sizeof(Small), st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
                                         camera_center, means3D, colors, opacity, scales, rotations, neural_opacity, T.count + 1);
-  e = hipGetLastError();
+  const hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }
 
@@ -943,14 +947,13 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
   if (attr_rc != hipSuccess) return segs::set_hip_error(attr_rc, __func__);
-  {
-    const hipError_t me = hipMemsetAsync(T.gsum + L.total + 8, 0, sizeof(float), st);
-    if (me != hipSuccess) return segs::set_hip_error(me, __func__);
-  }
+  // the regulariser sum was cleared by the forward (pack_tables_kernel) and is cleared again by reg_finish_kernel; it is
+  // only accumulated when somebody reads it
+  float* reg_sum = scaling_reg_out ? T.gsum + L.total + 8 : nullptr;
   neural_bwd_kernel<<<NEURAL_GRID, 256, bwd_lds, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
                                         camera_center, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor,
-                                        dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, scaling_reg_weight, T.gsum + L.total + 8);
-  if (scaling_reg_out) reg_finish_kernel<<<1, 1, 0, st>>>(T.count, T.gsum + L.total + 8, scaling_reg_weight, scaling_reg_out);
+                                        dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, scaling_reg_weight, reg_sum);
+  if (scaling_reg_out) reg_finish_kernel<<<1, 1, 0, st>>>(T.count, reg_sum, scaling_reg_weight, scaling_reg_out);
   const WJobs J = make_jobs(L);
   wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), 64, 0, st>>>(J, T.count, T.rows, T.partial);
   wgrad_reduce_kernel<<<dim3((37 * 72 + 15) / 16, WG_JOBS), 256, 0, st>>>(J, T.partial, T.gsum, dL_dmlp_params);

@@ -1,8 +1,10 @@
 """Keyframe-parallel training of the anchor-level step rehearsed on ONE GPU: two processes (gloo, both on
 cuda:0) hold identical replicas, each renders its own keyframe, the flat gradient bucket is all-reduced and the fused
-Adam applies the mean.  Checks: replicas stay bit-identical; the result equals a single process that accumulates both
-keyframes' gradients and steps once with grad_scale = 1/2 (float atomics in the raster backward sum in arbitrary order
--> tolerance, not bits).  The product path uses backend "nccl" (RCCL) with one GPU per rank."""
+Adam applies the mean.  Checks: replicas stay bit-identical; the all-reduced gradient of the first step equals the sum of
+the two keyframes' gradients accumulated by a single process (parity at gradient level; float atomics in the
+raster backward sum in arbitrary order -> 1e-4 relative, not bits); the parameters after two steps agree except where
+Adam (eps 1e-15) turns a gradient that is itself rounding noise into a full-size step.  The product path uses backend
+"nccl" (RCCL) with one GPU per rank."""
 import os
 import tempfile
 
@@ -36,6 +38,13 @@ def _worker(rank, world, port, outdir):
     model = ng.synthetic_model(3000, ng.ModelDims(), kfs[0][0], dev, seed=7)
     step = ng.ScaffoldTrainerStep(model, 320, 240)
     gts = [torch.full((3, 240, 320), 0.3 + 0.2 * k, device=dev) for k in range(2)]
+    # the first step's exchanged gradient, as training_once forms it (the optimizer zeroes the bucket afterwards)
+    step._forward_backward(kfs[rank][1], gts[rank])
+    dist.all_reduce(model.grads)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(os.path.join(outdir, "grads_step1.npy"), model.grads.cpu().numpy())
+    model.grads.zero_()
     for _ in range(2):
         step.training_once([k for _, k in kfs], gts)       # rank r takes keyframe (it * world + r) % 2 = r
     torch.cuda.synchronize()
@@ -49,6 +58,7 @@ def test_two_rank_scaffold_step_matches_single_process_mean_gradient():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, 29533, d), nprocs=2, join=True)
         p0, p1 = np.load(os.path.join(d, "params_0.npy")), np.load(os.path.join(d, "params_1.npy"))
+        g_dp = np.load(os.path.join(d, "grads_step1.npy"))
     assert np.array_equal(p0, p1), "replicas diverged"
     # single process: both keyframes' gradients accumulated, one Adam step with the mean
     dev = torch.device("cuda:0")
@@ -59,6 +69,10 @@ def test_two_rank_scaffold_step_matches_single_process_mean_gradient():
     for it in range(2):
         for k in range(2):
             step._forward_backward(kfs[k][1], gts[k])       # gradients accumulate in model.grads
+        if it == 0:
+            g_one = model.grads.cpu().numpy()
+            tol = 1e-4 * np.abs(g_one) + 1e-5 * np.abs(g_one).max()
+            assert np.all(np.abs(g_dp - g_one) <= tol), float(np.abs(g_dp - g_one).max())
         step.world = 2                                       # grad_scale = 1/2
         step.iteration += 1
         groups = model.adam_groups(step.learning_rates(step.iteration))
@@ -68,4 +82,6 @@ def test_two_rank_scaffold_step_matches_single_process_mean_gradient():
     torch.cuda.synchronize()
     ref = model.params.cpu().numpy()
     scale = np.abs(ref).max()
-    assert np.abs(p0 - ref).max() <= 2e-5 * scale, float(np.abs(p0 - ref).max())
+    off = np.abs(p0 - ref) > 2e-5 * scale
+    assert off.mean() < 1e-3, (float(off.mean()), float(np.abs(p0 - ref).max()))
+    assert np.abs(p0 - ref).max() <= 4 * 0.08, float(np.abs(p0 - ref).max())     # two steps of at most lr each, both ways
