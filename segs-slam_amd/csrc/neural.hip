@@ -840,26 +840,38 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WJobs jobs, const flo
 // Appearance embedding: appearance_feat = Wa pose + ba is the same for every anchor and enters the colour MLP's first
 // layer linearly, so with g = dL/d(colour hidden pre-activation bias) (already reduced into gsum):
 //   dW1k[j][kapp + a] = g[j] app[a];   dapp[a] = sum_j W1k[j][kapp + a] g[j];   dWa[a][q] = dapp[a] pose[q];  dba = dapp.
-__global__ void __launch_bounds__(64) appearance_finish_kernel(Layout L, const float* __restrict__ params,
-                                                               const float* __restrict__ pose7, const float* __restrict__ gsum,
-                                                               float* __restrict__ dparams) {
-  __shared__ float app[MAX_APP], g[FD];
-  const int a = threadIdx.x;
-  if (a < FD) g[a] = gsum[L.b1[2] + a];
-  if (a < L.app) {
-    float s = params[L.ab + a];
-    for (int q = 0; q < 7; q++) s += params[L.aw + a * 7 + q] * pose7[q];
-    app[a] = s;
+// One 1024-thread workgroup, one (hidden j, embedding a) product per thread and round: the first version walked the 32
+// read-modify-writes of a column in one thread (11.6 us of dependent global round trips).  The regulariser's final
+// division rides along when the caller asked for it (reg_out != nullptr), saving reg_finish_kernel's launch.
+__global__ void __launch_bounds__(1024) appearance_finish_kernel(Layout L, const float* __restrict__ params,
+                                                                 const float* __restrict__ pose7, const float* __restrict__ gsum,
+                                                                 float* __restrict__ dparams, const uint32_t* __restrict__ count,
+                                                                 float* __restrict__ reg_sum, float reg_w, float* __restrict__ reg_out) {
+  __shared__ float app[MAX_APP], g[FD], part[FD][MAX_APP + 1];
+  const int tid = threadIdx.x;
+  if (tid == 0 && reg_out != nullptr) {
+    *reg_out = reg_w * (*reg_sum) / (float)max(count[1], 1u);   // reg_weight * mean(prod(scaling))
+    *reg_sum = 0.f;
+  }
+  if (tid < FD) g[tid] = gsum[L.b1[2] + tid];
+  if (tid < L.app) {
+    float s = params[L.ab + tid];
+    for (int q = 0; q < 7; q++) s += params[L.aw + tid * 7 + q] * pose7[q];
+    app[tid] = s;
   }
   __syncthreads();
-  if (a < L.app) {
+  for (int idx = tid; idx < FD * L.app; idx += 1024) {
+    const int j = idx / L.app, a = idx - j * L.app;
+    const int w = L.w1[2] + j * L.in[2] + L.kapp + a;
+    part[j][a] = params[w] * g[j];
+    dparams[w] += g[j] * app[a];
+  }
+  __syncthreads();
+  if (tid < L.app) {
     float dapp = 0.f;
-    for (int j = 0; j < FD; j++) {
-      dapp += params[L.w1[2] + j * L.in[2] + L.kapp + a] * g[j];
-      dparams[L.w1[2] + j * L.in[2] + L.kapp + a] += g[j] * app[a];
-    }
-    for (int q = 0; q < 7; q++) dparams[L.aw + a * 7 + q] += dapp * pose7[q];
-    dparams[L.ab + a] += dapp;
+    for (int j = 0; j < FD; j++) dapp += part[j][tid];      // fixed order: deterministic
+    for (int q = 0; q < 7; q++) dparams[L.aw + tid * 7 + q] += dapp * pose7[q];
+    dparams[L.ab + tid] += dapp;
   }
 }
 
@@ -953,11 +965,12 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   neural_bwd_kernel<<<NEURAL_GRID, 256, bwd_lds, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
                                         camera_center, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor,
                                         dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, scaling_reg_weight, reg_sum);
-  if (scaling_reg_out) reg_finish_kernel<<<1, 1, 0, st>>>(T.count, reg_sum, scaling_reg_weight, scaling_reg_out);
+  if (scaling_reg_out && L.app == 0) reg_finish_kernel<<<1, 1, 0, st>>>(T.count, reg_sum, scaling_reg_weight, scaling_reg_out);
   const WJobs J = make_jobs(L);
   wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), 64, 0, st>>>(J, T.count, T.rows, T.partial);
   wgrad_reduce_kernel<<<dim3((37 * 72 + 15) / 16, WG_JOBS), 256, 0, st>>>(J, T.partial, T.gsum, dL_dmlp_params);
-  if (L.app > 0) appearance_finish_kernel<<<1, 64, 0, st>>>(L, mlp_params, pose7, T.gsum, dL_dmlp_params);
+  if (L.app > 0) appearance_finish_kernel<<<1, 1024, 0, st>>>(L, mlp_params, pose7, T.gsum, dL_dmlp_params, T.count, reg_sum,
+                                                              scaling_reg_weight, scaling_reg_out);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }

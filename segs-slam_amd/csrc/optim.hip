@@ -14,16 +14,18 @@
 
 namespace {
 constexpr int MAX_SEG = 16;
+constexpr int VEC_PER_THREAD = 4;                       // float4 accesses in flight per thread and tensor
+constexpr int CHUNK_VEC = 256 * VEC_PER_THREAD;         // float4 vectors per workgroup (4096 parameters)
 struct SegTable {
   long long offset[MAX_SEG];
   long long count[MAX_SEG];
   float step_size[MAX_SEG];  // lr / (1 - b1^t)
+  int block_start[MAX_SEG + 1];  // first workgroup of each segment: segments run side by side, not one after the other
   int nseg;
 };
 
 __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float b1, float b2, float omb1, float omb2,
-                                         float inv_sqrt_bc2_is_div, float sqrt_bc2, float eps, float step_size, float gscale) {
-  (void)inv_sqrt_bc2_is_div;
+                                         float sqrt_bc2, float eps, float step_size, float gscale) {
   const float gr = g * gscale;
   m = m * b1 + gr * omb1;
   v = v * b2 + gr * gr * omb2;
@@ -31,6 +33,9 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
   p = p - step_size * (m / denom);
 }
 
+// One workgroup = one chunk of 1024 aligned float4 vectors of ONE segment (plus, for the segment's first workgroup, its
+// <= 3 unaligned head and <= 3 tail elements).  The first version looped over the segments inside every thread: the ten
+// small MLP segments then cost one dependent global round trip each (27 us for 3.6 M parameters, 47 % of the copy rate).
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
                                                    float* __restrict__ v, SegTable tab, float b1, float b2, float omb1, float omb2,
                                                    float sqrt_bc2, float eps, float gscale, int zero_grad,
@@ -38,36 +43,57 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
   // guarded step: the gradients of an iteration the resident rasterizer flagged as overflowed are discarded on the
   // device (parameters and moments untouched, gradient bucket cleared) without the host having to look first
   const bool skip = skip_flag != nullptr && *skip_flag != 0u;
-  for (int s = 0; s < tab.nseg; s++) {
-    const long long off = tab.offset[s], cnt = tab.count[s];
-    const float ss = tab.step_size[s];
-    // vector body on the 16-byte aligned middle, scalar head/tail
-    const long long head = min(cnt, (long long)((4 - (off & 3)) & 3));
-    const long long nvec = (cnt - head) / 4;
-    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long gsz = (long long)gridDim.x * blockDim.x;
-    for (long long i = gtid; i < nvec; i += gsz) {
-      const long long e = off + head + 4 * i;
-      if (skip) { if (zero_grad) *reinterpret_cast<float4*>(grad + e) = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
-      float4 p4 = *reinterpret_cast<float4*>(param + e), g4 = *reinterpret_cast<float4*>(grad + e);
-      float4 m4 = *reinterpret_cast<float4*>(m + e), v4 = *reinterpret_cast<float4*>(v + e);
-      adam_one(p4.x, g4.x, m4.x, v4.x, b1, b2, omb1, omb2, 0.f, sqrt_bc2, eps, ss, gscale);
-      adam_one(p4.y, g4.y, m4.y, v4.y, b1, b2, omb1, omb2, 0.f, sqrt_bc2, eps, ss, gscale);
-      adam_one(p4.z, g4.z, m4.z, v4.z, b1, b2, omb1, omb2, 0.f, sqrt_bc2, eps, ss, gscale);
-      adam_one(p4.w, g4.w, m4.w, v4.w, b1, b2, omb1, omb2, 0.f, sqrt_bc2, eps, ss, gscale);
-      *reinterpret_cast<float4*>(param + e) = p4;
-      *reinterpret_cast<float4*>(m + e) = m4;
-      *reinterpret_cast<float4*>(v + e) = v4;
-      if (zero_grad) *reinterpret_cast<float4*>(grad + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  while (s + 1 < tab.nseg && (int)blockIdx.x >= tab.block_start[s + 1]) s++;   // wave-uniform, <= 15 steps
+  const int b = (int)blockIdx.x - tab.block_start[s];
+  const long long off = tab.offset[s], cnt = tab.count[s];
+  const float ss = tab.step_size[s];
+  const long long head = min(cnt, (long long)((4 - (off & 3)) & 3));
+  const long long nvec = (cnt - head) / 4;
+  const long long a0 = off + head;                       // first 16-byte aligned element of the segment
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  long long e[VEC_PER_THREAD];
+  bool ok[VEC_PER_THREAD];
+  float4 p4[VEC_PER_THREAD], g4[VEC_PER_THREAD], m4[VEC_PER_THREAD], v4[VEC_PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < VEC_PER_THREAD; u++) {
+    const long long i = (long long)b * CHUNK_VEC + u * 256 + threadIdx.x;
+    ok[u] = i < nvec;
+    e[u] = a0 + 4 * (ok[u] ? i : 0);
+  }
+  if (!skip) {
+#pragma unroll
+    for (int u = 0; u < VEC_PER_THREAD; u++) {
+      if (!ok[u]) continue;
+      p4[u] = *reinterpret_cast<float4*>(param + e[u]); g4[u] = *reinterpret_cast<float4*>(grad + e[u]);
+      m4[u] = *reinterpret_cast<float4*>(m + e[u]); v4[u] = *reinterpret_cast<float4*>(v + e[u]);
     }
-    const long long tail0 = head + 4 * nvec;
-    for (long long i = gtid; i < head + (cnt - tail0); i += gsz) {
-      const long long e = off + (i < head ? i : tail0 + (i - head));
-      if (skip) { if (zero_grad) grad[e] = 0.f; continue; }
-      float p1 = param[e], g1 = grad[e], m1 = m[e], v1 = v[e];
-      adam_one(p1, g1, m1, v1, b1, b2, omb1, omb2, 0.f, sqrt_bc2, eps, ss, gscale);
-      param[e] = p1; m[e] = m1; v[e] = v1;
-      if (zero_grad) grad[e] = 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < VEC_PER_THREAD; u++) {
+    if (!ok[u]) continue;
+    if (!skip) {
+      adam_one(p4[u].x, g4[u].x, m4[u].x, v4[u].x, b1, b2, omb1, omb2, sqrt_bc2, eps, ss, gscale);
+      adam_one(p4[u].y, g4[u].y, m4[u].y, v4[u].y, b1, b2, omb1, omb2, sqrt_bc2, eps, ss, gscale);
+      adam_one(p4[u].z, g4[u].z, m4[u].z, v4[u].z, b1, b2, omb1, omb2, sqrt_bc2, eps, ss, gscale);
+      adam_one(p4[u].w, g4[u].w, m4[u].w, v4[u].w, b1, b2, omb1, omb2, sqrt_bc2, eps, ss, gscale);
+      *reinterpret_cast<float4*>(param + e[u]) = p4[u];
+      *reinterpret_cast<float4*>(m + e[u]) = m4[u];
+      *reinterpret_cast<float4*>(v + e[u]) = v4[u];
+    }
+    if (zero_grad) *reinterpret_cast<float4*>(grad + e[u]) = zero4;
+  }
+  if (b == 0) {   // the segment's unaligned head and tail, scalar
+    const long long tail0 = head + 4 * nvec, nscal = head + (cnt - tail0);
+    if ((long long)threadIdx.x < nscal) {
+      const long long i = threadIdx.x;
+      const long long es = off + (i < head ? i : tail0 + (i - head));
+      if (!skip) {
+        float p1 = param[es], g1 = grad[es], m1 = m[es], v1 = v[es];
+        adam_one(p1, g1, m1, v1, b1, b2, omb1, omb2, sqrt_bc2, eps, ss, gscale);
+        param[es] = p1; m[es] = m1; v[es] = v1;
+      }
+      if (zero_grad) grad[es] = 0.f;
     }
   }
 }
@@ -79,7 +105,7 @@ extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg,
   if (!param || !grad || !exp_avg || !exp_avg_sq || !segments || nseg <= 0 || nseg > MAX_SEG || step <= 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   SegTable tab{};
   tab.nseg = nseg;
-  long long total = 0;
+  long long total = 0, blocks = 0;
   // bias corrections in double on the host, like LibTorch (1 - std::pow(beta, step))
   const double bc1 = 1.0 - std::pow(beta1, (double)step);
   const double bc2 = 1.0 - std::pow(beta2, (double)step);
@@ -89,12 +115,14 @@ extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg,
     tab.count[i] = segments[i].count;
     tab.step_size[i] = (float)(segments[i].lr / bc1);
     total += segments[i].count;
+    tab.block_start[i] = (int)blocks;
+    // >= 1 workgroup per non-empty segment (its first one also takes the unaligned head/tail); an empty segment gets none
+    if (segments[i].count > 0) blocks += (segments[i].count / 4 + CHUNK_VEC - 1) / CHUNK_VEC + (segments[i].count < 4 ? 1 : 0);
+    if (blocks > 0x7FFFFFFF) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "Adam bucket too large for one launch");
   }
+  tab.block_start[nseg] = (int)blocks;
   if (total == 0) return SEGS_OK;
   const float sqrt_bc2 = (float)std::sqrt(bc2);
-  long long blocks = (total / 4 + 255) / 256;
-  if (blocks > 256 * 8) blocks = 256 * 8;  // 8 workgroups per CU, grid-stride the rest
-  if (blocks < 1) blocks = 1;
   // Scalars cross into the float32 tensor arithmetic the way LibTorch's do: computed in double, rounded once
   adam_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, tab, (float)beta1, (float)beta2,
                                                             (float)(1.0 - beta1), (float)(1.0 - beta2), sqrt_bc2, (float)eps,
