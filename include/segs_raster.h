@@ -42,6 +42,12 @@ const char* segs_last_error(void);
  * and R differ.  Used with segs_neural_forward's candidate-domain outputs (segs_neural.h), where it stands for the
  * reference's boolean-mask compaction in front of the rasterizer (src/gaussian_renderer.cpp:320). */
 #define SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY 1u
+/* SEGS_RASTER_KEEP_DEAD_INSTANCES (resident entry points only): by default the resident forward drops, while sorting, every
+ * (Gaussian, tile) instance of the reference's bounding-rectangle duplication (rasterizer_impl.cu:70-111) that cannot pass
+ * alpha >= 1/255 at any pixel of its tile -- the pairs the reference skips pixel by pixel (forward.cu:404-412).  Image
+ * and gradients are unchanged; the per-tile lists get shorter.  With this flag the full lists are kept, as the
+ * reference-shaped segs_rasterize_forward always does (its R, point_list and ranges are the reference's, bit for bit). */
+#define SEGS_RASTER_KEEP_DEAD_INSTANCES 2u
 uint32_t segs_raster_set_flags(uint32_t flags);
 
 /* Resident mode only, per host thread; returns the previous pointer.  When set, segs_rasterize_forward_resident also

@@ -94,6 +94,40 @@ __device__ __forceinline__ bool ellipse_hits_rect(float cx, float cy, float A, f
   return best <= k;
 }
 
+// The same test for the four 8x8 quadrants of the tile at (fx, fy) at once.  The quadrants share their edge lines
+// (x = fx, fx+7, fx+8, fx+15, likewise y), so the clamped 1-D minimum along a line is set up once per line and evaluated
+// for the two spans it bounds: 16 edge minima at about 150 VALU operations instead of 4 x 60 (the emitter is VALU-bound
+// on this test).  Same mathematics as ellipse_hits_rect, evaluated as a dx^2 + dy (2 b dx + c dy); the threshold k is
+// inflated by the caller, so the last-bit differences stay on the conservative side.
+__device__ __forceinline__ uint32_t quadrant_mask(float cx, float cy, float A, float B, float C, float k, float nb_c /* -B/C */,
+                                                  float nb_a /* -B/A */, float fx, float fy) {
+  const float lx[4] = {fx - cx, fx + 7.f - cx, fx + 8.f - cx, fx + 15.f - cx};
+  const float ly[4] = {fy - cy, fy + 7.f - cy, fy + 8.f - cy, fy + 15.f - cy};
+  const float B2 = 2.f * B;
+  float v[4][2], h[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float dx = lx[i], t = nb_c * dx, adx2 = A * dx * dx, bdx2 = B2 * dx;   // line x = lx[i]
+    const float dy = ly[i], u = nb_a * dy, cdy2 = C * dy * dy, bdy2 = B2 * dy;   // line y = ly[i]
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const float yy = fminf(ly[2 * r + 1], fmaxf(ly[2 * r], t));
+      v[i][r] = adx2 + yy * (bdx2 + C * yy);
+      const float xx = fminf(lx[2 * r + 1], fmaxf(lx[2 * r], u));
+      h[i][r] = cdy2 + xx * (bdy2 + A * xx);
+    }
+  }
+  uint32_t mask = 0u;
+#pragma unroll
+  for (int qd = 0; qd < 4; qd++) {
+    const int qx = qd & 1, qy = qd >> 1;
+    const bool inside = lx[2 * qx] <= 0.f && lx[2 * qx + 1] >= 0.f && ly[2 * qy] <= 0.f && ly[2 * qy + 1] >= 0.f;
+    const float best = fminf(fminf(v[2 * qx][qy], v[2 * qx + 1][qy]), fminf(h[2 * qy][qx], h[2 * qy + 1][qx]));
+    if (inside || best <= k) mask |= 1u << qd;
+  }
+  return mask;
+}
+
 // Inclusive offsets of tiles_touched in DEPTH order (one per sorted slot): block prefix from scan_block_sums_kernel
 // plus an in-workgroup scan.
 __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
@@ -154,12 +188,13 @@ __device__ __forceinline__ int wave_lower_bound(const uint32_t* __restrict__ a, 
 __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ incl, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
-    const uint32_t* __restrict__ n_dev /* resident mode: R lives on the device, `R` is the capacity */) {
+    const uint32_t* __restrict__ n_dev /* resident mode: R lives on the device, `R` is the capacity */,
+    int mark_dead /* instances that reach no quadrant get DEAD_KEY: the first tile-id pass drops them */) {
   __shared__ uint32_t s_incl[EMIT_SLOTS + 1];
   if (n_dev) R = (int)min(*n_dev, (uint32_t)R);
   __shared__ uint32_t s_idx[EMIT_SLOTS + 1];
-  __shared__ uint4 s_bin[EMIT_SLOTS + 1];
-  __shared__ float s_geo[EMIT_SLOTS + 1][6];  // x, y, A, B, C, k
+  __shared__ uint2 s_bin[EMIT_SLOTS + 1];                              // rect min (x | y << 16), rect max
+  __shared__ __attribute__((aligned(16))) float s_geo[EMIT_SLOTS + 1][8];  // x, y, A, B | C, k, -B/C, -B/A
   const int tid = threadIdx.x;
   const uint32_t s0 = blockIdx.x * EMIT_SLOTS, s1 = min((uint32_t)R, s0 + EMIT_SLOTS);
   if (s0 >= (uint32_t)R) return;
@@ -171,7 +206,7 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
   for (int k = tid; k < n_own; k += 256) {
     const uint32_t idx = order[g_lo + k];
     const uint4 b = reinterpret_cast<const uint4*>(bin)[idx];
-    s_idx[k] = idx; s_incl[k] = incl[g_lo + k]; s_bin[k] = b;
+    s_idx[k] = idx; s_incl[k] = incl[g_lo + k]; s_bin[k] = make_uint2(b.y, b.z);
     const float* r = rec + (size_t)idx * REC_DWORDS;
     const float2 xy = *reinterpret_cast<const float2*>(r);
     const float4 q2 = reinterpret_cast<const float4*>(r)[2];  // b, A, B, C
@@ -179,6 +214,7 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     float* g = s_geo[k];
     g[0] = xy.x; g[1] = xy.y; g[2] = q2.y; g[3] = q2.z; g[4] = q2.w;
     g[5] = (op * 255.0f > 1.0f) ? 2.0f * __logf(255.0f * op) * 1.0001f + 1e-3f : -1.0f;
+    g[6] = -q2.z / q2.w; g[7] = -q2.z / q2.y;   // once per Gaussian instead of once per instance
   }
   __syncthreads();
 #pragma unroll
@@ -190,25 +226,17 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     while (a < b2) { const int mid = (a + b2) >> 1; if (s_incl[mid] > j) b2 = mid; else a = mid + 1; }
     const int g = a;
     const uint32_t excl = g == 0 ? excl0 : s_incl[g - 1];
-    const uint4 bb = s_bin[g];
+    const uint2 bb = s_bin[g];
     const uint32_t t = j - excl;
-    const uint32_t minx = bb.y & 0xFFFFu, miny = bb.y >> 16, w = (bb.z & 0xFFFFu) - minx;
+    const uint32_t minx = bb.x & 0xFFFFu, miny = bb.x >> 16, w = (bb.y & 0xFFFFu) - minx;
     uint32_t q = (uint32_t)((float)t / (float)w);
     if (q * w > t) q--;
     if ((q + 1) * w <= t) q++;
     const uint32_t ty = miny + q, tx = minx + (t - q * w);
-    const float* ge = s_geo[g];
-    const float cx = ge[0], cy = ge[1], A = ge[2], B = ge[3], C = ge[4], k = ge[5];
-    uint32_t mask = 0u;
-    if (k > 0.f) {
-      const float fx = (float)(tx * TILE_X), fy = (float)(ty * TILE_Y);
-#pragma unroll
-      for (int qd = 0; qd < 4; qd++) {
-        const float x0 = fx + (float)((qd & 1) * 8), y0 = fy + (float)((qd >> 1) * 8);
-        if (ellipse_hits_rect(cx, cy, A, B, C, k, x0, x0 + 7.f, y0, y0 + 7.f)) mask |= 1u << qd;
-      }
-    }
-    keys[j] = ty * gx + tx;   // tile id only: depth order is already the emission order
+    const float4 ge0 = *reinterpret_cast<const float4*>(&s_geo[g][0]), ge1 = *reinterpret_cast<const float4*>(&s_geo[g][4]);
+    const float k = ge1.y;
+    const uint32_t mask = k > 0.f ? quadrant_mask(ge0.x, ge0.y, ge0.z, ge0.w, ge1.x, k, ge1.z, ge1.w, (float)(tx * TILE_X), (float)(ty * TILE_Y)) : 0u;
+    keys[j] = (mark_dead && mask == 0u) ? DEAD_KEY : ty * gx + tx;   // tile id only: depth order is already the emission order
     vals[j] = s_idx[g] | (mask << ID_BITS);
   }
 }
@@ -218,6 +246,7 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
 // alone when dbits < 0.  32-bit keys (the pipeline): digit of (key - dmin).  Depth bits of positive floats are monotone
 // in the depth, so sorting on them (ties included) gives exactly the reference's order.
 struct KeyMap { uint32_t dmin; int dbits; };
+#define DEAD_KEY_OF(K) (~(K)0)   // an all-ones key marks an entry the first pass of a sort may drop (see run_binning)
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, KeyMap km) {
   const uint64_t kc = km.dbits < 0 ? (key >> 32) : (((key >> 32) << km.dbits) | (uint64_t)((uint32_t)key - km.dmin));
   return (uint32_t)(kc >> shift) & 0xFFu;
@@ -246,7 +275,7 @@ template <typename K>
 __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __restrict__ keys, int n, int shift,
                                                                     uint32_t dmin, int dbits,
                                                                     uint32_t* __restrict__ block_hist, int nblocks,
-                                                                    const uint32_t* __restrict__ n_dev) {
+                                                                    const uint32_t* __restrict__ n_dev, int drop_dead) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   __shared__ uint32_t cnt[4][256];
@@ -267,7 +296,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     const size_t i = wave_base + (size_t)r * 64 + lane;
-    if (i < (size_t)n) atomicAdd(&my[digit_of(kreg[r], shift, km)], 1u);
+    if (i < (size_t)n && !(drop_dead && kreg[r] == (K)DEAD_KEY_OF(K))) atomicAdd(&my[digit_of(kreg[r], shift, km)], 1u);
   }
   __syncthreads();
   block_hist[(size_t)tid * nblocks + blockIdx.x] = cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
@@ -313,7 +342,8 @@ template <typename K>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, K* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int n, int shift, uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist,
-    const uint32_t* __restrict__ digit_totals, int nblocks, const uint32_t* __restrict__ n_dev) {
+    const uint32_t* __restrict__ digit_totals, int nblocks, const uint32_t* __restrict__ n_dev, int drop_dead,
+    uint32_t* __restrict__ n_live_out) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   __shared__ K s_keys[SORT_TILE];
@@ -344,7 +374,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     const size_t i = wave_base + (size_t)r * 64 + lane;
-    const bool valid = i < (size_t)n;
+    const bool valid = i < (size_t)n && !(drop_dead && key[r] == (K)DEAD_KEY_OF(K));   // dead keys take no rank: dropped here
     const uint32_t d = valid ? digit_of(key[r], shift, km) : 0u;
     const uint64_t vmask = __ballot(valid);
     const uint64_t peers = match_digit(d, vmask);
@@ -382,6 +412,9 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   __syncthreads();
   uint32_t lbase = 0, gbase = 0;
   for (int w = 0; w < wv; w++) { lbase += scan_tmp[w]; gbase += tot_tmp[w]; }
+  // with dead keys dropped the tile holds fewer than nvalid entries, and the pass leaves sum(digit_totals) of them in all
+  const int nout = drop_dead ? (int)(scan_tmp[0] + scan_tmp[1] + scan_tmp[2] + scan_tmp[3]) : nvalid;
+  if (n_live_out != nullptr && blockIdx.x == 0 && tid == 0) *n_live_out = tot_tmp[0] + tot_tmp[1] + tot_tmp[2] + tot_tmp[3];
   const uint32_t lstart = lbase + x - run;
   const uint32_t gstart = gbase + tx - tot + block_hist[(size_t)tid * nblocks + blockIdx.x];
   local_start[tid] = lstart;
@@ -401,7 +434,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 #pragma unroll 4
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     const int lp = r * SORT_THREADS + tid;
-    if (lp < nvalid) {
+    if (lp < nout) {
       const K k = s_keys[lp];
       const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of(k, shift, km)]);
       keys_out[gp] = k;
@@ -410,12 +443,12 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   }
 }
 
-template __global__ void radix_count_kernel<uint64_t>(const uint64_t*, int, int, uint32_t, int, uint32_t*, int, const uint32_t*);
-template __global__ void radix_count_kernel<uint32_t>(const uint32_t*, int, int, uint32_t, int, uint32_t*, int, const uint32_t*);
+template __global__ void radix_count_kernel<uint64_t>(const uint64_t*, int, int, uint32_t, int, uint32_t*, int, const uint32_t*, int);
+template __global__ void radix_count_kernel<uint32_t>(const uint32_t*, int, int, uint32_t, int, uint32_t*, int, const uint32_t*, int);
 template __global__ void radix_scatter_kernel<uint64_t>(const uint64_t*, const uint32_t*, uint64_t*, uint32_t*, int, int, uint32_t, int,
-                                                        const uint32_t*, const uint32_t*, int, const uint32_t*);
+                                                        const uint32_t*, const uint32_t*, int, const uint32_t*, int, uint32_t*);
 template __global__ void radix_scatter_kernel<uint32_t>(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, int, int, uint32_t, int,
-                                                        const uint32_t*, const uint32_t*, int, const uint32_t*);
+                                                        const uint32_t*, const uint32_t*, int, const uint32_t*, int, uint32_t*);
 
 // ---------------------------------------------------------------------------------------------
 // K9 (rasterizer_impl.cu:116-138).  The range table is zeroed by make_depth_keys_kernel earlier in the same stream
@@ -423,7 +456,8 @@ template __global__ void radix_scatter_kernel<uint32_t>(const uint32_t*, const u
 // tried and is slower (44 dependent loads per tile: 17 us vs 9 us at R = 3.7 M).
 __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys,
                                                                    uint2* __restrict__ ranges, const uint32_t* __restrict__ n_dev,
-                                                                   uint32_t* __restrict__ status, uint32_t* __restrict__ status_mirror) {
+                                                                   uint32_t* __restrict__ status, uint32_t* __restrict__ status_mirror,
+                                                                   const uint32_t* __restrict__ n_live /* entries left after dead keys were dropped, or null */) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (n_dev) {
     const uint32_t n = *n_dev;
@@ -434,6 +468,7 @@ __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const 
     }
     L = (int)min(n, (uint32_t)L);
   }
+  if (n_live) L = (int)min(*n_live, (uint32_t)L);
   if (idx >= L) return;
   const uint32_t cur = keys[idx];
   if (idx == 0) ranges[cur].x = 0;

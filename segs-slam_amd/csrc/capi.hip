@@ -90,10 +90,13 @@ uint32_t getHigherMsb(uint32_t n) {
 
 // K8: stable LSD radix sort, 8 bits per pass over key bits [0,end_bit).  Input is expected in side
 // `passes & 1` of the ping-pong pair so that the result lands in side 0.
+// drop_dead: entries whose key is all ones are left out by the FIRST pass (they take no histogram count and no rank), so
+// every later pass -- and the caller, through *n_live -- works on the survivors only: a stable partition for free.
 template <typename K>
 int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t dmin, int dbits, hipStream_t st,
-               const uint32_t* n_dev = nullptr) {
+               const uint32_t* n_dev = nullptr, bool drop_dead = false) {
   if (n <= 0) return SEGS_OK;
+  uint32_t* n_live = (uint32_t*)(bin + L.n_live);
   const int passes = (end_bit + 7) / 8;
   int side = passes & 1;
   uint32_t* block_hist = (uint32_t*)(bin + L.block_hist);
@@ -104,8 +107,10 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     K* kout = (K*)(bin + L.keys[side ^ 1]);
     uint32_t* vout = (uint32_t*)(bin + L.vals[side ^ 1]);
     const int shift = 8 * p;
+    const int drop = drop_dead && p == 0;
+    const uint32_t* n_in = (drop_dead && p > 0) ? n_live : n_dev;
     { PROF(K_RADIX_COUNT);
-    radix_count_kernel<K><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, block_hist, L.nblocks, n_dev);
+    radix_count_kernel<K><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, block_hist, L.nblocks, n_in, drop);
     }
     LAUNCH_TRY("radix_count_kernel");
     { PROF(K_RADIX_SCAN);
@@ -114,7 +119,7 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     LAUNCH_TRY("radix_scan_kernel");
     { PROF(K_RADIX_SCATTER);
     radix_scatter_kernel<K><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, block_hist, digit_totals, L.nblocks,
-                                                              n_dev);
+                                                              n_in, drop, drop ? n_live : nullptr);
     }
     LAUNCH_TRY("radix_scatter_kernel");
     side ^= 1;
@@ -162,7 +167,7 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
 // `total_out` (3 device words) receives the instance count produced by the depth-ordered scan.
 int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSortLayout& GS, uint2* ranges, int P, int n_cap,
                 const uint32_t* n_dev, uint32_t dmin, int dbits, uint32_t dcull, uint32_t gx, uint32_t gy, uint32_t* total_out,
-                hipStream_t st, bool depth_keys_ready = false) {
+                hipStream_t st, bool depth_keys_ready = false, bool drop_dead = false) {
   const int bit = (int)getHigherMsb(gx * gy);
   // (1)
   char* gbin = bin + GS.base;
@@ -190,15 +195,17 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   LAUNCH_TRY("ordered_offsets_kernel");
   { PROF(K_DUPLICATE);
   duplicate_with_keys_kernel<<<(n_cap + 1023) / 1024, 256, 0, st>>>(P, n_cap, G.bin(), G.rec(), order, G.offsets(),
-                                                                    (uint32_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev);
+                                                                    (uint32_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev,
+                                                                    drop_dead ? 1 : 0);
   }
   LAUNCH_TRY("duplicate_with_keys_kernel");
   // (3)
-  rc = sort_pairs<uint32_t>(bin, BL, n_cap, bit, 0u, 0, st, n_dev);
+  rc = sort_pairs<uint32_t>(bin, BL, n_cap, bit, 0u, 0, st, n_dev, drop_dead);
   if (rc) return rc;
   { PROF(K_RANGES);
   identify_tile_ranges_kernel<<<(n_cap + 255) / 256, 256, 0, st>>>(n_cap, (const uint32_t*)(bin + BL.keys[0]), ranges, n_dev,
-                                                                   n_dev ? total_out : nullptr, n_dev ? g_status_mirror : nullptr);
+                                                                   n_dev ? total_out : nullptr, n_dev ? g_status_mirror : nullptr,
+                                                                   drop_dead ? (const uint32_t*)(bin + BL.n_live) : nullptr);
   }
   LAUNCH_TRY("identify_tile_ranges_kernel");
   return SEGS_OK;
@@ -536,7 +543,11 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
                           rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M, cam_pos, st,
                           (uint32_t*)(gbin + GS.inner.keys[gside]), (uint32_t*)(gbin + GS.inner.vals[gside]), ranges);
   if (rc) return rc;
-  rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, 0u, 32, 0xFFFFFFFFu, gx, gy, status, st, true);
+  // dead instances (no quadrant of their tile can reach alpha >= 1/255: 43 % of them at 500 k Gaussians / 1080p) are
+  // dropped by the first tile-id pass; lists, ranges and n_contrib then count live entries only -- an internal contract
+  // between this forward and its backward, like the reference's own scratch layout
+  rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, 0u, 32, 0xFFFFFFFFu, gx, gy, status, st, true,
+                   (g_flags & SEGS_RASTER_KEEP_DEAD_INSTANCES) == 0u);
   if (rc) return rc;
   // status[3] (overflow) and the host mirror are written by identify_tile_ranges_kernel at the end of run_binning
   { PROF(K_RENDER_FWD);

@@ -90,7 +90,7 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_TILE = SORT_ITEMS_PER_THREAD * SORT_THREADS;  // 2048 items per workgroup
 
 struct BinningLayout {
-  size_t keys[2], vals[2], block_hist, digit_totals, total;
+  size_t keys[2], vals[2], block_hist, digit_totals, n_live, total;
   int R, nblocks;
 };
 // Mirrors BinningState::fromChunk (rasterizer_impl.cu:181-194): ping-pong key/value arrays + sort temp.
@@ -104,6 +104,7 @@ inline BinningLayout binning_layout(int R) {
   for (int i = 0; i < 2; i++) { b.vals[i] = o; o = align_up(o + (size_t)R * 4); }
   b.block_hist = o;   o = align_up(o + (size_t)256 * (b.nblocks > 0 ? b.nblocks : 1) * 4);
   b.digit_totals = o; o = align_up(o + 256 * 4);
+  b.n_live = o;       o = align_up(o + 4);   // entries left after the first pass dropped the dead keys (sort_pairs)
   b.total = o + ALIGN;
   return b;
 }

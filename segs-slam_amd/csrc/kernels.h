@@ -51,19 +51,20 @@ __global__ void ordered_offsets_kernel(int P, const BinInfo* __restrict__ bin, c
 __global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
-                                           const uint32_t* __restrict__ n_dev);
+                                           const uint32_t* __restrict__ n_dev, int mark_dead);
+constexpr uint32_t DEAD_KEY = 0xFFFFFFFFu;   // tile-id key of an instance that reaches no quadrant of its tile
 template <typename K>   // K = uint32_t (the pipeline's own sorts) or uint64_t (segs_sort_pairs)
 __global__ void radix_count_kernel(const K* __restrict__ keys, int n, int shift, uint32_t dmin, int dbits,
-                                   uint32_t* __restrict__ block_hist, int nblocks, const uint32_t* __restrict__ n_dev);
+                                   uint32_t* __restrict__ block_hist, int nblocks, const uint32_t* __restrict__ n_dev, int drop_dead);
 __global__ void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_totals);
 template <typename K>
 __global__ void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                      K* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
                                      uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_totals, int nblocks,
-                                     const uint32_t* __restrict__ n_dev);
+                                     const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out);
 __global__ void identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges,
                                             const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ status,
-                                            uint32_t* __restrict__ status_mirror);
+                                            uint32_t* __restrict__ status_mirror, const uint32_t* __restrict__ n_live);
 
 // ---- render.hip
 __global__ void render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
