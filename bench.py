@@ -175,7 +175,9 @@ def main():
 
     if rank == 0:
         eng.check()
-        R = eng.R
+        # R of the formulas below is the REFERENCE's num_rendered (bounding-square duplication, taken from the calibrating
+        # reference-shaped forward); the resident forwards bin fewer instances (tight rectangles, dead instances dropped)
+        R = eng.R_reference or eng.R
         P_vis = int((eng.radii > 0).sum().item())
         gx, gy = (cam.width + 15) // 16, (cam.height + 15) // 16
         passes_tile = (max(1, int(gx * gy - 1).bit_length()) + 7) // 8
@@ -207,7 +209,7 @@ def main():
                                    + (" + L1/SSIM loss + fused Adam" if args.mode == "trainer" else "")
                                    + (f"; anchor-level mapper step: {args.anchors} anchors x 10 offsets -> neural Gaussians "
                                       "(MLPs fwd+bwd), L1/SSIM, fused Adam" if args.mode == "scaffold" else ""),
-                       "P": eng.P, "P_visible": P_vis, "num_rendered": R, "width": cam.width, "height": cam.height,
+                       "P": eng.P, "P_visible": P_vis, "num_rendered": R, "instances_binned": eng.R, "width": cam.width, "height": cam.height,
                        "sort_passes": {"depth_keys_P": passes_depth, "tile_keys_R": passes_tile}, "parallelism": f"keyframe-dp{world}",
                        "forward": "sync (reference API)" if args.sync_forward else "resident (no host sync)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -145,7 +145,7 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
                    const float* scales, float mod, const float* rots, const float* cov3D_precomp, const float* view,
                    const float* proj, float tan_fovx, float tan_fovy, int* radii, const float* shs, int D, int M,
                    const float* cam_pos, hipStream_t st, uint32_t* depth_keys = nullptr, uint32_t* depth_vals = nullptr,
-                   uint2* ranges = nullptr) {
+                   uint2* ranges = nullptr, uint32_t extra_flags = 0u) {
   const float focal_y = H / (2.0f * tan_fovy);   // rasterizer_impl.cu:221-222
   const float focal_x = W / (2.0f * tan_fovx);
   const uint32_t gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
@@ -153,7 +153,7 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
   preprocess_fwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, scales, mod, rots, opac, colors, cov3D_precomp, view,
                                                      proj, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, radii,
                                                      G.rec(), G.bin(), G.block_sums(), G.block_sums() + (G.L.nblocks + 1), shs, D, M, cam_pos,
-                                                     G.clamped(), g_flags, depth_keys, depth_vals, ranges, (int)(gx * gy));
+                                                     G.clamped(), g_flags | extra_flags, depth_keys, depth_vals, ranges, (int)(gx * gy));
   }
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
@@ -541,7 +541,8 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
   const int gside = (4 & 1);   // 32 key bits = 4 byte passes: the sort starts from side 0 (see sort_pairs)
   int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales, scale_modifier,
                           rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M, cam_pos, st,
-                          (uint32_t*)(gbin + GS.inner.keys[gside]), (uint32_t*)(gbin + GS.inner.vals[gside]), ranges);
+                          (uint32_t*)(gbin + GS.inner.keys[gside]), (uint32_t*)(gbin + GS.inner.vals[gside]), ranges,
+                          (g_flags & SEGS_RASTER_KEEP_DEAD_INSTANCES) ? 0u : PREPROCESS_TIGHT_RECT);
   if (rc) return rc;
   // dead instances (no quadrant of their tile can reach alpha >= 1/255: 43 % of them at 500 k Gaussians / 1080p) are
   // dropped by the first tile-id pass; lists, ranges and n_contrib then count live entries only -- an internal contract

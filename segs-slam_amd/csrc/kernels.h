@@ -52,6 +52,7 @@ __global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restri
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
                                            const uint32_t* __restrict__ n_dev, int mark_dead);
+constexpr uint32_t PREPROCESS_TIGHT_RECT = 0x80000000u;   // internal flag bit of preprocess_fwd_kernel (resident forward)
 constexpr uint32_t DEAD_KEY = 0xFFFFFFFFu;   // tile-id key of an instance that reaches no quadrant of its tile
 template <typename K>   // K = uint32_t (the pipeline's own sorts) or uint64_t (segs_sort_pairs)
 __global__ void radix_count_kernel(const K* __restrict__ keys, int n, int shift, uint32_t dmin, int dbits,

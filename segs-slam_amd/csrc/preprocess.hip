@@ -323,6 +323,23 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     if ((flags & 1u) && !(opacities[idx] > 0.f)) g.radius = 0;
     BinInfo b{0u, 0u, 0u, 0u};
     if (g.radius > 0) {
+      if (flags & PREPROCESS_TIGHT_RECT) {
+        // Resident mode: bin only the tiles the alpha >= 1/255 ellipse can reach.  d^T Q d <= k = 2 ln(255 o) has the
+        // axis-aligned half extents sqrt(k cov_xx), sqrt(k cov_yy) (cov = Q^-1, the dilated 2D covariance); the rect is
+        // the reference's (3 sigma square, getRect) INTERSECTED with that box, never larger, so exactly the reference's
+        // contributing pairs remain.  k is inflated like the emitter's (binning.hip), the extents once more.
+        const float op0 = opacities[idx];
+        if (op0 * 255.0f > 1.0f) {
+          const float k = 2.0f * __logf(255.0f * op0) * 1.0001f + 1e-3f;
+          const float hx = sqrtf(k * g.cov_a) * 1.0001f + 0.01f, hy = sqrtf(k * g.cov_c) * 1.0001f + 0.01f;
+          const int tx0 = (int)floorf((g.px - hx) * (1.0f / TILE_X)), tx1 = (int)floorf((g.px + hx) * (1.0f / TILE_X)) + 1;
+          const int ty0 = (int)floorf((g.py - hy) * (1.0f / TILE_Y)), ty1 = (int)floorf((g.py + hy) * (1.0f / TILE_Y)) + 1;
+          g.minx = (uint32_t)max((int)g.minx, tx0); g.maxx = (uint32_t)max((int)g.minx, min((int)g.maxx, tx1));
+          g.miny = (uint32_t)max((int)g.miny, ty0); g.maxy = (uint32_t)max((int)g.miny, min((int)g.maxy, ty1));
+        } else {
+          g.maxx = g.minx;   // alpha >= 1/255 is impossible: no instance at all
+        }
+      }
       touched = (g.maxy - g.miny) * (g.maxx - g.minx);
       b.depth_bits = __float_as_uint(g.depth);
       dbits_mine = b.depth_bits;

@@ -48,10 +48,12 @@ class RasterEngine:
     reports an overflow if R ever outgrew it."""
 
     def __init__(self, P: int, width: int, height: int, device="cuda:0", resident: bool = False,
-                 skip_nonpositive_opacity: bool = False):
+                 skip_nonpositive_opacity: bool = False, keep_dead_instances: bool = False):
         self.resident = bool(resident)
         # SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY (segs_raster.h): candidate-domain inputs of segs_neural_forward
-        self.flags = 1 if skip_nonpositive_opacity else 0
+        # SEGS_RASTER_KEEP_DEAD_INSTANCES: resident forwards bin the reference's full bounding squares (R == R_reference)
+        self.flags = (1 if skip_nonpositive_opacity else 0) | (2 if keep_dead_instances else 0)
+        self.R_reference = 0
         self.capacity = 0
         self._status_host = None
         self.P, self.W, self.H = int(P), int(width), int(height)   # P = allocated rows; P_active <= P are rasterized
@@ -80,7 +82,10 @@ class RasterEngine:
 
     # ---- resident mode plumbing
     def _setup_resident(self, R: int):
-        self.capacity = int(R * 1.5) + 65536
+        # R is the reference-shaped count of the calibrating forward.  Resident forwards bin tight rectangles (typically
+        # 0.6-0.75 of it, never more), so 1.25 R leaves them the headroom 1.5 R gives the full lists; the R-sized kernels
+        # are launched over the capacity, surplus workgroups cost about 2 us per launch.
+        self.capacity = int(R * (1.5 if self.flags & 2 else 1.25)) + 65536
         dev = self.device
         self._geom_r = torch.empty(self._lib.segs_geometry_bytes(self.P), dtype=torch.uint8, device=dev)
         self._img_r = torch.empty(self._lib.segs_image_bytes(self.W, self.H), dtype=torch.uint8, device=dev)
@@ -147,6 +152,7 @@ class RasterEngine:
             p(campos), float(tanfovx), float(tanfovy), 0, p(self.out_color), p(self.radii), self._stream(), C.byref(n))
         _capi.check(st, "segs_rasterize_forward")
         self.R = int(n.value)
+        self.R_reference = self.R     # the reference's num_rendered (bounding-square duplication, rasterizer_impl.cu:70-111)
         self._last = (bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
                       scale_modifier)
         if self.resident and self.capacity == 0:

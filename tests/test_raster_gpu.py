@@ -268,8 +268,9 @@ def test_autograd_module_matches_oracle():
 
 
 def test_resident_engine_matches_sync_path():
-    """The no-host-sync entry points (segs_rasterize_*_resident) give bit-identical images, radii and per-Gaussian
-    backward products as the reference-shaped synchronising call (same kernels, capacity-keyed scratch)."""
+    """The no-host-sync entry points (segs_rasterize_*_resident) give bit-identical images and radii, and the same
+    per-Gaussian backward products, as the reference-shaped synchronising call -- with the reference's full instance
+    lists (keep_dead_instances) and with the default tight binning that leaves out instances no pixel can see."""
     from segs_slam_amd.raster_engine import RasterEngine
     sc = scenes.make_scene(30_000, 320, 240, 260.0, 260.0, seed=17, bg=(0.1, 0.2, 0.3))
     sc.scales *= 2.0
@@ -278,8 +279,8 @@ def test_resident_engine_matches_sync_path():
              v=_t(cam.world_view_transform), p=_t(cam.full_proj_transform), cp=_t(cam.camera_center))
     dL = _t(sc.dL_dout_color)
     outs = []
-    for resident in (False, True):
-        eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=resident)
+    for resident, keep in ((False, False), (True, True), (True, False)):
+        eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=resident, keep_dead_instances=keep)
         for it in range(3):  # resident: first call calibrates through the sync path, the rest are no-sync
             img = eng.forward(a["bg"], a["m"], a["c"], a["o"], a["s"], a["r"], a["v"], a["p"], a["cp"], cam.tanfovx, cam.tanfovy).clone()
             eng.backward(dL)
@@ -288,8 +289,11 @@ def test_resident_engine_matches_sync_path():
         assert (not resident) or (eng.capacity > eng.R > 0 and eng._last_resident)
         outs.append((img.cpu().numpy(), eng.radii.cpu().numpy(), eng.R, eng.dL_dcov3D.cpu().numpy().copy(),
                      {k: v.cpu().numpy().copy() for k, v in eng.grads.items()}))
-    (i0, r0, R0, c0, g0), (i1, r1, R1, c1, g1) = outs
-    assert R0 == R1 and np.array_equal(r0, r1) and np.array_equal(i0, i1)
+    (i0, r0, R0, c0, g0), (i1, r1, R1, c1, g1), (i2, r2, R2, c2, g2) = outs
+    assert R0 == R1 and 0 < R2 < R0, (R0, R1, R2)
+    assert np.array_equal(r0, r1) and np.array_equal(r0, r2)
+    assert np.array_equal(i0, i1) and np.array_equal(i0, i2)
     # gradients: float atomics are order-dependent -> tolerance, not bits
     for k in g0:
         assert_grad_close(k, g1[k], g0[k])
+        assert_grad_close(k, g2[k], g0[k])
