@@ -247,19 +247,22 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
 // in the depth, so sorting on them (ties included) gives exactly the reference's order.
 struct KeyMap { uint32_t dmin; int dbits; };
 #define DEAD_KEY_OF(K) (~(K)0)   // an all-ones key marks an entry the first pass of a sort may drop (see run_binning)
+template <int BITS>
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, KeyMap km) {
   const uint64_t kc = km.dbits < 0 ? (key >> 32) : (((key >> 32) << km.dbits) | (uint64_t)((uint32_t)key - km.dmin));
-  return (uint32_t)(kc >> shift) & 0xFFu;
+  return (uint32_t)(kc >> shift) & ((1u << BITS) - 1u);
 }
 // 32-bit keys (the pipeline's own two sorts: depth bits of the P Gaussians, tile ids of the R instances): 20 instead of
 // 32 bytes moved per key and pass.
-__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, KeyMap km) { return ((key - km.dmin) >> shift) & 0xFFu; }
+template <int BITS>
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, KeyMap km) { return ((key - km.dmin) >> shift) & ((1u << BITS) - 1u); }
 
-// Per-lane mask of the lanes (among `valid`) holding the same 8-bit digit: 8 ballots.
+// Per-lane mask of the lanes (among `valid`) holding the same BITS-bit digit: one ballot per digit bit.
+template <int BITS>
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint64_t valid) {
   uint64_t peers = valid;
 #pragma unroll
-  for (int bit = 0; bit < 8; bit++) {
+  for (int bit = 0; bit < BITS; bit++) {
     const bool set = (d >> bit) & 1u;
     const uint64_t m = __ballot(set);
     peers &= set ? m : ~m;
@@ -271,16 +274,19 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {  // number of set bits o
 }
 
 // Count matrix: block_hist[d * nblocks + b] = number of keys of workgroup b's 2048-key tile with digit d.
-template <typename K>
+// BITS = 8 everywhere except the depth sort of the resident forward, whose 27 significant key bits take three 9-bit
+// passes instead of four 8-bit ones (the passes over P keys are bound by their launch count, not by bytes).
+template <typename K, int BITS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __restrict__ keys, int n, int shift,
                                                                     uint32_t dmin, int dbits,
                                                                     uint32_t* __restrict__ block_hist, int nblocks,
                                                                     const uint32_t* __restrict__ n_dev, int drop_dead) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
-  __shared__ uint32_t cnt[4][256];
+  constexpr int NDIG = 1 << BITS;
+  __shared__ uint32_t cnt[4][NDIG];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int i = tid; i < 4 * 256; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
+  for (int i = tid; i < 4 * NDIG; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const size_t wave_base = (size_t)blockIdx.x * SORT_TILE + (size_t)wv * (SORT_TILE / 4);
   uint32_t* my = cnt[wv];
@@ -296,13 +302,14 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     const size_t i = wave_base + (size_t)r * 64 + lane;
-    if (i < (size_t)n && !(drop_dead && kreg[r] == (K)DEAD_KEY_OF(K))) atomicAdd(&my[digit_of(kreg[r], shift, km)], 1u);
+    if (i < (size_t)n && !(drop_dead && kreg[r] == (K)DEAD_KEY_OF(K))) atomicAdd(&my[digit_of<BITS>(kreg[r], shift, km)], 1u);
   }
   __syncthreads();
-  block_hist[(size_t)tid * nblocks + blockIdx.x] = cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
+  for (int d = tid; d < NDIG; d += SORT_THREADS)
+    block_hist[(size_t)d * nblocks + blockIdx.x] = cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
 }
 
-// Row d of the count matrix -> exclusive scan in place; row total -> digit_totals[d].  Grid = 256 workgroups.
+// Row d of the count matrix -> exclusive scan in place; row total -> digit_totals[d].  Grid = one workgroup per digit.
 // Eight consecutive entries per thread and round (2048 per round: one round up to R = 4 M instances), one barrier pair
 // per round -- the previous one-entry-per-thread loop spent 6 us per launch on barriers.
 __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks,
@@ -338,7 +345,7 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ 
 }
 
 // Stable scatter of one 2048-key tile (SORT_TILE).
-template <typename K>
+template <typename K, int BITS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, K* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int n, int shift, uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist,
@@ -346,14 +353,17 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     uint32_t* __restrict__ n_live_out) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
+  constexpr int NDIG = 1 << BITS;
+  constexpr int DPT = NDIG / SORT_THREADS;   // consecutive digits per thread in the prefix step (1 or 2)
+  static_assert(NDIG % SORT_THREADS == 0 && BITS <= 11, "digit | rank << BITS must fit the rank of 2048 keys");
   __shared__ K s_keys[SORT_TILE];
   __shared__ uint32_t s_vals[SORT_TILE];
-  __shared__ uint32_t cnt[4][256];       // per-wave running digit counters, then per-wave bases
-  __shared__ uint32_t local_start[256];  // start of digit run inside the tile
-  __shared__ int32_t gdelta[256];        // global position - local position, per digit
+  __shared__ uint32_t cnt[4][NDIG];       // per-wave running digit counters, then per-wave bases
+  __shared__ uint32_t local_start[NDIG];  // start of digit run inside the tile
+  __shared__ int32_t gdelta[NDIG];        // global position - local position, per digit
   __shared__ uint32_t scan_tmp[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int i = tid; i < 4 * 256; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
+  for (int i = tid; i < 4 * NDIG; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
 
   const size_t tile_base = (size_t)blockIdx.x * SORT_TILE;
@@ -362,7 +372,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 
   K key[SORT_ITEMS_PER_THREAD];
   uint32_t val[SORT_ITEMS_PER_THREAD];
-  uint32_t drank[SORT_ITEMS_PER_THREAD];  // digit | wave-local rank << 8 ; 0xFFFFFFFF = invalid
+  uint32_t drank[SORT_ITEMS_PER_THREAD];  // digit | wave-local rank << BITS ; 0xFFFFFFFF = invalid
   volatile uint32_t* my = cnt[wv];
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
@@ -375,33 +385,39 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     const size_t i = wave_base + (size_t)r * 64 + lane;
     const bool valid = i < (size_t)n && !(drop_dead && key[r] == (K)DEAD_KEY_OF(K));   // dead keys take no rank: dropped here
-    const uint32_t d = valid ? digit_of(key[r], shift, km) : 0u;
+    const uint32_t d = valid ? digit_of<BITS>(key[r], shift, km) : 0u;
     const uint64_t vmask = __ballot(valid);
-    const uint64_t peers = match_digit(d, vmask);
+    const uint64_t peers = match_digit<BITS>(d, vmask);
     const uint32_t below = mbcnt(peers);
     uint32_t old = 0;
     if (valid) old = my[d];
     __builtin_amdgcn_wave_barrier();
     if (valid && below == 0) my[d] = old + (uint32_t)__popcll(peers);
     __builtin_amdgcn_wave_barrier();
-    drank[r] = valid ? (d | ((old + below) << 8)) : 0xFFFFFFFFu;
+    drank[r] = valid ? (d | ((old + below) << BITS)) : 0xFFFFFFFFu;
   }
   __syncthreads();
 
-  // digit `tid`: per-wave exclusive bases, tile count, then exclusive scan over digits.
-  uint32_t run = 0;
+  // digits tid*DPT .. tid*DPT+DPT-1: per-wave exclusive bases, tile count, then exclusive scan over digits.
+  uint32_t run[DPT], tot[DPT], thread_run = 0, thread_tot = 0;
 #pragma unroll
-  for (int w = 0; w < 4; w++) { const uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
-  uint32_t x = run;
+  for (int j = 0; j < DPT; j++) {
+    const int d = tid * DPT + j;
+    uint32_t r = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint32_t c = cnt[w][d]; cnt[w][d] = r; r += c; }
+    run[j] = r; thread_run += r;
+    tot[j] = digit_totals[d]; thread_tot += tot[j];
+  }
+  uint32_t x = thread_run;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     uint32_t y = __shfl_up(x, off, 64);
     if (lane >= off) x += y;
   }
   if (lane == 63) scan_tmp[wv] = x;
-  // global base of digit `tid` = (sum of totals of smaller digits) + this tile's offset inside the digit row
-  uint32_t tot = digit_totals[tid];
-  uint32_t tx = tot;
+  // global base of a digit = (sum of totals of smaller digits) + this tile's offset inside the digit row
+  uint32_t tx = thread_tot;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     uint32_t y = __shfl_up(tx, off, 64);
@@ -412,20 +428,24 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   __syncthreads();
   uint32_t lbase = 0, gbase = 0;
   for (int w = 0; w < wv; w++) { lbase += scan_tmp[w]; gbase += tot_tmp[w]; }
+  uint32_t lstart = lbase + x - thread_run, gstart = gbase + tx - thread_tot;
+#pragma unroll
+  for (int j = 0; j < DPT; j++) {
+    const int d = tid * DPT + j;
+    local_start[d] = lstart;
+    gdelta[d] = (int32_t)(gstart + block_hist[(size_t)d * nblocks + blockIdx.x] - lstart);
+    lstart += run[j]; gstart += tot[j];
+  }
   // with dead keys dropped the tile holds fewer than nvalid entries, and the pass leaves sum(digit_totals) of them in all
   const int nout = drop_dead ? (int)(scan_tmp[0] + scan_tmp[1] + scan_tmp[2] + scan_tmp[3]) : nvalid;
   if (n_live_out != nullptr && blockIdx.x == 0 && tid == 0) *n_live_out = tot_tmp[0] + tot_tmp[1] + tot_tmp[2] + tot_tmp[3];
-  const uint32_t lstart = lbase + x - run;
-  const uint32_t gstart = gbase + tx - tot + block_hist[(size_t)tid * nblocks + blockIdx.x];
-  local_start[tid] = lstart;
-  gdelta[tid] = (int32_t)(gstart - lstart);
   __syncthreads();
 
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     if (drank[r] != 0xFFFFFFFFu) {
-      const uint32_t d = drank[r] & 0xFFu;
-      const uint32_t pos = local_start[d] + cnt[wv][d] + (drank[r] >> 8);
+      const uint32_t d = drank[r] & (uint32_t)(NDIG - 1);
+      const uint32_t pos = local_start[d] + cnt[wv][d] + (drank[r] >> BITS);
       s_keys[pos] = key[r];
       s_vals[pos] = val[r];
     }
@@ -436,19 +456,21 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const int lp = r * SORT_THREADS + tid;
     if (lp < nout) {
       const K k = s_keys[lp];
-      const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of(k, shift, km)]);
+      const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of<BITS>(k, shift, km)]);
       keys_out[gp] = k;
       vals_out[gp] = s_vals[lp];
     }
   }
 }
 
-template __global__ void radix_count_kernel<uint64_t>(const uint64_t*, int, int, uint32_t, int, uint32_t*, int, const uint32_t*, int);
-template __global__ void radix_count_kernel<uint32_t>(const uint32_t*, int, int, uint32_t, int, uint32_t*, int, const uint32_t*, int);
-template __global__ void radix_scatter_kernel<uint64_t>(const uint64_t*, const uint32_t*, uint64_t*, uint32_t*, int, int, uint32_t, int,
-                                                        const uint32_t*, const uint32_t*, int, const uint32_t*, int, uint32_t*);
-template __global__ void radix_scatter_kernel<uint32_t>(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, int, int, uint32_t, int,
-                                                        const uint32_t*, const uint32_t*, int, const uint32_t*, int, uint32_t*);
+#define SEGS_INSTANTIATE_RADIX(K, BITS)                                                                                          \
+  template __global__ void radix_count_kernel<K, BITS>(const K*, int, int, uint32_t, int, uint32_t*, int, const uint32_t*, int); \
+  template __global__ void radix_scatter_kernel<K, BITS>(const K*, const uint32_t*, K*, uint32_t*, int, int, uint32_t, int,      \
+                                                         const uint32_t*, const uint32_t*, int, const uint32_t*, int, uint32_t*);
+SEGS_INSTANTIATE_RADIX(uint64_t, 8)
+SEGS_INSTANTIATE_RADIX(uint32_t, 8)
+SEGS_INSTANTIATE_RADIX(uint32_t, 9)
+#undef SEGS_INSTANTIATE_RADIX
 
 // ---------------------------------------------------------------------------------------------
 // K9 (rasterizer_impl.cu:116-138).  The range table is zeroed by make_depth_keys_kernel earlier in the same stream
@@ -462,7 +484,9 @@ __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const 
   if (n_dev) {
     const uint32_t n = *n_dev;
     if (idx == 0 && status) {   // resident mode: overflow word, and the status words mirrored into host-mapped memory
-      const uint32_t over = n > (uint32_t)L ? 1u : 0u;
+      // status[2]: preprocess_fwd_kernel saw a depth outside the resident sort's key range (see DEPTH_KEY_BITS)
+      const uint32_t over = (n > (uint32_t)L || status[2] != 0u) ? 1u : 0u;
+      status[2] = 0u;
       status[3] = over;
       if (status_mirror) { status_mirror[0] = n; status_mirror[3] = over; }
     }

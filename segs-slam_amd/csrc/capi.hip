@@ -92,12 +92,12 @@ uint32_t getHigherMsb(uint32_t n) {
 // `passes & 1` of the ping-pong pair so that the result lands in side 0.
 // drop_dead: entries whose key is all ones are left out by the FIRST pass (they take no histogram count and no rank), so
 // every later pass -- and the caller, through *n_live -- works on the survivors only: a stable partition for free.
-template <typename K>
+template <typename K, int BITS = 8>
 int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t dmin, int dbits, hipStream_t st,
                const uint32_t* n_dev = nullptr, bool drop_dead = false) {
   if (n <= 0) return SEGS_OK;
   uint32_t* n_live = (uint32_t*)(bin + L.n_live);
-  const int passes = (end_bit + 7) / 8;
+  const int passes = (end_bit + BITS - 1) / BITS;
   int side = passes & 1;
   uint32_t* block_hist = (uint32_t*)(bin + L.block_hist);
   uint32_t* digit_totals = (uint32_t*)(bin + L.digit_totals);
@@ -106,19 +106,19 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     const uint32_t* vin = (const uint32_t*)(bin + L.vals[side]);
     K* kout = (K*)(bin + L.keys[side ^ 1]);
     uint32_t* vout = (uint32_t*)(bin + L.vals[side ^ 1]);
-    const int shift = 8 * p;
+    const int shift = BITS * p;
     const int drop = drop_dead && p == 0;
     const uint32_t* n_in = (drop_dead && p > 0) ? n_live : n_dev;
     { PROF(K_RADIX_COUNT);
-    radix_count_kernel<K><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, block_hist, L.nblocks, n_in, drop);
+    radix_count_kernel<K, BITS><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, block_hist, L.nblocks, n_in, drop);
     }
     LAUNCH_TRY("radix_count_kernel");
     { PROF(K_RADIX_SCAN);
-    radix_scan_kernel<<<256, 256, 0, st>>>(block_hist, L.nblocks, digit_totals);
+    radix_scan_kernel<<<1 << BITS, 256, 0, st>>>(block_hist, L.nblocks, digit_totals);
     }
     LAUNCH_TRY("radix_scan_kernel");
     { PROF(K_RADIX_SCATTER);
-    radix_scatter_kernel<K><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, block_hist, digit_totals, L.nblocks,
+    radix_scatter_kernel<K, BITS><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, block_hist, digit_totals, L.nblocks,
                                                               n_in, drop, drop ? n_live : nullptr);
     }
     LAUNCH_TRY("radix_scatter_kernel");
@@ -145,7 +145,7 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
                    const float* scales, float mod, const float* rots, const float* cov3D_precomp, const float* view,
                    const float* proj, float tan_fovx, float tan_fovy, int* radii, const float* shs, int D, int M,
                    const float* cam_pos, hipStream_t st, uint32_t* depth_keys = nullptr, uint32_t* depth_vals = nullptr,
-                   uint2* ranges = nullptr, uint32_t extra_flags = 0u) {
+                   uint2* ranges = nullptr, uint32_t extra_flags = 0u, uint32_t* depth_overflow = nullptr) {
   const float focal_y = H / (2.0f * tan_fovy);   // rasterizer_impl.cu:221-222
   const float focal_x = W / (2.0f * tan_fovx);
   const uint32_t gx = (W + TILE_X - 1) / TILE_X, gy = (H + TILE_Y - 1) / TILE_Y;
@@ -153,7 +153,8 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
   preprocess_fwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, scales, mod, rots, opac, colors, cov3D_precomp, view,
                                                      proj, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, radii,
                                                      G.rec(), G.bin(), G.block_sums(), G.block_sums() + (G.L.nblocks + 1), shs, D, M, cam_pos,
-                                                     G.clamped(), g_flags | extra_flags, depth_keys, depth_vals, ranges, (int)(gx * gy));
+                                                     G.clamped(), g_flags | extra_flags, depth_keys, depth_vals, ranges, (int)(gx * gy),
+                                                     depth_overflow);
   }
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
@@ -167,18 +168,20 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
 // `total_out` (3 device words) receives the instance count produced by the depth-ordered scan.
 int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSortLayout& GS, uint2* ranges, int P, int n_cap,
                 const uint32_t* n_dev, uint32_t dmin, int dbits, uint32_t dcull, uint32_t gx, uint32_t gy, uint32_t* total_out,
-                hipStream_t st, bool depth_keys_ready = false, bool drop_dead = false) {
+                hipStream_t st, bool depth_keys_ready = false, bool drop_dead = false, bool nine_bit_depth = false) {
   const int bit = (int)getHigherMsb(gx * gy);
   // (1)
   char* gbin = bin + GS.base;
   const BinningLayout& GL = GS.inner;
-  const int gside = ((dbits + 7) / 8) & 1;  // depth keys in [dmin, dcull], dcull - dmin < 2^dbits; culled Gaussians carry dcull
+  // depth keys in [dmin, dcull], dcull - dmin < 2^dbits; culled Gaussians carry dcull
+  const int gside = (nine_bit_depth ? (dbits + 8) / 9 : (dbits + 7) / 8) & 1;
   if (!depth_keys_ready) { PROF(K_DUPLICATE);
   make_depth_keys_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), dcull, (uint32_t*)(gbin + GL.keys[gside]), (uint32_t*)(gbin + GL.vals[gside]),
                                                       ranges, (int)(gx * gy));
   }
   LAUNCH_TRY("make_depth_keys_kernel");
-  int rc = sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st);
+  int rc = nine_bit_depth ? sort_pairs<uint32_t, 9>(gbin, GL, P, dbits, dmin, dbits, st)
+                          : sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st);
   if (rc) return rc;
   const uint32_t* order = (const uint32_t*)(gbin + GL.vals[0]);
   // (2)
@@ -296,7 +299,8 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
     int dbits = 1;
     while (dbits < 32 && (dspan >> dbits) != 0u) dbits++;
     uint32_t* total_scratch = (uint32_t*)(bin + GS.block_sums) + G.L.nblocks;
-    int rc = run_binning(G, bin, BL, GS, ranges, P, R, nullptr, dmin, dbits, dmin + dspan, gx, gy, total_scratch, st);
+    const bool nine = (dbits + 8) / 9 < (dbits + 7) / 8;   // e.g. the usual 26 bits: three 9-bit passes instead of four 8-bit ones
+    int rc = run_binning(G, bin, BL, GS, ranges, P, R, nullptr, dmin, dbits, dmin + dspan, gx, gy, total_scratch, st, false, false, nine);
     if (rc) return rc;
   }
   { PROF(K_RENDER_FWD);
@@ -535,20 +539,21 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
   const GaussSortLayout GS = gauss_sort_layout(capacity, P);
   if (!radii) radii = G.radii_internal();
   uint2* ranges = (uint2*)(img + IL.ranges);
-  // The depth keys are sorted on all 32 bits (the exact range is only known on the device; positive finite floats stay
-  // below the culled key 0xFFFFFFFF), so K1 can write them -- and zero the range table -- itself: one launch less.
+  // The exact depth range is only known on the device, so K1 writes the raw depth bits as keys -- and zeroes the range
+  // table -- itself (one launch less) and the sort looks at DEPTH_KEY_BITS = 27 bits above the near plane's pattern in
+  // three 9-bit passes (see kernels.h); Gaussians that own no instance carry the last key of that range.
   char* gbin = bin + GS.base;
-  const int gside = (4 & 1);   // 32 key bits = 4 byte passes: the sort starts from side 0 (see sort_pairs)
+  const int gside = (3 & 1);   // three passes: the sort starts from side 1 (see sort_pairs)
   int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales, scale_modifier,
                           rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M, cam_pos, st,
                           (uint32_t*)(gbin + GS.inner.keys[gside]), (uint32_t*)(gbin + GS.inner.vals[gside]), ranges,
-                          (g_flags & SEGS_RASTER_KEEP_DEAD_INSTANCES) ? 0u : PREPROCESS_TIGHT_RECT);
+                          (g_flags & SEGS_RASTER_KEEP_DEAD_INSTANCES) ? 0u : PREPROCESS_TIGHT_RECT, status + 2);
   if (rc) return rc;
   // dead instances (no quadrant of their tile can reach alpha >= 1/255: 43 % of them at 500 k Gaussians / 1080p) are
   // dropped by the first tile-id pass; lists, ranges and n_contrib then count live entries only -- an internal contract
   // between this forward and its backward, like the reference's own scratch layout
-  rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, 0u, 32, 0xFFFFFFFFu, gx, gy, status, st, true,
-                   (g_flags & SEGS_RASTER_KEEP_DEAD_INSTANCES) == 0u);
+  rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, DEPTH_KEY_MIN, DEPTH_KEY_BITS, 0xFFFFFFFFu, gx, gy, status, st, true,
+                   (g_flags & SEGS_RASTER_KEEP_DEAD_INSTANCES) == 0u, true);
   if (rc) return rc;
   // status[3] (overflow) and the host mirror are written by identify_tile_ranges_kernel at the end of run_binning
   { PROF(K_RENDER_FWD);

@@ -88,6 +88,7 @@ inline ImageLayout image_layout(int W, int H) {
 constexpr int SORT_ITEMS_PER_THREAD = 8;
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_TILE = SORT_ITEMS_PER_THREAD * SORT_THREADS;  // 2048 items per workgroup
+constexpr int SORT_MAX_DIGITS = 512;                             // count-matrix rows: 8-bit passes use 256 of them, 9-bit passes all
 
 struct BinningLayout {
   size_t keys[2], vals[2], block_hist, digit_totals, n_live, total;
@@ -102,8 +103,8 @@ inline BinningLayout binning_layout(int R) {
   size_t o = 0;
   for (int i = 0; i < 2; i++) { b.keys[i] = o; o = align_up(o + (size_t)R * 8); }
   for (int i = 0; i < 2; i++) { b.vals[i] = o; o = align_up(o + (size_t)R * 4); }
-  b.block_hist = o;   o = align_up(o + (size_t)256 * (b.nblocks > 0 ? b.nblocks : 1) * 4);
-  b.digit_totals = o; o = align_up(o + 256 * 4);
+  b.block_hist = o;   o = align_up(o + (size_t)SORT_MAX_DIGITS * (b.nblocks > 0 ? b.nblocks : 1) * 4);
+  b.digit_totals = o; o = align_up(o + SORT_MAX_DIGITS * 4);
   b.n_live = o;       o = align_up(o + 4);   // entries left after the first pass dropped the dead keys (sort_pairs)
   b.total = o + ALIGN;
   return b;

@@ -20,7 +20,11 @@ __global__ void preprocess_fwd_kernel(
     int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
     uint32_t* __restrict__ depth_range, const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos,
     uint32_t* __restrict__ clamped, uint32_t flags, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ depth_vals,
-    uint2* __restrict__ ranges, int num_tiles);
+    uint2* __restrict__ ranges, int num_tiles, uint32_t* __restrict__ depth_overflow);
+// Resident depth sort: every binned Gaussian has view depth > 0.2 (auxiliary.h:155), so its float bits exceed those of
+// 0.2f; 27 bits above that (16 binades: depths below 13 107.2) are sorted in three 9-bit passes.
+constexpr uint32_t DEPTH_KEY_MIN = 0x3E4CCCCDu;   // bits of 0.2f
+constexpr int DEPTH_KEY_BITS = 27;
 
 __global__ void visible_filter_kernel(
     int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
@@ -54,11 +58,11 @@ __global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restri
                                            const uint32_t* __restrict__ n_dev, int mark_dead);
 constexpr uint32_t PREPROCESS_TIGHT_RECT = 0x80000000u;   // internal flag bit of preprocess_fwd_kernel (resident forward)
 constexpr uint32_t DEAD_KEY = 0xFFFFFFFFu;   // tile-id key of an instance that reaches no quadrant of its tile
-template <typename K>   // K = uint32_t (the pipeline's own sorts) or uint64_t (segs_sort_pairs)
+template <typename K, int BITS>   // K = uint32_t (the pipeline's own sorts) or uint64_t (segs_sort_pairs); BITS per digit: 8 or 9
 __global__ void radix_count_kernel(const K* __restrict__ keys, int n, int shift, uint32_t dmin, int dbits,
                                    uint32_t* __restrict__ block_hist, int nblocks, const uint32_t* __restrict__ n_dev, int drop_dead);
 __global__ void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_totals);
-template <typename K>
+template <typename K, int BITS>
 __global__ void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                      K* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
                                      uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_totals, int nblocks,

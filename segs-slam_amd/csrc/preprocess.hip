@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     uint32_t* __restrict__ depth_range /* per workgroup: [b] = max(depth_bits), [nblocks + b] = max(~depth_bits), visible only */,
     const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, uint32_t* __restrict__ clamped,
     uint32_t flags, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ depth_vals, uint2* __restrict__ ranges,
-    int num_tiles) {
+    int num_tiles, uint32_t* __restrict__ depth_overflow /* resident: set when a binned depth leaves the 27-bit key range */) {
   __shared__ float lds[768];
   __shared__ uint32_t wave_sums[4], wave_dmax[4], wave_dnmin[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -363,8 +363,14 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     radii[idx] = g.radius;
     reinterpret_cast<uint4*>(bin)[idx] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
     if (depth_keys) {   // resident mode: what make_depth_keys_kernel would write (32-bit depth keys, culled = 0xFFFFFFFF)
-      depth_keys[idx] = b.tiles_touched ? b.depth_bits : 0xFFFFFFFFu;
+      // The resident depth sort looks at DEPTH_KEY_BITS bits above the near plane's bit pattern (three 9-bit passes).
+      // Gaussians without instances take the largest key of that range so that they sort to the END (the emitter relies
+      // on every owner inside a slot range having at least one instance); a binned depth that reaches it -- beyond
+      // 0.2 * 2^16 = 13 107 -- would alias: flag the step, the host redoes it through the exact path.
+      constexpr uint32_t KEY_LAST = DEPTH_KEY_MIN + ((1u << DEPTH_KEY_BITS) - 1u);
+      depth_keys[idx] = b.tiles_touched ? b.depth_bits : KEY_LAST;
       depth_vals[idx] = (uint32_t)idx;
+      if (depth_overflow && b.tiles_touched && (b.depth_bits - DEPTH_KEY_MIN) >= ((1u << DEPTH_KEY_BITS) - 1u)) *depth_overflow = 1u;
     }
   }
   if (ranges)
