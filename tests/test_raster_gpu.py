@@ -297,3 +297,34 @@ def test_resident_engine_matches_sync_path():
     for k in g0:
         assert_grad_close(k, g1[k], g0[k])
         assert_grad_close(k, g2[k], g0[k])
+
+
+def test_resident_depth_key_range_overflow_falls_back_to_the_exact_path():
+    """The resident depth sort covers view depths below 0.2 * 2^16 = 13 107 (27 key bits above the near plane).  A binned
+    Gaussian beyond that flags the step like a capacity overflow; the next forward goes through the synchronising path,
+    whose sort uses the exact host-known depth range."""
+    from segs_slam_amd.raster_engine import RasterEngine
+    sc = scenes.make_scene(2000, 160, 96, 140.0, 140.0, seed=23)
+    sc.means3D[:5] = [[0.0, 0.0, 20000.0], [300.0, 0.0, 21000.0], [-300.0, 100.0, 15000.0], [0.0, -200.0, 30000.0], [10.0, 10.0, 14000.0]]
+    sc.scales[:5] = 400.0
+    sc.opacity[:5] = 0.9
+    cam = sc.camera
+    a = [_t(x) for x in (sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, sc.rotations, cam.world_view_transform,
+                         cam.full_proj_transform, cam.camera_center)]
+    ref = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=False)
+    want = ref.forward(*a, cam.tanfovx, cam.tanfovy).clone()
+    assert int((ref.radii[:5] > 0).sum()) >= 3          # the far Gaussians are really binned
+    eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=True)
+    img = eng.forward(*a, cam.tanfovx, cam.tanfovy).clone()          # calibrating call: synchronising path
+    assert torch.equal(img, want) and eng.check(raise_on_overflow=False)
+    eng.forward(*a, cam.tanfovx, cam.tanfovy)                        # resident call: out-of-range depth -> flagged
+    assert eng._last_resident and eng.check(raise_on_overflow=False) is False
+    img = eng.forward(*a, cam.tanfovx, cam.tanfovy).clone()          # redone through the exact path
+    assert not eng._last_resident and torch.equal(img, want)
+    # a scene inside the range is not flagged
+    sc.means3D[:5, 2] = 5000.0
+    a[1] = _t(sc.means3D)
+    eng2 = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=True)
+    for _ in range(3):
+        eng2.forward(*a, cam.tanfovx, cam.tanfovy)
+    assert eng2._last_resident and eng2.check(raise_on_overflow=False)
