@@ -96,6 +96,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension must be built (python -c 'import __graft_entry__ as g; "
                 "g.build()' or make -C segs-slam_amd/csrc). There is no CPU fallback.")
+        # PyTorch first: its wheel bundles its own libamdhip64; loaded afterwards, torch would bring a SECOND HIP runtime into
+        # the process next to the system one this library resolved, and launches from here then fail with "no ROCm-capable
+        # device is detected".  With torch loaded first the loader binds this library to the runtime torch already uses.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             try:
