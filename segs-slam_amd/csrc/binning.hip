@@ -157,12 +157,14 @@ __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const BinIn
   if (total_out && blockIdx.x == gridDim.x - 1 && tid == 255) total_out[0] = base + x;   // R = inclusive total
 }
 
-// The emitter is parallel over OUTPUT slots, not over Gaussians: workgroup b owns instances [b*1024, (b+1)*1024) of the
+// The emitter is parallel over OUTPUT slots, not over Gaussians: workgroup b owns instances [b*512, (b+1)*512) of the
 // unsorted list, finds the Gaussians (in depth order) that own them by binary search in the inclusive offsets, stages
 // those owners once in LDS and lets every lane resolve its slot with an LDS binary search ("load-balanced search").
 // A Gaussian covering thousands of tiles is thereby spread over many workgroups instead of serialising one wave,
 // and all 12-byte pairs leave as coalesced stores.
-constexpr int EMIT_SLOTS = 1024;
+// 512 slots: 25 KB of LDS per workgroup -> 6 workgroups per CU.  1024 slots (49 KB, 3 per CU) left the LDS binary searches
+// without cover: 40 us against 34 us at 2.6 M instances; 256 slots pay the two global owner searches too often (40 us).
+constexpr int EMIT_SLOTS = 512;
 // First index g in [0, n) with a[g] > key (STRICT) or a[g] >= key, n if none; `a` ascending.  64-ary search by one wave:
 // every round the 64 lanes probe 64 evenly spaced elements at once and a ballot picks the segment (4 rounds of one
 // parallel load for n = 500 k instead of 19 dependent loads: the emitter workgroups were latency-bound on this search).

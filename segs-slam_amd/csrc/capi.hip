@@ -197,7 +197,7 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   }
   LAUNCH_TRY("ordered_offsets_kernel");
   { PROF(K_DUPLICATE);
-  duplicate_with_keys_kernel<<<(n_cap + 1023) / 1024, 256, 0, st>>>(P, n_cap, G.bin(), G.rec(), order, G.offsets(),
+  duplicate_with_keys_kernel<<<(n_cap + 511) / 512, 256, 0, st>>>(P, n_cap, G.bin(), G.rec(), order, G.offsets(),
                                                                     (uint32_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev,
                                                                     drop_dead ? 1 : 0);
   }
