@@ -103,3 +103,33 @@ def test_full_size_parity_against_oracle(workload):
     o, g = run_parity(sc, backward=True)
     if workload == "c2_1080p":
         assert o.R == 3744721 and int((g["radii"] > 0).sum()) == 356695      # the numbers quoted with every bench line
+
+
+@pytest.mark.parametrize("workload", ["c2_1080p", "1080p_3m"])
+def test_resident_path_matches_the_reference_shaped_path_at_full_size(workload):
+    """What bench.py times (resident entry points: tight binning, dead instances dropped in the first tile pass, 9-bit depth
+    sort) against the reference-shaped entry points the oracle test above pins: same image and radii bit for bit, same
+    gradients within the float-atomic tolerance, fewer instances binned."""
+    from segs_slam_amd import scenes
+    from segs_slam_amd.raster_engine import RasterEngine
+    from test_raster_gpu import _t, assert_grad_close
+    sc = scenes.make_config_scene(workload)
+    cam = sc.camera
+    a = [_t(x) for x in (sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, sc.rotations, cam.world_view_transform,
+                         cam.full_proj_transform, cam.camera_center)]
+    dL = _t(sc.dL_dout_color)
+    res = []
+    for resident in (False, True):
+        eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=resident)
+        for _ in range(2):
+            img = eng.forward(*a, cam.tanfovx, cam.tanfovy).clone()
+            eng.backward(dL)
+        assert eng.check() and eng._last_resident == resident
+        torch.cuda.synchronize()
+        res.append((img, eng.radii.clone(), eng.R, {k: v.cpu().numpy().copy() for k, v in eng.grads.items()},
+                    eng.dL_dmean2D.cpu().numpy().copy()))
+    (i0, r0, R0, g0, m0), (i1, r1, R1, g1, m1) = res
+    assert torch.equal(i0, i1) and torch.equal(r0, r1) and 0 < R1 < R0
+    for k in g0:
+        assert_grad_close(k, g1[k], g0[k])
+    assert_grad_close("dL_dmean2D", m1, m0)        # what the densification statistics read
