@@ -143,7 +143,9 @@ int segs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* 
  * (hipGraph-capturable).  The caller owns all scratch: geom_buffer >= segs_geometry_bytes(P), image_buffer >=
  * segs_image_bytes(W,H), binning_buffer >= segs_resident_binning_bytes(P, capacity) where `capacity` bounds the number of
  * (Gaussian, tile) instances.  `status` is 4 device words: [0] = num_rendered R, [3] = 1 if R exceeded the capacity
- * (outputs of that call are then meaningless; re-run with a larger capacity).  The reference has no counterpart: its
+ * (outputs of that call are then meaningless; re-run with a larger capacity).  geom_buffer must be ZERO-FILLED before its
+ * first use: the resident backward does not clear the per-Gaussian gradient accumulators inside it with a fill per call,
+ * it writes zeros back over each row it consumes (a buffer that is clean stays clean).  The reference has no counterpart: its
  * forward always blocks on a device-to-host copy of R (rasterizer_impl.cu:281). */
 size_t segs_resident_binning_bytes(int P, int capacity);
 int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity,

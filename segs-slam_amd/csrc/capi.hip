@@ -312,14 +312,17 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   return SEGS_OK;
 }
 
-int segs_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height,
-                            const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+// self_clean (resident entry point): the per-Gaussian accumulator rows are not cleared by a memset before the tile kernel;
+// preprocess_bwd_kernel writes zeros back over every row it consumes, so a buffer that starts out zero-filled is clean
+// again after every backward (one 32 MB fill and its launch less per iteration).
+static int rasterize_backward_impl(int P, int D, int M, int R, const float* background, int width, int height,
+                            const float* means3D, const float* shs, const float* scales,
                             float scale_modifier, const float* rotations, const float* cov3D_precomp,
                             const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
                             float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
                             const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream) {
-  (void)colors_precomp;
+                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream,
+                            bool self_clean) {
   hipStream_t st = (hipStream_t)stream;
   if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad sizes");
   if (P == 0) return SEGS_OK;  // src/rasterize_points.cu:159
@@ -339,7 +342,7 @@ int segs_rasterize_backward(int P, int D, int M, int R, const float* background,
   const uint32_t gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
   const float focal_y = height / (2.0f * tan_fovy), focal_x = width / (2.0f * tan_fovx);  // rasterizer_impl.cu:436-437
 
-  { PROF(K_MEMSET);
+  if (!self_clean) { PROF(K_MEMSET);
   HIP_TRY(hipMemsetAsync(G.gacc(), 0, (size_t)P * GACC_DWORDS * 4, st));
   }
   if (R > 0) {
@@ -354,10 +357,25 @@ int segs_rasterize_backward(int P, int D, int M, int R, const float* background,
   preprocess_bwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, radii, cov3D_precomp ? nullptr : scales, rotations,
                                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
                                                      tan_fovx, tan_fovy, G.gacc(), G.rec(), (float)width, (float)height, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                                                     dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, shs, D, M, campos, G.clamped(), dL_dsh);
+                                                     dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, shs, D, M, campos, G.clamped(), dL_dsh,
+                                                     self_clean ? 1 : 0);
   }
   LAUNCH_TRY("preprocess_bwd_kernel");
   return SEGS_OK;
+}
+
+int segs_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                            const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                            float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                            const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                            float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                            const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                            float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream) {
+  (void)colors_precomp;
+  return rasterize_backward_impl(P, D, M, R, background, width, height, means3D, shs, scales, scale_modifier, rotations,
+                                 cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
+                                 image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+                                 dL_dscale, dL_drot, stream, false);
 }
 
 int segs_visible_filter(int P, int M, int width, int height, const float* means3D, const float* scales,
@@ -453,7 +471,7 @@ int segs_debug_preprocess_backward(int P, int width, int height, const float* me
                                                          scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
                                                          tan_fovx, tan_fovy, nullptr, nullptr, (float)width, (float)height, const_cast<float*>(dL_dmean2D),
                                                          const_cast<float*>(dL_dconic), nullptr, nullptr, dL_dmean3D, dL_dcov3D,
-                                                         dL_dscale, dL_drot, nullptr, 0, 0, nullptr, nullptr, nullptr);
+                                                         dL_dscale, dL_drot, nullptr, 0, 0, nullptr, nullptr, nullptr, 0);
   LAUNCH_TRY("preprocess_bwd_kernel");
   return SEGS_OK;
 }
@@ -571,11 +589,12 @@ int segs_rasterize_backward_resident(char* geom_buffer, char* binning_buffer, ch
                                      float tan_fovy, const int* radii, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic,
                                      float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                                      float* dL_dscale, float* dL_drot, void* stream) {
-  // identical to segs_rasterize_backward except that the scratch layout is keyed by the capacity, not by R
-  return segs_rasterize_backward(P, D, M, capacity, background, width, height, means3D, shs, nullptr, scales, scale_modifier, rotations,
+  // identical to segs_rasterize_backward except that the scratch layout is keyed by the capacity, not by R, and that the
+  // accumulator rows of geom_buffer are kept clean by the backward itself (the buffer must start out zero-filled)
+  return rasterize_backward_impl(P, D, M, capacity, background, width, height, means3D, shs, scales, scale_modifier, rotations,
                                  cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
                                  image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
-                                 dL_dscale, dL_drot, stream);
+                                 dL_dscale, dL_drot, stream, true);
 }
 
 // ---- measurement support (bench.py): HIP events recorded on the launch stream around selected kernels.

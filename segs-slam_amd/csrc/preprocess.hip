@@ -431,12 +431,12 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ scales,
     const float* __restrict__ rotations, float mod, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ view, const float* __restrict__ proj, float h_x, float h_y, float tan_fovx, float tan_fovy,
-    const float* __restrict__ gacc, const float* __restrict__ rec_in, float img_w, float img_h,
+    float* __restrict__ gacc, const float* __restrict__ rec_in, float img_w, float img_h,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
     const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, const uint32_t* __restrict__ clamped,
-    float* __restrict__ dL_dsh) {
+    float* __restrict__ dL_dsh, int clean_gacc /* write zeros back over the consumed accumulator row (resident backward) */) {
   __shared__ float lds[768];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const float3 mean = load_row3(means3D, P, lds);
@@ -455,6 +455,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     const float4* a = reinterpret_cast<const float4*>(gacc + (size_t)idx * GACC_DWORDS);
     const float4 a0 = a[0], a1 = a[1];
     const float a8 = gacc[(size_t)idx * GACC_DWORDS + 8];
+    if (clean_gacc && radii[idx] > 0) {   // only binned Gaussians' rows can have been touched by the tile kernel
+      float4* z = reinterpret_cast<float4*>(gacc + (size_t)idx * GACC_DWORDS);
+      z[0] = make_float4(0.f, 0.f, 0.f, 0.f); z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      gacc[(size_t)idx * GACC_DWORDS + 8] = 0.f;
+    }
     float dop = 0.f;
     g2x = 0.f; g2y = 0.f; gcx = 0.f; gcy = 0.f; gcw = 0.f;
     if (radii[idx] > 0) {

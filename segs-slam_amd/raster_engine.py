@@ -87,7 +87,8 @@ class RasterEngine:
         # are launched over the capacity, surplus workgroups cost about 2 us per launch.
         self.capacity = int(R * (1.5 if self.flags & 2 else 1.25)) + 65536
         dev = self.device
-        self._geom_r = torch.empty(self._lib.segs_geometry_bytes(self.P), dtype=torch.uint8, device=dev)
+        # zero-filled: the resident backward keeps the accumulator rows inside clean itself instead of a fill per iteration
+        self._geom_r = torch.zeros(self._lib.segs_geometry_bytes(self.P), dtype=torch.uint8, device=dev)
         self._img_r = torch.empty(self._lib.segs_image_bytes(self.W, self.H), dtype=torch.uint8, device=dev)
         self._bin_r = torch.empty(self._lib.segs_resident_binning_bytes(self.P, self.capacity), dtype=torch.uint8, device=dev)
         self._status = torch.zeros(4, dtype=torch.int32, device=dev)

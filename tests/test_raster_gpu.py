@@ -287,6 +287,11 @@ def test_resident_engine_matches_sync_path():
         eng.check()
         torch.cuda.synchronize()
         assert (not resident) or (eng.capacity > eng.R > 0 and eng._last_resident)
+        if resident:   # a second backward on the same forward state: the self-cleaning accumulators start from zero again
+            first = {k: v.cpu().numpy().copy() for k, v in eng.grads.items()}
+            eng.backward(dL)
+            for k, v in eng.grads.items():
+                assert_grad_close(k, v.cpu().numpy(), first[k])
         outs.append((img.cpu().numpy(), eng.radii.cpu().numpy(), eng.R, eng.dL_dcov3D.cpu().numpy().copy(),
                      {k: v.cpu().numpy().copy() for k, v in eng.grads.items()}))
     (i0, r0, R0, c0, g0), (i1, r1, R1, c1, g1), (i2, r2, R2, c2, g2) = outs
