@@ -82,3 +82,31 @@ def test_sh_gpu_matches_oracle(deg):
     for got, key in ((grads[5], "dL_dsh"), (grads[3], "dL_dmean3D"), (grads[6], "dL_dscale"), (grads[2], "dL_dopacity")):
         g, r = got.cpu().numpy(), ref[key]
         assert np.all(np.abs(g - r) <= 1e-4 * np.abs(r) + 1e-5 * np.abs(r).max()), key
+
+
+@pytest.mark.gpu
+def test_project2_image_matches_oracle():
+    """RasterizeGaussiansprojectCUDA (src/rasterize_points.cu:282-360 -> Rasterizer::project2_image,
+    rasterizer_impl.cu:494-585 -> projectCUDA, forward.cu:573-673): per-Gaussian pixel position, radius and colour.  The
+    reference leaves rows of rejected Gaussians uninitialised, so only radii > 0 rows are compared (bit-exact)."""
+    from segs_slam_amd import rasterize_points as rp
+    DEV = "cuda:0"
+    sc, sh, _ = _scene(5000, 2, 91)
+    cam = sc.camera
+    o = _oracle(sc, sh, 2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    e = torch.empty(0, device=DEV)
+    bg, m3, op, sca, rot, tsh = t(sc.bg), t(sc.means3D), t(sc.opacity), t(sc.scales), t(sc.rotations), t(sh)
+    view, proj, campos = t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center)
+    pts, radii, col = rp.RasterizeGaussiansprojectCUDA(bg, m3, e, op, sca, rot, 1.0, e, view, proj, cam.tanfovx, cam.tanfovy,
+                                                       cam.height, cam.width, tsh, 2, campos, False)
+    vis = o.get("radii") > 0
+    assert vis.sum() > 1000 and np.array_equal(radii.cpu().numpy(), o.get("radii"))
+    assert np.array_equal(pts.cpu().numpy()[vis].view(np.uint32), o.get("means2D")[vis].view(np.uint32))
+    assert np.array_equal(col.cpu().numpy()[vis].view(np.uint32), o.get("rgb")[vis].view(np.uint32))
+    # precomputed colours: positions and radii are unchanged
+    pts2, radii2, _ = rp.RasterizeGaussiansprojectCUDA(bg, m3, t(sc.colors), op, sca, rot, 1.0, e, view, proj, cam.tanfovx,
+                                                       cam.tanfovy, cam.height, cam.width, e, 0, campos, False)
+    assert torch.equal(radii2, radii) and torch.equal(pts2[t(vis)], pts[t(vis)])
+    with pytest.raises(RuntimeError):
+        rp.RasterizeGaussiansprojectCUDA(bg, torch.zeros(4, 2, device=DEV), e, e, e, e, 1.0, e, view, proj, 1.0, 1.0, 8, 8, e, 0, campos, False)
