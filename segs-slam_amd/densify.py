@@ -71,7 +71,7 @@ class AnchorDensifier:
         _capi.check(st, "segs_training_statis")
 
     # ---- adjust_anchor ---------------------------------------------------------------------------------------------
-    def _append(self, new_anchor: torch.Tensor, new_feat: torch.Tensor, cur_size: float):
+    def _append(self, new_anchor: torch.Tensor, new_feat: torch.Tensor, cur_size: float, new_scaling: Optional[torch.Tensor] = None):
         """:1623-1696: concatenate the new rows to the six tensors, zero-extend the Adam moments and the counters."""
         m = self.model
         n_new = new_anchor.shape[0]
@@ -87,13 +87,31 @@ class AnchorDensifier:
         m.param("anchor")[A0:A1] = new_anchor
         m.param("offset")[A0:A1] = 0
         m.param("anchor_feat")[A0:A1] = new_feat
-        m.param("scaling")[A0:A1] = torch.log(torch.ones((n_new, 6), dtype=torch.float32, device=m.device) * cur_size)
+        m.param("scaling")[A0:A1] = (torch.log(torch.ones((n_new, 6), dtype=torch.float32, device=m.device) * cur_size)
+                                     if new_scaling is None else new_scaling)
         m.rotation[A0:A1] = 0
         m.rotation[A0:A1, 0] = 1.0
         x = 0.1 * torch.ones((n_new, 1), dtype=torch.float32, device=m.device)
         m.opacity[A0:A1] = torch.log(x / (1 - x))
         self._stats["anchor_demon"][A0:A1] = 0
         self._stats["opacity_accum"][A0:A1] = 0
+
+    def increase_pcd(self, points: torch.Tensor) -> int:
+        """GaussianModel::increasePcd (src/gaussian_model.cpp:443-520): new anchors at the voxel centres of `points` (N,3)
+        -- unique among themselves, NOT checked against the existing anchors, like the reference -- with zero offsets and
+        features, scales from the mean squared distance to the 3 nearest new voxels, zero counters and zero Adam moments
+        (densificationPostfix).  Returns the number of anchors added."""
+        from .neural_gaussians import anchors_from_points
+        if points.numel() == 0:
+            return 0
+        m = self.model
+        anchor, scaling = anchors_from_points(points.to(m.device, torch.float32), self.p.voxel_size)
+        n_new = anchor.shape[0]
+        A0, no = m.A, m.dims.n_offsets
+        self._append(anchor, torch.zeros((n_new, m.dims.feat_dim), dtype=torch.float32, device=m.device), 0.0, scaling)
+        self._stats["offset_denom"][A0 * no:m.A * no] = 0
+        self._stats["offset_gradient_accum"][A0 * no:m.A * no] = 0
+        return n_new
 
     def anchor_growing(self, grads: torch.Tensor, threshold: float, offset_mask: torch.Tensor, rands: List[torch.Tensor]):
         """:1559-1699.  grads (A_init*no,), offset_mask (A_init*no,) bool, rands[i] (A_init*no,) in [0,1)."""

@@ -492,6 +492,47 @@ class ScaffoldTrainerStep:
         return loss
 
 
+def init_mlps(dims: ModelDims, generator: torch.Generator) -> Dict[str, torch.Tensor]:
+    """torch::nn::Linear's default initialisation (U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases) of the
+    Sequential MLPs built in GaussianModel's constructor (src/gaussian_model.cpp:60-150).  The reference draws from
+    LibTorch's global generator; any seeded stream of the same distribution stands for it."""
+    import math
+    mlp = {}
+    for name in dims.mlp_tensor_names():
+        shape = dims.mlp_tensor_shape(name)
+        fan_in = shape[1] if len(shape) == 2 else dims.mlp_tensor_shape(name.replace(".bias", ".weight"))[1]
+        mlp[name] = (torch.rand(*shape, generator=generator) * 2 - 1) / math.sqrt(fan_in)
+    return mlp
+
+
+def anchors_from_points(points: torch.Tensor, voxel_size: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Shared head of createFromPcd / increasePcd (src/gaussian_model.cpp:343-361, 455-470): voxel centres
+    unique_dim(round(points / voxel_size)) * voxel_size in lexicographic order, and log(sqrt(clamp_min(distCUDA2, 1e-7)))
+    repeated over the 6 scaling columns.  `points` (N,3) float32 on the GPU."""
+    from .points import distCUDA2
+    fused = (torch.unique(torch.round(points / voxel_size), dim=0, sorted=True) * voxel_size).to(torch.float32).contiguous()
+    dist2 = torch.clamp_min(distCUDA2(fused), 0.0000001)
+    scaling = torch.log(torch.sqrt(dist2)).unsqueeze(1).repeat(1, 6)
+    return fused, scaling
+
+
+def create_from_pcd(points: torch.Tensor, dims: ModelDims, voxel_size: float, device, capacity: Optional[int] = None,
+                    mlp_seed: int = 0) -> ScaffoldModel:
+    """GaussianModel::createFromPcd (src/gaussian_model.cpp:327-381): anchors at the occupied voxels of the point cloud,
+    zero offsets and features, isotropic log-scales from simple-knn, identity rotations, opacity inverse_sigmoid(0.1),
+    freshly initialised MLPs."""
+    points = points.to(device, torch.float32)
+    anchor, scaling = anchors_from_points(points, voxel_size)
+    A = anchor.shape[0]
+    model = ScaffoldModel(A, dims, device, capacity)
+    zeros = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)  # noqa: E731
+    model.load(anchor, zeros(A, dims.n_offsets, 3), zeros(A, dims.feat_dim), scaling,
+               init_mlps(dims, torch.Generator().manual_seed(0x5E65 + mlp_seed)))
+    x = 0.1 * torch.ones((A, 1), dtype=torch.float32, device=device)
+    model.opacity[:A] = torch.log(x / (1 - x))          # general_utils::inverse_sigmoid
+    return model
+
+
 def synthetic_model(A: int, dims: ModelDims, cam, device, seed: int = 0) -> ScaffoldModel:
     """Seeded synthetic anchors inside the frustum of `cam` (a scenes.Camera at the origin looking down +z) with
     torch::nn::Linear-style uniform MLP init: the mapper-loop workload of SURVEY 8d config 3 (no dataset in the image).

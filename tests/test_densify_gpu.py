@@ -164,3 +164,60 @@ def test_trainer_survives_a_map_pruned_to_nothing():
         loss = step.training_once([kf], [gt])
     torch.cuda.synchronize()
     assert abs(float(loss) - (0.8 * 0.4 + 0.2 * 1.0)) < 0.05      # L1 = 0.4 against zeros, SSIM ~ 0
+
+
+def test_create_from_pcd_and_increase_pcd_match_restatement():
+    """GaussianModel::createFromPcd / increasePcd (src/gaussian_model.cpp:327-381, 443-520) restated on the CPU: voxel centres
+    by torch.unique over round(points / voxel_size), scales from the oracle's simple-knn (tests/test_points.py pins the GPU
+    kernel to it bit for bit)."""
+    from oracle import gs_oracle
+    from segs_slam_amd import densify, neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    vs = 0.05
+    pts = torch.rand(6000, 3, generator=g) * torch.tensor([2.0, 1.5, 1.0]) + torch.tensor([-1.0, -0.75, 2.0])
+    pts = torch.cat([pts, pts[:1500] + 0.004])                 # near-duplicates: many land in an occupied voxel
+
+    def restate(p):
+        u = (torch.unique(torch.round(p / vs), dim=0, sorted=True) * vs).to(torch.float32)
+        d2 = torch.from_numpy(gs_oracle.knn_mean_dist2(u.numpy())).clamp_min(0.0000001)
+        return u, torch.log(torch.sqrt(d2)).unsqueeze(1).repeat(1, 6)
+
+    model = ng.create_from_pcd(pts, ng.ModelDims(), vs, dev)
+    u, sc = restate(pts)
+    A = u.shape[0]
+    assert model.A == A and A < pts.shape[0]
+    assert torch.equal(model.param("anchor").cpu(), u)
+    assert torch.allclose(model.param("scaling").cpu(), sc, rtol=1e-6, atol=1e-6)
+    assert float(model.param("offset").abs().max()) == 0.0 and float(model.param("anchor_feat").abs().max()) == 0.0
+    assert torch.allclose(model.opacity[:A].cpu(), torch.full((A, 1), float(np.log(0.1 / 0.9))), atol=1e-6)
+    assert torch.equal(model.rotation[:A].cpu(), torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(A, 1))
+    w = model.param("mlp_cov.0.weight")
+    assert float(w.abs().max()) <= 1.0 / np.sqrt(w.shape[1]) and float(w.abs().max()) > 0.0      # nn::Linear's default range
+
+    # increasePcd: new voxels appended (unique among themselves only), counters and Adam moments of the new rows zero
+    dens = densify.AnchorDensifier(model, densify.DensifyParams(voxel_size=vs))
+    model.exp_avg.fill_(0.5)
+    new = torch.rand(900, 3, generator=g) * torch.tensor([1.0, 1.0, 0.5]) + torch.tensor([1.2, -0.5, 2.2])
+    new = torch.cat([new, pts[:50]])                            # some fall into voxels that already hold an anchor: kept, like the reference
+    n_new = dens.increase_pcd(new.to(dev))
+    u2, sc2 = restate(new)
+    assert n_new == u2.shape[0] and model.A == A + n_new
+    assert torch.equal(model.param("anchor")[A:].cpu(), u2) and torch.equal(model.param("anchor")[:A].cpu(), u)
+    assert torch.allclose(model.param("scaling")[A:].cpu(), sc2, rtol=1e-6, atol=1e-6)
+    for name in model.widths:
+        assert float(model._view(model.exp_avg, name)[A:].abs().max()) == 0.0
+        assert float(model._view(model.exp_avg, name)[:A].min()) == 0.5
+    assert float(dens.stat("offset_denom")[A * 10:].abs().max()) == 0.0 and float(dens.stat("anchor_demon")[A:].abs().max()) == 0.0
+    assert dens.increase_pcd(torch.zeros(0, 3, device=dev)) == 0
+
+    # the grown model trains
+    cam = scenes.make_camera(160, 120, 150.0, 150.0, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    model.exp_avg.zero_()
+    step = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
+    gt = torch.full((3, cam.height, cam.width), 0.5, device=dev)
+    losses = [float(step.training_once([kf], [gt])) for _ in range(30)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
