@@ -27,6 +27,11 @@ extern "C" {
 int segs_training_statis(int A, int n_offsets, const float* neural_opacity, const int* visible_radii, const int* radii,
                          const float* dL_dmean2D, float* opacity_accum, float* anchor_demon, float* offset_gradient_accum,
                          float* offset_denom, void* stream);
+/* Same, dropped on the device when *skip_flag != 0 (the overflow word status[3] of segs_rasterize_forward_resident): the
+ * training loop then needs no host synchronisation per iteration to keep an invalid pass out of the statistics. */
+int segs_training_statis_guarded(int A, int n_offsets, const float* neural_opacity, const int* visible_radii, const int* radii,
+                                 const float* dL_dmean2D, float* opacity_accum, float* anchor_demon, float* offset_gradient_accum,
+                                 float* offset_denom, const uint32_t* skip_flag, void* stream);
 
 /* Scratch for one growing level over A anchors with at most n_candidates = A_init * n_offsets candidate slots. */
 size_t segs_anchor_growing_temp_bytes(int A, int n_candidates);

@@ -34,6 +34,7 @@ SYMBOLS = {
     "segs_raster_set_flags": (C.c_uint, [C.c_uint]),
     "segs_raster_set_status_mirror": (_vp, [_vp]),
     "segs_training_statis": (_i, [_i, _i] + [_vp] * 9),
+    "segs_training_statis_guarded": (_i, [_i, _i] + [_vp] * 10),
     "segs_anchor_growing_temp_bytes": (_sz, [_i, _i]),
     "segs_anchor_growing_level": (_i, [_i, _i, _i, _i] + [_vp] * 7 + [_f, _f, _f, _i] + [_vp] * 5),
     "segs_neural_param_layout": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -30,7 +30,11 @@ __device__ __forceinline__ uint64_t pack_key(int x, int y, int z) {
 __global__ void __launch_bounds__(256) stats_kernel(int A, int no, const float* __restrict__ nop, const int* __restrict__ vis,
                                                     const int* __restrict__ radii, const float* __restrict__ g2d,
                                                     float* __restrict__ opacity_accum, float* __restrict__ anchor_demon,
-                                                    float* __restrict__ grad_accum, float* __restrict__ denom) {
+                                                    float* __restrict__ grad_accum, float* __restrict__ denom,
+                                                    const uint32_t* __restrict__ skip_flag) {
+  // guarded form: a pass the resident rasterizer flagged as overflowed must not enter the statistics (its radii and
+  // gradients are meaningless); dropped here on the device, like the optimizer step (segs_adam_step_guarded)
+  if (skip_flag != nullptr && *skip_flag != 0u) return;
   const int a = blockIdx.x * 256 + threadIdx.x;
   if (a >= A) return;
   if (vis && vis[a] <= 0) return;                       // anchor_visible_mask (:1471-1478)
@@ -203,17 +207,25 @@ size_t grow_carve(int A, int nc, char* base, GrowTemp* t) {
 
 extern "C" {
 
-int segs_training_statis(int A, int n_offsets, const float* neural_opacity, const int* visible_radii, const int* radii,
-                         const float* dL_dmean2D, float* opacity_accum, float* anchor_demon, float* offset_gradient_accum,
-                         float* offset_denom, void* stream) {
+int segs_training_statis_guarded(int A, int n_offsets, const float* neural_opacity, const int* visible_radii, const int* radii,
+                                 const float* dL_dmean2D, float* opacity_accum, float* anchor_demon, float* offset_gradient_accum,
+                                 float* offset_denom, const uint32_t* skip_flag, void* stream) {
   if (A < 0 || n_offsets <= 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   if (A == 0) return SEGS_OK;
   if (!neural_opacity || !radii || !dL_dmean2D || !opacity_accum || !anchor_demon || !offset_gradient_accum || !offset_denom)
     return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   stats_kernel<<<(A + 255) / 256, 256, 0, (hipStream_t)stream>>>(A, n_offsets, neural_opacity, visible_radii, radii, dL_dmean2D,
-                                                                 opacity_accum, anchor_demon, offset_gradient_accum, offset_denom);
+                                                                 opacity_accum, anchor_demon, offset_gradient_accum, offset_denom,
+                                                                 skip_flag);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
+}
+
+int segs_training_statis(int A, int n_offsets, const float* neural_opacity, const int* visible_radii, const int* radii,
+                         const float* dL_dmean2D, float* opacity_accum, float* anchor_demon, float* offset_gradient_accum,
+                         float* offset_denom, void* stream) {
+  return segs_training_statis_guarded(A, n_offsets, neural_opacity, visible_radii, radii, dL_dmean2D, opacity_accum, anchor_demon,
+                                      offset_gradient_accum, offset_denom, nullptr, stream);
 }
 
 size_t segs_anchor_growing_temp_bytes(int A, int n_candidates) {

@@ -61,14 +61,16 @@ class AnchorDensifier:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.model.device).cuda_stream)
 
-    def training_statis(self, neural: NeuralGaussians, visible_radii: torch.Tensor, radii: torch.Tensor, dL_dmean2D: torch.Tensor):
-        """src/gaussian_model.cpp:1459-1503 in the candidate domain (called between start_stat and update_until)."""
+    def training_statis(self, neural: NeuralGaussians, visible_radii: torch.Tensor, radii: torch.Tensor, dL_dmean2D: torch.Tensor,
+                        skip_flag: Optional[C.c_void_p] = None):
+        """src/gaussian_model.cpp:1459-1503 in the candidate domain (called between start_stat and update_until).
+        `skip_flag`: device address of the resident rasterizer's overflow word; the pass is then dropped on the device."""
         m = self.model
         s = self._stats
-        st = self._lib.segs_training_statis(m.A, m.dims.n_offsets, _p(neural.neural_opacity), _p(visible_radii), _p(radii),
-                                            _p(dL_dmean2D), _p(s["opacity_accum"]), _p(s["anchor_demon"]),
-                                            _p(s["offset_gradient_accum"]), _p(s["offset_denom"]), self._stream())
-        _capi.check(st, "segs_training_statis")
+        st = self._lib.segs_training_statis_guarded(m.A, m.dims.n_offsets, _p(neural.neural_opacity), _p(visible_radii), _p(radii),
+                                                    _p(dL_dmean2D), _p(s["opacity_accum"]), _p(s["anchor_demon"]),
+                                                    _p(s["offset_gradient_accum"]), _p(s["offset_denom"]), skip_flag, self._stream())
+        _capi.check(st, "segs_training_statis_guarded")
 
     # ---- adjust_anchor ---------------------------------------------------------------------------------------------
     def _append(self, new_anchor: torch.Tensor, new_feat: torch.Tensor, cur_size: float, new_scaling: Optional[torch.Tensor] = None):

@@ -463,19 +463,25 @@ class ScaffoldTrainerStep:
         lrs = self.learning_rates(self.iteration)
         k = self.keyframe_for(self.iteration - 1, len(keyframes))
         loss = self._forward_backward(keyframes[k], gt_images[k])
-        if (self.world > 1 or self.densifier is not None) and self.model.A > 0:
-            # ranks must agree on whether the step counts, and the densify statistics must not see an invalid pass:
-            # resolve the overflow word on the host (one synchronisation) and redo the pass through the re-sizing path
+        d = self.densifier
+        in_stat_window = d is not None and self.model.A > 0 and d.p.start_stat < self.iteration < d.p.update_until  # gaussian_mapper.cpp:961-968
+        adjust_now = in_stat_window and self.iteration > d.p.update_from and self.iteration % d.p.update_interval == 0
+        if (self.world > 1 or adjust_now) and self.model.A > 0:
+            # ranks must agree on whether the step counts, and adjust_anchor reads the statistics on the host: resolve the
+            # overflow word here (one synchronisation) and redo an invalid pass through the re-sizing path.  On all other
+            # single-rank iterations nothing waits for the device: statistics and optimizer are guarded by that word on the
+            # device, an overflowed pass is dropped and the next forward re-sizes the scratch.
             if not self.engine.check(raise_on_overflow=False):
                 self.model.grads.zero_()
                 loss = self._forward_backward(keyframes[k], gt_images[k])
         if self.world > 1:
             dist.all_reduce(self.model.grads, group=self.pg)
         adjusted = False
-        d = self.densifier
-        if d is not None and self.model.A > 0 and d.p.start_stat < self.iteration < d.p.update_until:  # gaussian_mapper.cpp:961-968
-            d.training_statis(self.neural, self.visible_radii, self.engine.radii, self.engine.dL_dmean2D)
-            if self.iteration > d.p.update_from and self.iteration % d.p.update_interval == 0:
+        if in_stat_window:
+            status = getattr(self.engine, "_status", None)
+            guard = C.c_void_p(status.data_ptr() + 12) if (status is not None and self.world == 1) else None
+            d.training_statis(self.neural, self.visible_radii, self.engine.radii, self.engine.dL_dmean2D, guard)
+            if adjust_now:
                 d.adjust_anchor(generator=self.densify_generator)
                 adjusted = True
         groups = self.model.adam_groups(lrs)

@@ -33,7 +33,7 @@ step = ng.ScaffoldTrainerStep(model, cam.width, cam.height, scaling_reg_weight=0
 dens = densify.AnchorDensifier(model, densify.DensifyParams(voxel_size=0.01, start_stat=100, update_from=300, update_interval=100,
                                                             update_until=iters, densify_grad_threshold=thr))
 step.enable_densification(dens, seed=0)
-t0 = time.perf_counter()
+t0 = t_last = time.perf_counter()
 for it in range(1, iters + 1):
     loss = step.training_once(kfs, gts)
     if it % 100 == 0:
@@ -41,7 +41,9 @@ for it in range(1, iters + 1):
         l = float(loss)
         assert np.isfinite(l), (it, l)
         print(f"it {it:5d} loss {l:.5f} anchors {model.A:7d} capacity {model.capacity:7d} R {step.engine.R:8d} "
-              f"mem {torch.cuda.memory_allocated() / 2**20:7.0f} MiB  {1e3 * (time.perf_counter() - t0) / it:.3f} ms/it", flush=True)
+              f"mem {torch.cuda.memory_allocated() / 2**20:7.0f} MiB  {1e3 * (time.perf_counter() - t0) / it:.3f} ms/it since start, "
+              f"{10 * (time.perf_counter() - t_last):.3f} ms/it over the last 100 (one adjust_anchor included)", flush=True)
+        t_last = time.perf_counter()
         if stop_at and model.A >= stop_at:
             break
 assert torch.isfinite(model.params).all()
