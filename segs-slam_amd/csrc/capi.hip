@@ -88,7 +88,7 @@ uint32_t getHigherMsb(uint32_t n) {
   return msb;
 }
 
-// K8: stable LSD radix sort, 8 bits per pass over key bits [0,end_bit).  Input is expected in side
+// K8: stable LSD radix sort, BITS (8 or 9) bits per pass over key bits [0,end_bit).  Input is expected in side
 // `passes & 1` of the ping-pong pair so that the result lands in side 0.
 // drop_dead: entries whose key is all ones are left out by the FIRST pass (they take no histogram count and no rank), so
 // every later pass -- and the caller, through *n_live -- works on the survivors only: a stable partition for free.
