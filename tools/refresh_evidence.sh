@@ -6,7 +6,7 @@ TAG=${1:-rXX}
 tools/collect_profiles.sh $TAG c2_1080p
 OUT=gpurun_out/${TAG}_other_workloads.txt
 : > $OUT
-for WL in c1 c2 1080p_1m 1080p_3m c5; do
+for WL in c1 c2 1080p_1m 1080p_2m 1080p_3m c5; do
   timeout -k 10 300 python3 bench.py --workload $WL --no-cpu-baseline 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
