@@ -138,6 +138,7 @@ struct Geom {
   uint32_t* num_rendered() const { return (uint32_t*)(base + L.num_rendered); }
   uint32_t* clamped() const { return (uint32_t*)(base + L.clamped); }
   float* gacc() const { return (float*)(base + L.gacc); }
+  uint32_t* touched() const { return (uint32_t*)(base + L.touched); }
 };
 Geom geom_at(char* p, int P) { return Geom{geom_layout(P), align_ptr(p)}; }
 
@@ -154,7 +155,7 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
                                                      proj, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, radii,
                                                      G.rec(), G.bin(), G.block_sums(), G.block_sums() + (G.L.nblocks + 1), shs, D, M, cam_pos,
                                                      G.clamped(), g_flags | extra_flags, depth_keys, depth_vals, ranges, (int)(gx * gy),
-                                                     depth_overflow);
+                                                     depth_overflow, G.touched());
   }
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
@@ -187,13 +188,13 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   // (2)
   uint32_t* sums2 = (uint32_t*)(bin + GS.block_sums);
   { PROF(K_SCAN);
-  ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2);
+  ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.touched(), order, sums2, G.offsets());
   }
   LAUNCH_TRY("ordered_block_sums_kernel");
   const int tpasses = (bit + 7) / 8;
   const int side = tpasses & 1;
   { PROF(K_SCAN);
-  ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.bin(), order, sums2, G.offsets(), total_out);
+  ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, sums2, G.offsets(), total_out);
   }
   LAUNCH_TRY("ordered_offsets_kernel");
   { PROF(K_DUPLICATE);

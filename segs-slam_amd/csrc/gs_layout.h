@@ -49,7 +49,7 @@ constexpr size_t ALIGN = 256;
 inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
-  size_t rec, bin, offsets, radii_internal, block_sums, clamped, num_rendered, gacc, total;
+  size_t rec, bin, offsets, radii_internal, block_sums, clamped, num_rendered, gacc, touched, total;
   int P, nblocks;
 };
 // Mirrors GeometryState::fromChunk (rasterizer_impl.cu:155-170) in role, not in layout.
@@ -66,6 +66,7 @@ inline GeomLayout geom_layout(int P) {
   g.clamped = o;        o = align_up(o + (size_t)P * 4);  // SH path: 3 clamp flags packed in one word
   g.num_rendered = o;   o = align_up(o + 64);
   g.gacc = o;           o = align_up(o + (size_t)P * GACC_DWORDS * 4);
+  g.touched = o;        o = align_up(o + (size_t)P * 4);  // tiles_touched once more, dense: the depth-ordered prefix gathers 4 B, not a 16-B BinInfo
   g.total = o + ALIGN;  // slack so the base pointer can be aligned up
   return g;
 }

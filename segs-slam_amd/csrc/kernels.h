@@ -20,7 +20,7 @@ __global__ void preprocess_fwd_kernel(
     int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
     uint32_t* __restrict__ depth_range, const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos,
     uint32_t* __restrict__ clamped, uint32_t flags, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ depth_vals,
-    uint2* __restrict__ ranges, int num_tiles, uint32_t* __restrict__ depth_overflow);
+    uint2* __restrict__ ranges, int num_tiles, uint32_t* __restrict__ depth_overflow, uint32_t* __restrict__ touched_dense);
 // Resident depth sort: every binned Gaussian has view depth > 0.2 (auxiliary.h:155), so its float bits exceed those of
 // 0.2f; 27 bits above that (16 binades: depths below 13 107.2) are sorted in three 9-bit passes.
 constexpr uint32_t DEPTH_KEY_MIN = 0x3E4CCCCDu;   // bits of 0.2f
@@ -49,8 +49,7 @@ __global__ void preprocess_bwd_kernel(
 // ---- binning.hip
 __global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, const uint32_t* __restrict__ depth_range,
                                        uint32_t* __restrict__ total);
-__global__ void ordered_offsets_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
-                                       const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ incl,
+__global__ void ordered_offsets_kernel(int P, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ incl,
                                        uint32_t* __restrict__ total_out);
 __global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
@@ -90,8 +89,8 @@ __global__ void rebuild_keys_kernel(int R, const uint32_t* __restrict__ tile_key
                                     const BinInfo* __restrict__ bin, uint64_t* __restrict__ keys64);
 __global__ void make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, uint32_t dcull, uint32_t* __restrict__ keys,
                                        uint32_t* __restrict__ vals, uint2* __restrict__ ranges, int num_tiles);
-__global__ void ordered_block_sums_kernel(int P, const BinInfo* __restrict__ bin, const uint32_t* __restrict__ order,
-                                          uint32_t* __restrict__ block_sums);
+__global__ void ordered_block_sums_kernel(int P, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ order,
+                                          uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched);
 __global__ void point_offsets_kernel(int P, const BinInfo* __restrict__ bin, uint32_t* __restrict__ offsets);
 __global__ void strip_mask_kernel(int n, const uint32_t* __restrict__ vals, uint32_t* __restrict__ out);
 

@@ -300,7 +300,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     uint32_t* __restrict__ depth_range /* per workgroup: [b] = max(depth_bits), [nblocks + b] = max(~depth_bits), visible only */,
     const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, uint32_t* __restrict__ clamped,
     uint32_t flags, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ depth_vals, uint2* __restrict__ ranges,
-    int num_tiles, uint32_t* __restrict__ depth_overflow /* resident: set when a binned depth leaves the 27-bit key range */) {
+    int num_tiles, uint32_t* __restrict__ depth_overflow /* resident: set when a binned depth leaves the 27-bit key range */,
+    uint32_t* __restrict__ touched_dense) {
   __shared__ float lds[768];
   __shared__ uint32_t wave_sums[4], wave_dmax[4], wave_dnmin[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -362,6 +363,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     }
     radii[idx] = g.radius;
     reinterpret_cast<uint4*>(bin)[idx] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
+    touched_dense[idx] = b.tiles_touched;
     if (depth_keys) {   // resident mode: what make_depth_keys_kernel would write (32-bit depth keys, culled = 0xFFFFFFFF)
       // The resident depth sort looks at DEPTH_KEY_BITS bits above the near plane's bit pattern (three 9-bit passes).
       // Gaussians without instances take the largest key of that range so that they sort to the END (the emitter relies
