@@ -50,6 +50,8 @@ def main():
                          "Gaussians; scaffold: the anchor-level mapper step (prefilter, neural-Gaussian MLPs, raster, loss, "
                          "their backward, Adam) over --anchors anchors x 10 offsets (SURVEY 8d config 3)")
     ap.add_argument("--anchors", type=int, default=50000)
+    ap.add_argument("--appearance-dim", type=int, default=32, help="scaffold mode: Model.appearance_dim (ScanNet configurations: 16)")
+    ap.add_argument("--no-feat-bank", action="store_true", help="scaffold mode: Model.use_feat_bank = 0 (ScanNet configurations)")
     ap.add_argument("--sync-forward", action="store_true",
                     help="use the reference-shaped forward that blocks on a D2H copy of num_rendered every step "
                          "(default: resident no-sync entry points after one calibrating step)")
@@ -109,7 +111,8 @@ def main():
 
     if args.mode == "scaffold":
         from segs_slam_amd import neural_gaussians as ng
-        model = ng.synthetic_model(args.anchors, ng.ModelDims(), cam, dev, seed=0)   # replicas must be identical; the keyframe differs per rank
+        dims = ng.ModelDims(appearance_dim=args.appearance_dim, use_feat_bank=not args.no_feat_bank)
+        model = ng.synthetic_model(args.anchors, dims, cam, dev, seed=0)   # replicas must be identical; the keyframe differs per rank
         tstep = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
         eng = tstep.engine
         kfs = [ng.Keyframe(view, proj, campos, torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)]
@@ -208,7 +211,8 @@ def main():
                                    "fwd+bwd raster" + (", RCCL all-reduce of parameter grads" if world > 1 else "")
                                    + (" + L1/SSIM loss + fused Adam" if args.mode == "trainer" else "")
                                    + (f"; anchor-level mapper step: {args.anchors} anchors x 10 offsets -> neural Gaussians "
-                                      "(MLPs fwd+bwd), L1/SSIM, fused Adam" if args.mode == "scaffold" else ""),
+                                      f"(appearance_dim {args.appearance_dim}, feature bank {'off' if args.no_feat_bank else 'on'}; MLPs fwd+bwd), "
+                                      "L1/SSIM, fused Adam" if args.mode == "scaffold" else ""),
                        "P": eng.P, "P_visible": P_vis, "num_rendered": R, "instances_binned": eng.R, "width": cam.width, "height": cam.height,
                        "sort_passes": {"depth_keys_P": passes_depth, "tile_keys_R": passes_tile}, "parallelism": f"keyframe-dp{world}",
                        "forward": "sync (reference API)" if args.sync_forward else "resident (no host sync)"},
