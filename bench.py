@@ -278,20 +278,29 @@ def pmc_traffic(workload, kernel):
     return e["hbm_bytes"], os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(sc):
+def cpu_baseline(sc, budget_s: float = 12.0, max_iters: int = 10):
     """The CPU oracle (a port of the reference algorithm; the reference has no CPU raster path)
-    timed on this host: ONE fwd+bwd iteration of the same workload (bounded sample)."""
+    timed on this host: whole fwd+bwd iterations of the same workload until about `budget_s` seconds of wall time are
+    spent (at least 2, at most `max_iters`); the first iteration is reported but not counted (page faults, thread start)."""
     from oracle import gs_oracle
     cam = sc.camera
     o = gs_oracle.Oracle()
-    t0 = time.perf_counter()
-    o.forward(sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, sc.scale_modifier, sc.rotations,
-              cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.height, cam.width)
-    t1 = time.perf_counter()
-    o.backward(sc.dL_dout_color)
-    t2 = time.perf_counter()
-    return {"value": 1.0 / (t2 - t0), "unit": "iters/s", "cores": int(gs_oracle.lib().gso_threads()), "kind": "port",
-            "sample": f"1 fwd+bwd iteration of the same scene (fwd {t1 - t0:.2f} s, bwd {t2 - t1:.2f} s), OpenMP oracle",
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_start < budget_s and len(times) < max_iters + 1):
+        t0 = time.perf_counter()
+        o.forward(sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, sc.scale_modifier, sc.rotations,
+                  cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.height, cam.width)
+        t1 = time.perf_counter()
+        o.backward(sc.dL_dout_color)
+        t2 = time.perf_counter()
+        times.append((t1 - t0, t2 - t1))
+    timed = times[1:]
+    fwd = sum(t[0] for t in timed) / len(timed)
+    bwd = sum(t[1] for t in timed) / len(timed)
+    return {"value": 1.0 / (fwd + bwd), "unit": "iters/s", "cores": int(gs_oracle.lib().gso_threads()), "kind": "port",
+            "sample": f"{len(timed)} fwd+bwd iterations of the same scene after one untimed (mean fwd {fwd:.2f} s, bwd {bwd:.2f} s; "
+                      f"first iteration {sum(times[0]):.2f} s), OpenMP oracle",
             "host_cpus": os.cpu_count()}
 
 
