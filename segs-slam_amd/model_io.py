@@ -79,3 +79,41 @@ def save_mlp_checkpoints(model, result_dir: str):
         m, layer, kind = name.split(".")
         idx = {"0": 1, "2": 2}[layer]
         _save_txt(model.param(name), os.path.join(result_dir, f"{stems[m]}_{kind}{idx}.txt"))
+
+
+_STEMS = {"mlp_opacity": "opacity", "mlp_cov": "cov", "mlp_color": "color", "mlp_feature_bank": "feat", "mlp_apperance": "appearance"}
+
+
+def load_mlp_checkpoints(result_dir: str, dims) -> Dict[str, np.ndarray]:
+    """Reads back the text files of save_mlp_checkpoints (5 decimals, as the reference writes them) into arrays of the shapes
+    ModelDims.mlp_tensor_shape gives.  The reference has no reader for these files; this is the counterpart its own
+    `save_mlp_checkpoints` output needs to be usable as an initial state here."""
+    out = {}
+    for name in dims.mlp_tensor_names():
+        m, layer, kind = name.split(".")
+        path = os.path.join(result_dir, f"{_STEMS[m]}_{kind}{ {'0': 1, '2': 2}[layer] }.txt")
+        a = np.loadtxt(path, dtype=np.float32, ndmin=2)
+        shape = dims.mlp_tensor_shape(name)
+        if a.size != int(np.prod(shape)):
+            raise ValueError(f"{path}: {a.shape} does not match {name} {shape}")
+        out[name] = a.reshape(shape)
+    return out
+
+
+def load_model(ply_path: str, mlp_dir: str, dims, device, capacity=None):
+    """GaussianModel::loadPly (src/gaussian_model.cpp:1054-1177) plus the MLP text checkpoints -> a ScaffoldModel on `device`:
+    anchors, offsets (stored transposed in the file, :1160-1164), features, opacity, log-scales and rotations from the PLY
+    the reference's savePly writes, MLP weights from load_mlp_checkpoints."""
+    import torch
+    from .neural_gaussians import ScaffoldModel
+    d = load_ply(ply_path)
+    A = d["anchor"].shape[0]
+    if d["anchor_feat"].shape[1] != dims.feat_dim or d["offset"].shape[1] != dims.n_offsets:
+        raise ValueError(f"{ply_path}: feat_dim {d['anchor_feat'].shape[1]} / n_offsets {d['offset'].shape[1]} do not match the model dimensions")
+    model = ScaffoldModel(A, dims, device, capacity)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    mlp = {k: t(v) for k, v in load_mlp_checkpoints(mlp_dir, dims).items()}
+    model.load(t(d["anchor"]), t(d["offset"]), t(d["anchor_feat"]), t(d["scaling"]), mlp)
+    model.opacity[:A] = t(d["opacity"]).to(model.device)
+    model.rotation[:A] = t(d["rotation"]).to(model.device)
+    return model

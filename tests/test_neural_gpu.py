@@ -197,7 +197,7 @@ def test_scaffold_trainer_reduces_loss():
 def test_model_io_round_trip(tmp_path):
     """save_ply writes the reference's property list (src/gaussian_model.cpp:1179-1261) and reads back bit-exactly;
     the MLP text files have the reference's names and `%.5f` rows."""
-    from segs_slam_amd import model_io
+    from segs_slam_amd import model_io, neural_gaussians as ng
     dev = torch.device("cuda:0")
     _, model, (anchor, offset, feat, scaling_log, mlp) = _setup(CASES[0], 37, 9, dev)
     p = str(tmp_path / "point_cloud.ply")
@@ -218,6 +218,16 @@ def test_model_io_round_trip(tmp_path):
     assert rows[3].split(" ")[5] == f"{float(mlp['mlp_cov.2.weight'][3, 5]):.5f}"
     for fn in ("opacity_weight1.txt", "opacity_bias2.txt", "color_bias1.txt", "feat_weight2.txt"):
         assert (tmp_path / "mlp" / fn).exists()
+    # and back: the anchor tensors bit-exactly, the MLPs to the 5 decimals the text format keeps
+    again = model_io.load_model(p, str(tmp_path / "mlp"), model.dims, dev)
+    assert again.A == 37
+    for name in ("anchor", "offset", "anchor_feat", "scaling"):
+        assert torch.equal(again.param(name), model.param(name)), name
+    assert torch.equal(again.rotation[:37], model.rotation[:37]) and torch.equal(again.opacity[:37], model.opacity[:37])
+    for name in model.dims.mlp_tensor_names():
+        assert float((again.param(name) - model.param(name)).abs().max()) <= 5.1e-6, name
+    with pytest.raises(ValueError):
+        model_io.load_model(p, str(tmp_path / "mlp"), ng.ModelDims(appearance_dim=16), dev)
 
 
 def test_second_slab_of_persistent_workgroups_is_consistent():
