@@ -318,6 +318,7 @@ class ScaffoldTrainerStep:
         self.mlp_steps = 0
         self.densifier = None            # densify.AnchorDensifier, see enable_densification()
         self.densify_generator = None
+        self.keyframe_selector = None    # keyframe_window.SlidingWindowKeyframes: the mapper's walk instead of round-robin
         # the mapper (not the trainer) multiplies rendering and target by mask_rgb = (gt != 0).any(-1): gt is (3,H,W), so this
         # is a per-(channel, row) mask of shape (3,H,1) that blanks rows whose target is entirely zero
         # (src/gaussian_mapper.cpp:917-922).  Off by default (trainer semantics); mapper_config.make_mapper_step turns it on.
@@ -461,7 +462,11 @@ class ScaffoldTrainerStep:
     def training_once(self, keyframes: List[Keyframe], gt_images: List[torch.Tensor]) -> torch.Tensor:
         self.iteration += 1
         lrs = self.learning_rates(self.iteration)
-        k = self.keyframe_for(self.iteration - 1, len(keyframes))
+        if self.keyframe_selector is not None:
+            # useOneRandomSlidingWindowKeyframe (src/gaussian_mapper.cpp:827): one draw per rank, identical on every rank
+            k = self.keyframe_selector.use_for_ranks(self.world)[self.rank]
+        else:
+            k = self.keyframe_for(self.iteration - 1, len(keyframes))
         loss = self._forward_backward(keyframes[k], gt_images[k])
         d = self.densifier
         in_stat_window = d is not None and self.model.A > 0 and d.p.start_stat < self.iteration < d.p.update_until  # gaussian_mapper.cpp:961-968

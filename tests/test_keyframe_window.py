@@ -1,0 +1,77 @@
+"""segs_slam_amd.keyframe_window: the mapper's keyframe walk (src/gaussian_mapper.cpp:1444-1495)."""
+from segs_slam_amd.keyframe_window import SlidingWindowKeyframes
+
+
+def test_walk_visits_a_permutation_and_respects_the_budgets():
+    w = SlidingWindowKeyframes(seed=3)
+    assert w.use_one() == -1
+    for _ in range(6):
+        w.add_keyframe(2)
+    first_lap = [w.use_one() for _ in range(6)]
+    assert sorted(first_lap) == list(range(6))                   # one lap = one permutation
+    second_lap = [w.use_one() for _ in range(6)]
+    assert second_lap == first_lap                               # same shuffle until a keyframe is added
+    assert all(r == 0 for r in w.remaining) and all(w.used_times[k] == 2 for k in range(6))
+    # budgets exhausted: the lap that finds nobody gives every keyframe one more use and goes on
+    third = [w.use_one() for _ in range(6)]
+    assert sorted(third) == list(range(6)) and all(r == 0 for r in w.remaining)
+
+
+def test_keyframes_without_budget_are_skipped_and_new_ones_reshuffle():
+    w = SlidingWindowKeyframes(seed=5)
+    for t in (0, 3, 0, 3):
+        w.add_keyframe(t)
+    picks = [w.use_one() for _ in range(6)]
+    assert set(picks) == {1, 3} and w.remaining == [0, 0, 0, 0]
+    new = w.add_keyframe(8)                                      # the reference's newKeyframeTimesOfUse
+    assert new == 4
+    assert w.use_one() == 4                                      # the only keyframe with budget; the others are skipped
+    # A quirk kept from the reference: the "nobody left" test fires when the walk returns to its STARTING index, which is
+    # the keyframe used last -- so with a single live keyframe the next use walks a full lap, gives EVERY keyframe one more
+    # use (:1477-1479) and only then looks at the keyframe under the cursor.
+    before = list(w.remaining)
+    nxt = w.use_one()
+    assert sum(w.remaining) == sum(before) + 5 - 1 and w.remaining[nxt] == before[nxt] + 1 - 1
+    w.increase_times_of_use(0, 2)
+    assert w.remaining[0] >= 2
+
+
+def _literal_walk(shuffle, remaining, idx, uses):
+    """The loop of :1471-1485 written out once more, for a fixed permutation."""
+    out, remaining = [], list(remaining)
+    for _ in range(uses):
+        start = idx
+        while True:
+            idx += 1
+            if idx >= len(shuffle):
+                idx = 0
+            if idx == start:
+                remaining = [r + 1 for r in remaining]
+            kf = shuffle[idx]
+            if remaining[kf] > 0:
+                break
+        remaining[kf] -= 1
+        out.append(kf)
+    return out
+
+
+def test_walk_equals_the_literal_loop():
+    w = SlidingWindowKeyframes(seed=7)
+    budgets = [1, 0, 4, 2, 0, 0, 3]
+    for t in budgets:
+        w.add_keyframe(t)
+    first = w.use_one()                                           # draws the permutation
+    shuffle = list(w._shuffle)
+    assert _literal_walk(shuffle, list(budgets), 0, 1) == [first]
+    got = [first] + [w.use_one() for _ in range(40)]
+    assert got == _literal_walk(shuffle, list(budgets), 0, 41)
+
+
+def test_same_seed_same_sequence_on_every_rank():
+    a, b = SlidingWindowKeyframes(seed=11), SlidingWindowKeyframes(seed=11)
+    for w in (a, b):
+        for _ in range(9):
+            w.add_keyframe(4)
+    seq_a = [a.use_for_ranks(4) for _ in range(5)]
+    seq_b = [b.use_for_ranks(4) for _ in range(5)]
+    assert seq_a == seq_b and all(len(set(s)) == 4 for s in seq_a[:2])   # within a lap the ranks get distinct keyframes

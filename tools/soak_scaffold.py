@@ -22,6 +22,7 @@ sc = scenes.make_config_scene("c2")
 cam = sc.camera
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
 kfs, gts = [], []
+from segs_slam_amd.keyframe_window import SlidingWindowKeyframes  # noqa: E402
 for k in range(8):                      # 8 keyframes on a small orbit, targets = a smooth pattern per keyframe
     camk = scenes.make_config_scene("c2", keyframe=k).camera
     kfs.append(ng.Keyframe(t(camk.world_view_transform), t(camk.full_proj_transform), t(camk.camera_center),
@@ -33,6 +34,9 @@ step = ng.ScaffoldTrainerStep(model, cam.width, cam.height, scaling_reg_weight=0
 dens = densify.AnchorDensifier(model, densify.DensifyParams(voxel_size=0.01, start_stat=100, update_from=300, update_interval=100,
                                                             update_until=iters, densify_grad_threshold=thr))
 step.enable_densification(dens, seed=0)
+step.keyframe_selector = SlidingWindowKeyframes(seed=0)      # the mapper's keyframe walk (src/gaussian_mapper.cpp:1459-1495)
+for _ in kfs:
+    step.keyframe_selector.add_keyframe(8)                    # Mapper.new_keyframe_times_of_use
 t0 = t_last = time.perf_counter()
 for it in range(1, iters + 1):
     loss = step.training_once(kfs, gts)
