@@ -80,29 +80,15 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(uint32_t* __restr
 // Each emitted VALUE also carries the 4-bit mask of 8x8 quadrants of the tile in which this Gaussian can pass
 // the alpha >= 1/255 test at all: exact minimum of the quadratic form over the quadrant's pixel rectangle
 // against 2 ln(255 o) (conservatively inflated).  See gs_layout.h.
-__device__ __forceinline__ bool ellipse_hits_rect(float cx, float cy, float A, float B, float C, float k,
-                                                  float x0, float x1, float y0, float y1) {
-  const float lx0 = x0 - cx, lx1 = x1 - cx, ly0 = y0 - cy, ly1 = y1 - cy;
-  if (lx0 <= 0.f && lx1 >= 0.f && ly0 <= 0.f && ly1 >= 0.f) return true;  // centre inside the rectangle
-  const float inv_c = 1.0f / C, inv_a = 1.0f / A;
-  float best = 3.0e38f;
-#pragma unroll
-  for (int e = 0; e < 2; e++) {
-    const float dx = e ? lx1 : lx0;
-    const float dy = fminf(ly1, fmaxf(ly0, -B * dx * inv_c));
-    best = fminf(best, A * dx * dx + 2.f * B * dx * dy + C * dy * dy);
-    const float ey = e ? ly1 : ly0;
-    const float ex = fminf(lx1, fmaxf(lx0, -B * ey * inv_a));
-    best = fminf(best, A * ex * ex + 2.f * B * ex * ey + C * ey * ey);
-  }
-  return best <= k;
-}
-
-// The same test for the four 8x8 quadrants of the tile at (fx, fy) at once.  The quadrants share their edge lines
+// The test for one pixel rectangle [x0,x1] x [y0,y1] (relative to the centre: lx0..ly1): true if the centre lies inside;
+// otherwise the minimum of A dx^2 + 2 B dx dy + C dy^2 over the rectangle sits on one of its four edges, and along an edge
+// (say dx fixed) it is the quadratic in dy clamped to the edge span at its vertex -B dx / C.  The rectangle is hit iff the
+// smallest of the four edge minima is <= k.
+// quadrant_mask does this for the four 8x8 quadrants of the tile at (fx, fy) at once.  The quadrants share their edge lines
 // (x = fx, fx+7, fx+8, fx+15, likewise y), so the clamped 1-D minimum along a line is set up once per line and evaluated
-// for the two spans it bounds: 16 edge minima at about 150 VALU operations instead of 4 x 60 (the emitter is VALU-bound
-// on this test).  Same mathematics as ellipse_hits_rect, evaluated as a dx^2 + dy (2 b dx + c dy); the threshold k is
-// inflated by the caller, so the last-bit differences stay on the conservative side.
+// for the two spans it bounds: 16 edge minima at about 150 VALU operations instead of 4 x 60 for four separate tests (the
+// emitter is VALU-bound on this).  Evaluated as a dx^2 + dy (2 b dx + c dy); the threshold k is inflated by the caller, so
+// last-bit differences stay on the conservative side.
 __device__ __forceinline__ uint32_t quadrant_mask(float cx, float cy, float A, float B, float C, float k, float nb_c /* -B/C */,
                                                   float nb_a /* -B/A */, float fx, float fy) {
   const float lx[4] = {fx - cx, fx + 7.f - cx, fx + 8.f - cx, fx + 15.f - cx};
