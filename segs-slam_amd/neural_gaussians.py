@@ -287,6 +287,28 @@ class Keyframe:
     tanfovx: float
     tanfovy: float
 
+    @classmethod
+    def from_pose(cls, q_wxyz, t_xyz, width: int, height: int, fx: float, fy: float, device, znear: float = 0.01,
+                  zfar: float = 100.0) -> "Keyframe":
+        """GaussianKeyframe::setPose (src/gaussian_keyframe.cpp:21-42: the quaternion is normalised) followed by
+        computeTransformTensors (:151-184: R = q.toRotationMatrix(), view / projection / full projection in the transposed
+        layout, camera centre) -- the tensors one keyframe hands to the renderer, plus the 7-vector the appearance MLP reads."""
+        import numpy as np
+        from . import scenes
+        q = np.asarray(q_wxyz, dtype=np.float64)
+        q = q / np.linalg.norm(q)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=np.float32)
+        t = np.asarray(t_xyz, dtype=np.float32)
+        cam = scenes.make_camera(width, height, fx, fy, R, t, znear, zfar)
+        dev = torch.device(device)
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+        pose7 = np.concatenate([t, q.astype(np.float32)]).astype(np.float32)
+        return cls(tt(cam.world_view_transform), tt(cam.full_proj_transform), tt(cam.camera_center), tt(pose7), cam.tanfovx,
+                   cam.tanfovy)
+
 
 class ScaffoldTrainerStep:
     """prefilter_voxel -> generate_neural_gaussians -> rasterize -> L1/SSIM -> backward -> [all-reduce] -> fused Adam,

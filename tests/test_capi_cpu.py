@@ -100,3 +100,20 @@ def test_neural_param_layout_matches_state_dict_order():
     bad = _capi.NeuralDims(64, 10, 0, 0, 0, 0, 0)
     assert lib.segs_neural_param_layout(C.byref(bad), None, None, None, None) != 0
     assert lib.segs_neural_temp_bytes(C.byref(bad), 10) == 0
+
+
+def test_keyframe_from_pose_matches_the_camera_helpers():
+    """Keyframe.from_pose = setPose + computeTransformTensors (src/gaussian_keyframe.cpp:21-42, 151-184) on the CPU."""
+    import torch
+    from segs_slam_amd import neural_gaussians as ng, scenes
+    ang = 0.3
+    q = np.array([np.cos(ang / 2), 0.0, np.sin(ang / 2), 0.0]) * 3.0                # un-normalised on purpose
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], dtype=np.float32)
+    t = np.array([0.2, -0.1, 0.5], dtype=np.float32)
+    kf = ng.Keyframe.from_pose(q, t, 640, 480, 525.0, 520.0, "cpu")
+    cam = scenes.make_camera(640, 480, 525.0, 520.0, R, t)
+    assert torch.allclose(kf.view, torch.from_numpy(cam.world_view_transform), atol=1e-6)
+    assert torch.allclose(kf.proj, torch.from_numpy(cam.full_proj_transform), atol=1e-5)
+    assert torch.allclose(kf.campos, torch.from_numpy(cam.camera_center), atol=1e-6)
+    assert abs(kf.tanfovx - cam.tanfovx) < 1e-7 and abs(kf.tanfovy - cam.tanfovy) < 1e-7
+    assert torch.allclose(kf.pose7, torch.tensor([0.2, -0.1, 0.5, np.cos(ang / 2), 0.0, np.sin(ang / 2), 0.0], dtype=torch.float32), atol=1e-6)
