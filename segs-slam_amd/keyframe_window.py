@@ -63,3 +63,22 @@ class SlidingWindowKeyframes:
     def use_for_ranks(self, world: int) -> List[int]:
         """One draw per rank of a keyframe-parallel step; every rank calls this with the same state and takes entry `rank`."""
         return [self.use_one() for _ in range(world)]
+
+
+def nerfpp_norm(camera_centers) -> tuple:
+    """GaussianScene::getNerfppNorm (src/gaussian_scene.cpp:113-149): (translate, radius) with translate = -mean of the
+    camera centres and radius = 1.1 x the largest distance of a centre from that mean, in float32.  The radius is the
+    scene extent (`cameras_extent`) that scales the position / offset learning rates (spatial_lr_scale)."""
+    c = np.asarray(camera_centers, dtype=np.float32).reshape(-1, 3)
+    if c.shape[0] == 0:
+        raise ValueError("no keyframes")
+    avg = np.zeros(3, dtype=np.float32)
+    for row in c:                      # accumulated in float32, camera by camera, like the reference
+        avg += row
+    avg /= np.float32(c.shape[0])
+    max_dist = np.float32(0.0)
+    for row in c:
+        d = np.float32(np.linalg.norm((row - avg).astype(np.float32)))
+        if d > max_dist:
+            max_dist = d
+    return -avg, float(np.float32(max_dist * np.float32(1.1)))

@@ -75,3 +75,13 @@ def test_same_seed_same_sequence_on_every_rank():
     seq_a = [a.use_for_ranks(4) for _ in range(5)]
     seq_b = [b.use_for_ranks(4) for _ in range(5)]
     assert seq_a == seq_b and all(len(set(s)) == 4 for s in seq_a[:2])   # within a lap the ranks get distinct keyframes
+
+
+def test_nerfpp_norm():
+    import numpy as np
+    from segs_slam_amd.keyframe_window import nerfpp_norm
+    c = np.array([[0, 0, 0], [2, 0, 0], [0, 2, 0], [2, 2, 0]], dtype=np.float32)
+    translate, radius = nerfpp_norm(c)
+    assert np.allclose(translate, [-1, -1, 0]) and abs(radius - 1.1 * np.sqrt(2)) < 1e-6
+    translate, radius = nerfpp_norm(c[:1])
+    assert np.allclose(translate, [0, 0, 0]) and radius == 0.0
