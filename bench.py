@@ -2,12 +2,15 @@
 """bench.py -- mapper train-iteration throughput of the rasterizer hot path on MI355X.
 
 One "step" = one pass of the hot path over one keyframe of synthetic input, inputs resident in HBM:
-  forward raster (preprocess, scan, duplicate, radix sort, ranges, render)  ->  backward raster
+  forward raster (preprocess, depth sort, instance emission, tile sort, ranges, render)  ->  backward raster
   (tile backward, fused per-Gaussian backward) with a fixed dL/dimage  [-> RCCL all-reduce of the
   Gaussian-parameter gradients when N > 1: keyframe-parallel training, one keyframe per GPU].
 
-Contract: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run)
-prints ONE JSON line on rank 0.  `value` = keyframe-iterations per second over all N GPUs.
+Contract: python bench.py --gpus N --steps K --warmup W prints ONE JSON line (rank 0).  With N > 1 the ranks are either
+the ones torch.distributed.run started (RANK / WORLD_SIZE in the environment) or, when the script is started plainly,
+N child processes this script starts itself BEFORE anything touches the GPU.  `value` = keyframe-iterations per second over
+all N GPUs.  Default workload: `1080p_3m` (3 M Gaussians at 1920x1080: the size north_star names, outside the 256 MiB
+Infinity Cache).
 """
 import argparse
 import json
@@ -19,13 +22,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+# /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak; 256 CUs x 4 SIMDs at 2.4 GHz, a wave64 VALU instruction occupies its
+# SIMD for 2 cycles; chip-wide global float-atomic rate ("Global float atomics": 1.26-1.36 TB/s of added bytes)
+HBM_PEAK_GBPS = 8000.0
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0        # G wave-instructions per second
+ATOMIC_PEAK_GBPS = 1300.0
+LIVE_EVENT_KERNELS = ("render_bwd_kernel", "render_fwd_kernel", "preprocess_bwd_kernel")
 
 
 def algorithmic_bytes(P, P_vis, R, W, H, passes_depth, passes_tile):
-    """algorithmic bytes per kernel of one fwd+bwd raster.  The sort line is this design's
-    two-level sort (P depth keys, then R tile keys; per pass: count reads the 8-B key, scatter reads and writes the
-    12-B key+value pair), which moves fewer bytes than the reference's (8+24*passes)*R single 64-bit sort."""
+    """algorithmic bytes per kernel of one fwd+bwd raster over R instances.  The sort line is this
+    design's two-level sort (P depth keys, then R tile keys; per pass: count reads the key, scatter reads and writes the
+    key+value pair), which moves fewer bytes than the reference's (8+24*passes)*R single 64-bit sort."""
     T = ((W + 15) // 16) * ((H + 15) // 16)
     return {
         "preprocess_fwd_kernel": 104 * P_vis + 8 * (P - P_vis),
@@ -39,12 +47,12 @@ def algorithmic_bytes(P, P_vis, R, W, H, passes_depth, passes_tile):
     }
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c2_1080p", help="scene config name (segs_slam_amd.scenes.CONFIGS)")
+    ap.add_argument("--workload", default="1080p_3m", help="scene config name (segs_slam_amd.scenes.CONFIGS)")
     ap.add_argument("--mode", default="raster", choices=["raster", "trainer", "scaffold"],
                     help="raster: fwd+bwd raster (+all-reduce); trainer: + fused L1/SSIM loss and fused Adam over the "
                          "Gaussians; scaffold: the anchor-level mapper step (prefilter, neural-Gaussian MLPs, raster, loss, "
@@ -52,11 +60,14 @@ def main():
     ap.add_argument("--anchors", type=int, default=50000)
     ap.add_argument("--appearance-dim", type=int, default=32, help="scaffold mode: Model.appearance_dim (ScanNet configurations: 16)")
     ap.add_argument("--no-feat-bank", action="store_true", help="scaffold mode: Model.use_feat_bank = 0 (ScanNet configurations)")
+    ap.add_argument("--dense-allreduce", action="store_true",
+                    help="trainer / scaffold mode with N > 1: one all-reduce and a full Adam on every rank instead of "
+                         "reduce-scatter -> sharded Adam -> all-gather")
     ap.add_argument("--sync-forward", action="store_true",
                     help="use the reference-shaped forward that blocks on a D2H copy of num_rendered every step "
                          "(default: resident no-sync entry points after one calibrating step)")
     ap.add_argument("--graph", action="store_true", help="replay the resident fwd+bwd from a captured hipGraph (N=1 only); the "
-                    "dominant kernel's live HIP-event timing is then taken from the eager warm-up pass")
+                    "dominant kernel's HIP-event timing then comes from the profiled steps after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank path)")
@@ -65,7 +76,44 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (exercises the RCCL calls on a one-GPU box)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (one per GPU, rendezvous on
+    127.0.0.1) before this process has touched the GPU or imported torch, and hand rank 0's stdout -- the one JSON line --
+    through.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, pending = 0, list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in pending:       # a rank died: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     # stdout carries exactly one JSON line: libraries that print there (RCCL writes its version banner to stdout when the
     # first communicator is created) are sent to stderr for the whole run, the line goes to the saved descriptor
@@ -83,8 +131,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP extension has no CPU fallback")
     if args.rehearse_on_one_gpu:
@@ -107,27 +155,29 @@ def main():
     bg, m3, col, op, sca, rot = t(sc.bg), t(sc.means3D), t(sc.colors), t(sc.opacity), t(sc.scales), t(sc.rotations)
     view, proj, campos = t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center)
     dL = t(sc.dL_dout_color)
-    eng = RasterEngine(sc.P, cam.width, cam.height, dev, resident=not args.sync_forward)
-
+    tstep = None
     if args.mode == "scaffold":
         from segs_slam_amd import neural_gaussians as ng
         dims = ng.ModelDims(appearance_dim=args.appearance_dim, use_feat_bank=not args.no_feat_bank)
         model = ng.synthetic_model(args.anchors, dims, cam, dev, seed=0)   # replicas must be identical; the keyframe differs per rank
         tstep = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
+        tstep.sharded_optimizer = not args.dense_allreduce
         eng = tstep.engine
         kfs = [ng.Keyframe(view, proj, campos, torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)]
         gts = [torch.rand(3, cam.height, cam.width, device=dev)]
         tstep.keyframe_for = lambda step, n: 0
-    if args.mode == "trainer":
+    elif args.mode == "trainer":
         from segs_slam_amd.gaussian_trainer import TrainerStep, keyframe_tensors
-        tstep = TrainerStep.on_gpu(sc, dev)
+        tstep = TrainerStep.on_gpu(sc, dev, sharded_optimizer=not args.dense_allreduce)
         eng = tstep.engine
         kfs = [keyframe_tensors(cam, dev)]
         gts = [torch.rand(3, cam.height, cam.width, device=dev)]
         tstep.keyframe_for = lambda step, n: 0
+    else:
+        eng = RasterEngine(sc.P, cam.width, cam.height, dev, resident=not args.sync_forward)
 
     def step():
-        if args.mode in ("trainer", "scaffold"):
+        if tstep is not None:
             tstep.training_once(kfs, gts)
             return
         eng.forward(bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy)
@@ -140,18 +190,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup; the per-kernel breakdown (all kernels, HIP events) is taken on the warmup steps
-    with KernelProfile() as prof_all:
-        for _ in range(max(args.warmup, 1)):
-            step()
-        torch.cuda.synchronize()
-    breakdown = prof_all.result
-    sort_names = ("radix_count_kernel", "radix_scan_kernel", "radix_scatter_kernel")
-    per_step = {k: v["total_ms"] / max(args.warmup, 1) for k, v in breakdown.items()}
-    dominant = max((k for k in per_step if k != "memset"), key=lambda k: per_step[k])
+    # ---- W untimed warm-up steps (the first one is the calibrating, synchronising forward of the resident engine)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
 
-    # ---- timed region: exactly K steps, barrier + sync on both sides; the dominant kernel is timed live
-    # with HIP events on its launch stream inside this region
+    # ---- timed region: exactly K steps, barrier + sync on both sides; the tile kernels are timed live with HIP events on
+    # their launch stream inside this region
     graph = None
     if args.graph and world == 1 and args.mode == "raster" and not args.sync_forward:
         eng.check()
@@ -160,7 +205,7 @@ def main():
             step()
         torch.cuda.synchronize()
     fence()
-    with KernelProfile([dominant] if graph is None else []) as prof_dom:
+    with KernelProfile(LIVE_EVENT_KERNELS if graph is None else []) as prof_live:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             if graph is not None:
@@ -169,31 +214,49 @@ def main():
                 step()
         fence()
         elapsed = time.perf_counter() - t0
-    if graph is not None:
-        prof_dom.result = {dominant: breakdown[dominant]}
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- per-kernel table: the same steady-state steps once more, every kernel bracketed by HIP events (not in the timed
+    # region: two event records per kernel would perturb it)
+    n_prof = max(1, min(args.steps, 20))
+    with KernelProfile() as prof_all:
+        for _ in range(n_prof):
+            step()
+        torch.cuda.synchronize()
+    breakdown = prof_all.result
+    per_step = {k: v["total_ms"] / n_prof for k, v in breakdown.items()}
+    dominant = max((k for k in per_step if k != "memset"), key=lambda k: per_step[k])
+    sort_names = ("radix_count_kernel", "radix_scan_kernel", "radix_scatter_kernel")
+
     if rank == 0:
         eng.check()
-        # R of the formulas below is the REFERENCE's num_rendered (bounding-square duplication, taken from the calibrating
-        # reference-shaped forward); the resident forwards bin fewer instances (tight rectangles, dead instances dropped)
-        R = eng.R_reference or eng.R
+        # The reference's num_rendered R (bounding-square duplication, from the calibrating reference-shaped forward) prices
+        # the reference's work; the resident forward bins fewer instances (tight rectangles) and drops the dead ones in the
+        # first tile-id pass, so its tile kernels walk `instances_live`: the dominant kernel's roofline is priced on THOSE.
+        R_ref = eng.R_reference or eng.R
+        R_live = getattr(eng, "R_live", 0) or eng.R
         P_vis = int((eng.radii > 0).sum().item())
         gx, gy = (cam.width + 15) // 16, (cam.height + 15) // 16
         passes_tile = (max(1, int(gx * gy - 1).bit_length()) + 7) // 8
-        passes = int(round(breakdown.get("radix_scatter_kernel", {"launches": 0})["launches"] / max(args.warmup, 1)))
+        passes = int(round(breakdown.get("radix_scatter_kernel", {"launches": 0})["launches"] / n_prof))
         passes_depth = max(passes - passes_tile, 0)
-        ab = algorithmic_bytes(eng.P, P_vis, R, cam.width, cam.height, passes_depth, passes_tile)
-        dom = prof_dom.result[dominant]
-        dom_bytes = ab[dominant] if dominant in ab else ab["radix_sort(all passes)"] / (3 * max(passes, 1))
-        traffic, traffic_src = pmc_traffic(args.workload, dominant) if args.mode == "raster" else (None, None)
-        achieved = dom_bytes / (dom["avg_ms"] * 1e-3) / 1e9
-        total_bytes = sum(ab.values())
+        ab_ref = algorithmic_bytes(eng.P_active, P_vis, R_ref, cam.width, cam.height, passes_depth, passes_tile)
+        ab_live = algorithmic_bytes(eng.P_active, P_vis, R_live, cam.width, cam.height, passes_depth, passes_tile)
+        live = prof_live.result.get(dominant)
+        dom = live if live else breakdown[dominant]
+        dom_src = "HIP events inside the timed region" if live else f"HIP events over {n_prof} steady-state steps after the timed region"
+
+        def dom_bytes(ab):
+            return ab[dominant] if dominant in ab else ab["radix_sort(all passes)"] / (3 * max(passes, 1))
+        t_dom = dom["avg_ms"] * 1e-3
+        achieved = dom_bytes(ab_live) / t_dom / 1e9
+        pmc, pmc_src = pmc_entry(args.workload, dominant) if args.mode == "raster" else (None, None)
+        total_bytes = sum(ab_ref.values())
         ms_per_step = elapsed / args.steps * 1e3
-        raster_ms = sum(v for k, v in per_step.items())
+        raster_ms = sum(per_step.values())
         out = {
             "metric": "mapper train-iters/sec (fwd+bwd raster)",
             "value": world * args.steps / elapsed,
@@ -207,24 +270,47 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {eng.P} Gaussians, {cam.width}x{cam.height}, 1 keyframe per GPU, "
-                                   "fwd+bwd raster" + (", RCCL all-reduce of parameter grads" if world > 1 else "")
+            "config": {"workload": f"{args.workload}: {eng.P_active} Gaussians, {cam.width}x{cam.height}, 1 keyframe per GPU, "
+                                   "fwd+bwd raster" + (", RCCL all-reduce of parameter grads" if world > 1 and tstep is None else "")
                                    + (" + L1/SSIM loss + fused Adam" if args.mode == "trainer" else "")
                                    + (f"; anchor-level mapper step: {args.anchors} anchors x 10 offsets -> neural Gaussians "
                                       f"(appearance_dim {args.appearance_dim}, feature bank {'off' if args.no_feat_bank else 'on'}; MLPs fwd+bwd), "
-                                      "L1/SSIM, fused Adam" if args.mode == "scaffold" else ""),
-                       "P": eng.P, "P_visible": P_vis, "num_rendered": R, "instances_binned": eng.R, "width": cam.width, "height": cam.height,
+                                      "L1/SSIM, fused Adam" if args.mode == "scaffold" else "")
+                                   + ((", dense all-reduce" if args.dense_allreduce else ", reduce-scatter -> sharded Adam -> all-gather")
+                                      if (world > 1 and tstep is not None) else ""),
+                       "P": eng.P_active, "P_visible": P_vis, "num_rendered": R_ref, "instances_binned": eng.R, "instances_live": R_live,
+                       "width": cam.width, "height": cam.height,
                        "sort_passes": {"depth_keys_P": passes_depth, "tile_keys_R": passes_tile}, "parallelism": f"keyframe-dp{world}",
                        "forward": "sync (reference API)" if args.sync_forward else "resident (no host sync)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
-                         "note": "tile kernels are VALU-bound, not HBM-bound (SURVEY 8d); see DESIGN.md"},
-            "raster": {"algorithmic_bytes": total_bytes, "kernel_ms_sum": raster_ms,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc.get("hbm_bytes") if pmc else None, "traffic_source": pmc_src,
+                         "algorithmic_bytes_per_launch": dom_bytes(ab_live), "priced_on": "instances_live (what the launch walks)",
+                         "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"], "timing": dom_src,
+                         "on_reference_num_rendered": {"algorithmic_bytes_per_launch": dom_bytes(ab_ref),
+                                                       "achieved": dom_bytes(ab_ref) / t_dom / 1e9,
+                                                       "frac": dom_bytes(ab_ref) / t_dom / 1e9 / HBM_PEAK_GBPS},
+                         "note": "the tile kernels are VALU-/atomic-bound, not HBM-bound (SURVEY 8d): see roofline_valu, roofline_atomic"},
+            "roofline_valu": None, "roofline_atomic": None,
+            "raster": {"algorithmic_bytes": total_bytes, "algorithmic_bytes_live": sum(ab_live.values()), "kernel_ms_sum": raster_ms,
+                       "kernel_ms_source": f"HIP events over {n_prof} steady-state steps after the timed region",
                        "achieved_GBps": total_bytes / (raster_ms * 1e-3) / 1e9,
+                       "whole_step_GBps": total_bytes / (ms_per_step * 1e-3) / 1e9,
+                       "whole_step_frac_of_hbm_peak": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                        "kernel_ms": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
                        "radix_sort_ms": round(sum(per_step.get(k, 0.0) for k in sort_names), 4)},
         }
+        if pmc and "SQ_INSTS_VALU" in pmc:
+            a = pmc["SQ_INSTS_VALU"] / t_dom / 1e9
+            out["roofline_valu"] = {"bound": "valu", "kernel": dominant, "achieved": a, "peak": VALU_PEAK_GINST,
+                                    "unit": "G wave-instructions/s", "frac": a / VALU_PEAK_GINST,
+                                    "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "source": pmc_src,
+                                    "note": "SQ_INSTS_VALU per launch / launch time against 1024 SIMDs x 2.4 GHz / 2 cycles per "
+                                            "wave64 instruction; v_exp/v_rcp/permlane take 8 and v_cndmask/v_cmp/DPP 4 cycles"}
+        if pmc and "write_bytes" in pmc:
+            a = pmc["write_bytes"] / t_dom / 1e9
+            out["roofline_atomic"] = {"bound": "global float atomics", "kernel": dominant, "achieved": a, "peak": ATOMIC_PEAK_GBPS,
+                                      "unit": "GB/s", "frac": a / ATOMIC_PEAK_GBPS, "write_bytes_per_launch": pmc["write_bytes"],
+                                      "algorithmic_atomic_bytes": 36 * R_live, "source": pmc_src}
         try:   # the tile kernels are reported in (pixel, Gaussian) pairs per second next to the byte figure
             out["raster"].update(pair_rates(eng, cam, per_step))
         except Exception as e:  # noqa: BLE001  (measurement garnish only; never fail the bench line over it)
@@ -262,10 +348,11 @@ def pair_rates(eng, cam, per_step):
     return out
 
 
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE and
-    WRITE_SIZE need separate passes, so they cannot be collected inside the timed run): profiles/rNN_pmc_<workload>.json,
-    written by tools/collect_profiles.sh + tools/pmc_summary.py (FETCH_SIZE doubled per the gfx950 correction)."""
+def pmc_entry(workload, kernel):
+    """Per-launch counters of `kernel` from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE, WRITE_SIZE
+    and the SQ counters need separate passes, so they cannot be collected inside the timed run): the newest
+    profiles/rNN_pmc_<workload>.json, written by tools/collect_profiles.sh + tools/pmc_summary.py (FETCH_SIZE doubled per the
+    gfx950 correction; the calibrating first step is left out)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{workload}.json")))
     if not files:
@@ -273,12 +360,12 @@ def pmc_traffic(workload, kernel):
     with open(files[-1]) as f:
         tab = json.load(f)
     e = tab.get("segs::" + kernel)
-    if not e or "hbm_bytes" not in e:
+    if not e:
         return None, None
-    return e["hbm_bytes"], os.path.relpath(files[-1], ROOT)
+    return e, os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(sc, budget_s: float = 12.0, max_iters: int = 10):
+def cpu_baseline(sc, budget_s: float = 15.0, max_iters: int = 10):
     """The CPU oracle (a port of the reference algorithm; the reference has no CPU raster path)
     timed on this host: whole fwd+bwd iterations of the same workload until about `budget_s` seconds of wall time are
     spent (at least 2, at most `max_iters`); the first iteration is reported but not counted (page faults, thread start)."""

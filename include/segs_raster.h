@@ -140,23 +140,26 @@ int segs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* 
                     int n, int end_bit, char* temp, void* stream);
 
 /* ---- Resident (steady-state) variants for training loops: NO host synchronisation and a fixed launch sequence
- * (hipGraph-capturable).  The caller owns all scratch: geom_buffer >= segs_geometry_bytes(P), image_buffer >=
- * segs_image_bytes(W,H), binning_buffer >= segs_resident_binning_bytes(P, capacity) where `capacity` bounds the number of
- * (Gaussian, tile) instances.  `status` is 4 device words: [0] = num_rendered R, [3] = 1 if R exceeded the capacity
+ * (hipGraph-capturable).  The caller owns all scratch: geom_buffer >= segs_geometry_bytes(geom_rows), image_buffer >=
+ * segs_image_bytes(W,H), binning_buffer >= segs_resident_binning_bytes(geom_rows, capacity).  `geom_rows` >= P is the row
+ * count the geometry buffer was sized (and zero-filled) for: its carve-up is keyed by it, NOT by P, so a caller may
+ * rasterize any P <= geom_rows rows from call to call (a map that grows and shrinks inside pre-sized buffers) without the
+ * self-cleaned accumulator rows moving under it.  `capacity` bounds the number of
+ * (Gaussian, tile) instances.  `status` is 4 device words: [0] = num_rendered R (instances binned), [1] = instances live after the dead ones were dropped, [3] = 1 if R exceeded the capacity
  * (outputs of that call are then meaningless; re-run with a larger capacity).  geom_buffer must be ZERO-FILLED before its
  * first use: the resident backward does not clear the per-Gaussian gradient accumulators inside it with a fill per call,
  * it writes zeros back over each row it consumes (a buffer that is clean stays clean).  The reference has no counterpart: its
  * forward always blocks on a device-to-host copy of R (rasterizer_impl.cu:281). */
 size_t segs_resident_binning_bytes(int P, int capacity);
 int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity,
-                                    int P, int D, int M, const float* background, int width, int height,
+                                    int geom_rows, int P, int D, int M, const float* background, int width, int height,
                                     const float* means3D, const float* shs, const float* colors_precomp,
                                     const float* opacities, const float* scales, float scale_modifier,
                                     const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                                     const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                                     float* out_color, int* radii, uint32_t* status, void* stream);
 int segs_rasterize_backward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity,
-                                     int P, int D, int M, const float* background, int width, int height,
+                                     int geom_rows, int P, int D, int M, const float* background, int width, int height,
                                      const float* means3D, const float* shs, const float* scales, float scale_modifier,
                                      const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                                      const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,

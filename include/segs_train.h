@@ -42,6 +42,17 @@ int segs_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp
                            double beta1, double beta2, double eps, int64_t step, float grad_scale, int zero_grad,
                            const uint32_t* skip_flag, void* stream);
 
+/* Same, with the step count kept ON THE DEVICE: device_steps points at two int64 words (zero-filled before the first
+ * call; the pair is used in turn -- call number `call_index` = 0, 1, 2, ... of this state reads word call_index & 1 as the
+ * number of steps taken so far and leaves the count after this call in the other word).  A call whose skip_flag is set does
+ * not advance the count, exactly as torch::optim::Adam only counts the steps it takes; with the flag all-reduced over the
+ * ranks of a keyframe-parallel job every replica drops the same steps and no rank ever has to synchronise with its device
+ * to keep the bias corrections (formed in the kernel, in double: 1 - pow(beta, t)) right. */
+int segs_adam_step_device(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                          const segs_adam_segment* segments, int nseg,
+                          double beta1, double beta2, double eps, int64_t* device_steps, int call_index,
+                          float grad_scale, int zero_grad, const uint32_t* skip_flag, void* stream);
+
 /* Fused L1 + SSIM loss of the trainer/mapper step and its gradient w.r.t. the rendered image:
  *     loss = (1 - lambda) * mean|img1 - img2| + lambda * (1 - mean(SSIM(img1, img2)))
  * (src/gaussian_trainer.cpp:89-90, src/gaussian_mapper.cpp:924-928 with loss_utils::l1_loss / ssim,

@@ -49,9 +49,9 @@ SYMBOLS = {
     "segs_rasterize_backward": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "segs_resident_binning_bytes": (_sz, [_i, _i]),
-    "segs_rasterize_forward_resident": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp,
+    "segs_rasterize_forward_resident": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp,
                                               _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
-    "segs_rasterize_backward_resident": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp,
+    "segs_rasterize_backward_resident": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp,
                                                _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "segs_visible_filter": (_i, [_i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),
     "segs_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
@@ -73,6 +73,7 @@ SYMBOLS = {
     "segs_l1_ssim_loss": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "segs_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_int64, _f, _i, _vp]),
     "segs_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_int64, _f, _i, _vp, _vp]),
+    "segs_adam_step_device": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, _vp, _i, _f, _i, _vp, _vp]),
     "segs_profile_begin": (_i, [C.c_uint]),
     "segs_profile_end": (_i, []),
     "segs_profile_kernel_count": (_i, []),

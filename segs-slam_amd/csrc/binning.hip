@@ -192,7 +192,10 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
   // first owner: first g with incl[g] > s0; last owner: first g with incl[g] >= s1   (wave-uniform searches)
   const int g_lo = wave_lower_bound<true>(incl, P, s0);
   const int lo = wave_lower_bound<false>(incl, P, s1);
-  const int n_own = min(lo, P - 1) - g_lo + 1;  // <= EMIT_SLOTS: every owner has at least one instance in range
+  // <= EMIT_SLOTS when every owner has at least one instance in range.  In resident mode a binned Gaussian whose depth key
+  // reached the culled key (the step is then flagged through status[2] and redone) can leave zero-instance owners between
+  // binned ones: the clamp keeps that flagged launch inside the LDS staging arrays.
+  const int n_own = min(min(lo, P - 1) - g_lo + 1, EMIT_SLOTS + 1);
   const uint32_t excl0 = g_lo == 0 ? 0u : incl[g_lo - 1];
   for (int k = tid; k < n_own; k += 256) {
     const uint32_t idx = order[g_lo + k];
@@ -479,7 +482,10 @@ __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const 
       const uint32_t over = (n > (uint32_t)L || status[2] != 0u) ? 1u : 0u;
       status[2] = 0u;
       status[3] = over;
-      if (status_mirror) { status_mirror[0] = n; status_mirror[3] = over; }
+      // status[1]: instances left after the first tile-id pass dropped the dead ones (what the tile kernels walk)
+      const uint32_t live = n_live ? min(*n_live, min(n, (uint32_t)L)) : min(n, (uint32_t)L);
+      status[1] = live;
+      if (status_mirror) { status_mirror[0] = n; status_mirror[1] = live; status_mirror[3] = over; }
     }
     L = (int)min(n, (uint32_t)L);
   }

@@ -141,6 +141,15 @@ struct Geom {
   uint32_t* touched() const { return (uint32_t*)(base + L.touched); }
 };
 Geom geom_at(char* p, int P) { return Geom{geom_layout(P), align_ptr(p)}; }
+// Resident buffers are carved up for the `rows` they were ALLOCATED (and zero-filled) for, so that the self-cleaned
+// accumulator rows stay where they are when the caller rasterizes fewer rows (a map that shrinks inside pre-sized
+// buffers); only the launch extent follows P.
+Geom geom_at(char* p, int P, int rows) {
+  Geom g{geom_layout(rows), align_ptr(p)};
+  g.L.P = P;
+  g.L.nblocks = (P + 255) / 256;
+  return g;
+}
 
 int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, const float* colors, const float* opac,
                    const float* scales, float mod, const float* rots, const float* cov3D_precomp, const float* view,
@@ -323,9 +332,10 @@ static int rasterize_backward_impl(int P, int D, int M, int R, const float* back
                             float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
                             const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                             float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream,
-                            bool self_clean) {
+                            bool self_clean, int geom_rows) {
   hipStream_t st = (hipStream_t)stream;
   if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (geom_rows < P) return fail(SEGS_ERR_INVALID_ARGUMENT, "geom_rows must be >= P");
   if (P == 0) return SEGS_OK;  // src/rasterize_points.cu:159
   if (shs && (!campos || !dL_dsh || M <= 0)) return fail(SEGS_ERR_INVALID_ARGUMENT, "SH path needs campos, dL_dsh and M > 0");
   if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background || !means3D || !viewmatrix || !projmatrix)
@@ -334,7 +344,7 @@ static int rasterize_backward_impl(int P, int D, int M, int R, const float* back
     return fail(SEGS_ERR_INVALID_ARGUMENT, "null gradient output");
   if (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))
     return fail(SEGS_ERR_INVALID_ARGUMENT, "need scales+rotations (+ their gradient outputs) or cov3D_precomp");
-  Geom G = geom_at(geom_buffer, P);
+  Geom G = geom_at(geom_buffer, P, geom_rows);
   if (!radii) radii = G.radii_internal();
   const ImageLayout IL = image_layout(width, height);
   const BinningLayout BL = binning_layout(R);
@@ -376,7 +386,7 @@ int segs_rasterize_backward(int P, int D, int M, int R, const float* background,
   return rasterize_backward_impl(P, D, M, R, background, width, height, means3D, shs, scales, scale_modifier, rotations,
                                  cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
                                  image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
-                                 dL_dscale, dL_drot, stream, false);
+                                 dL_dscale, dL_drot, stream, false, P);
 }
 
 int segs_visible_filter(int P, int M, int width, int height, const float* means3D, const float* scales,
@@ -533,7 +543,7 @@ int segs_project2_image(int P, int D, int M, int width, int height, const float*
 // ---- Resident (steady-state) variants: no host synchronisation, fixed launch sequence (hipGraph-capturable). ----
 size_t segs_resident_binning_bytes(int P, int capacity) { return gauss_sort_layout(capacity < 0 ? 0 : capacity, P < 0 ? 0 : P).total; }
 
-int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity, int P, int D, int M,
+int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity, int geom_rows, int P, int D, int M,
                                     const float* background, int width, int height, const float* means3D, const float* shs,
                                     const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
                                     const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
@@ -541,7 +551,8 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
                                     int* radii, uint32_t* status, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (P <= 0 || capacity <= 0 || width <= 0 || height <= 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad sizes");
-  if (P > MAX_GAUSSIANS) return fail(SEGS_ERR_INVALID_ARGUMENT, "P exceeds 2^28 Gaussians");
+  if (geom_rows < P) return fail(SEGS_ERR_INVALID_ARGUMENT, "geom_rows (rows the geometry buffer was sized for) must be >= P");
+  if (geom_rows > MAX_GAUSSIANS) return fail(SEGS_ERR_INVALID_ARGUMENT, "P exceeds 2^28 Gaussians");
   if (!geom_buffer || !binning_buffer || !image_buffer || !status || !background || !out_color || !viewmatrix || !projmatrix ||
       !means3D || !opacities)
     return fail(SEGS_ERR_INVALID_ARGUMENT, "null required pointer");
@@ -550,7 +561,7 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
   if (!cov3D_precomp && (!scales || !rotations)) return fail(SEGS_ERR_INVALID_ARGUMENT, "need scales+rotations or cov3D_precomp");
   const uint32_t gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
   if (gx > 0xFFFFu || gy > 0xFFFFu) return fail(SEGS_ERR_INVALID_ARGUMENT, "image too large for 16-bit tile coordinates");
-  Geom G = geom_at(geom_buffer, P);
+  Geom G = geom_at(geom_buffer, P, geom_rows);
   char* img = align_ptr(image_buffer);
   char* bin = align_ptr(binning_buffer);
   const ImageLayout IL = image_layout(width, height);
@@ -583,7 +594,7 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
   return SEGS_OK;
 }
 
-int segs_rasterize_backward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity, int P, int D, int M,
+int segs_rasterize_backward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity, int geom_rows, int P, int D, int M,
                                      const float* background, int width, int height, const float* means3D, const float* shs,
                                      const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
                                      const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
@@ -595,7 +606,7 @@ int segs_rasterize_backward_resident(char* geom_buffer, char* binning_buffer, ch
   return rasterize_backward_impl(P, D, M, capacity, background, width, height, means3D, shs, scales, scale_modifier, rotations,
                                  cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
                                  image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
-                                 dL_dscale, dL_drot, stream, true);
+                                 dL_dscale, dL_drot, stream, true, geom_rows);
 }
 
 // ---- measurement support (bench.py): HIP events recorded on the launch stream around selected kernels.

@@ -20,6 +20,7 @@ struct SegTable {
   long long offset[MAX_SEG];
   long long count[MAX_SEG];
   float step_size[MAX_SEG];  // lr / (1 - b1^t)
+  double lr[MAX_SEG];        // device-side step count (segs_adam_step_device): step_size is formed in the kernel
   int block_start[MAX_SEG + 1];  // first workgroup of each segment: segments run side by side, not one after the other
   int nseg;
 };
@@ -36,10 +37,17 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 // One workgroup = one chunk of 1024 aligned float4 vectors of ONE segment (plus, for the segment's first workgroup, its
 // <= 3 unaligned head and <= 3 tail elements).  The first version looped over the segments inside every thread: the ten
 // small MLP segments then cost one dependent global round trip each (27 us for 3.6 M parameters, 47 % of the copy rate).
+// DEVICE_STEP: the step count t lives on the device (two int64 words used in turn: this launch reads steps[parity] and its
+// first workgroup leaves the count after this call in steps[parity ^ 1], so no workgroup can read a count another one has
+// already advanced).  A guarded step that is skipped does not advance it -- torch::optim::Adam only counts the steps it
+// takes -- and the host never has to learn whether it was.  The bias corrections are formed like LibTorch's, in double
+// (1 - pow(beta, t)), by one lane per workgroup.
+template <bool DEVICE_STEP>
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
                                                    float* __restrict__ v, SegTable tab, float b1, float b2, float omb1, float omb2,
                                                    float sqrt_bc2, float eps, float gscale, int zero_grad,
-                                                   const uint32_t* __restrict__ skip_flag) {
+                                                   const uint32_t* __restrict__ skip_flag, long long* __restrict__ steps, int parity,
+                                                   double beta1, double beta2) {
   // guarded step: the gradients of an iteration the resident rasterizer flagged as overflowed are discarded on the
   // device (parameters and moments untouched, gradient bucket cleared) without the host having to look first
   const bool skip = skip_flag != nullptr && *skip_flag != 0u;
@@ -47,7 +55,21 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
   while (s + 1 < tab.nseg && (int)blockIdx.x >= tab.block_start[s + 1]) s++;   // wave-uniform, <= 15 steps
   const int b = (int)blockIdx.x - tab.block_start[s];
   const long long off = tab.offset[s], cnt = tab.count[s];
-  const float ss = tab.step_size[s];
+  float ss = tab.step_size[s];
+  if (DEVICE_STEP) {
+    __shared__ float s_ss, s_sqrt_bc2;
+    if (threadIdx.x == 0) {
+      const long long done = steps[parity];
+      const double t = (double)(done + 1);
+      const double bc1 = 1.0 - pow(beta1, t), bc2 = 1.0 - pow(beta2, t);
+      s_ss = (float)(tab.lr[s] / bc1);
+      s_sqrt_bc2 = (float)sqrt(bc2);
+      if (blockIdx.x == 0) steps[parity ^ 1] = skip ? done : done + 1;
+    }
+    __syncthreads();
+    ss = s_ss;
+    sqrt_bc2 = s_sqrt_bc2;
+  }
   const long long head = min(cnt, (long long)((4 - (off & 3)) & 3));
   const long long nvec = (cnt - head) / 4;
   const long long a0 = off + head;                       // first 16-byte aligned element of the segment
@@ -99,17 +121,21 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
 }
 }  // namespace
 
-extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,
-                                      int nseg, double beta1, double beta2, double eps, int64_t step, float grad_scale, int zero_grad,
-                                      const uint32_t* skip_flag, void* stream) {
-  if (!param || !grad || !exp_avg || !exp_avg_sq || !segments || nseg <= 0 || nseg > MAX_SEG || step <= 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
+namespace {
+int adam_launch(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments, int nseg,
+                double beta1, double beta2, double eps, int64_t step, float grad_scale, int zero_grad, const uint32_t* skip_flag,
+                long long* device_steps, int parity, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !segments || nseg <= 0 || nseg > MAX_SEG || (!device_steps && step <= 0))
+    return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   SegTable tab{};
   tab.nseg = nseg;
   long long total = 0, blocks = 0;
-  // bias corrections in double on the host, like LibTorch (1 - std::pow(beta, step))
-  const double bc1 = 1.0 - std::pow(beta1, (double)step);
-  const double bc2 = 1.0 - std::pow(beta2, (double)step);
+  // bias corrections in double on the host, like LibTorch (1 - std::pow(beta, step)); with a device-side step count the
+  // kernel forms them itself
+  const double bc1 = device_steps ? 1.0 : 1.0 - std::pow(beta1, (double)step);
+  const double bc2 = device_steps ? 1.0 : 1.0 - std::pow(beta2, (double)step);
   for (int i = 0; i < nseg; i++) {
+    tab.lr[i] = segments[i].lr;
     if (segments[i].offset < 0 || segments[i].count < 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
     tab.offset[i] = segments[i].offset;
     tab.count[i] = segments[i].count;
@@ -120,15 +146,37 @@ extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg,
     if (segments[i].count > 0) blocks += (segments[i].count / 4 + CHUNK_VEC - 1) / CHUNK_VEC + (segments[i].count < 4 ? 1 : 0);
     if (blocks > 0x7FFFFFFF) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "Adam bucket too large for one launch");
   }
+  if (device_steps && blocks == 0) blocks = 1;   // nothing to update (an empty shard): one workgroup still advances the count
   tab.block_start[nseg] = (int)blocks;
-  if (total == 0) return SEGS_OK;
+  if (total == 0 && !device_steps) return SEGS_OK;
   const float sqrt_bc2 = (float)std::sqrt(bc2);
   // Scalars cross into the float32 tensor arithmetic the way LibTorch's do: computed in double, rounded once
-  adam_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, tab, (float)beta1, (float)beta2,
-                                                            (float)(1.0 - beta1), (float)(1.0 - beta2), sqrt_bc2, (float)eps,
-                                                            grad_scale, zero_grad, skip_flag);
+  if (device_steps)
+    adam_kernel<true><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, tab, (float)beta1, (float)beta2,
+                                                                    (float)(1.0 - beta1), (float)(1.0 - beta2), sqrt_bc2, (float)eps,
+                                                                    grad_scale, zero_grad, skip_flag, device_steps, parity & 1, beta1, beta2);
+  else
+    adam_kernel<false><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, tab, (float)beta1, (float)beta2,
+                                                                     (float)(1.0 - beta1), (float)(1.0 - beta2), sqrt_bc2, (float)eps,
+                                                                     grad_scale, zero_grad, skip_flag, nullptr, 0, beta1, beta2);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
+}
+}  // namespace
+
+extern "C" int segs_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,
+                                      int nseg, double beta1, double beta2, double eps, int64_t step, float grad_scale, int zero_grad,
+                                      const uint32_t* skip_flag, void* stream) {
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, segments, nseg, beta1, beta2, eps, step, grad_scale, zero_grad, skip_flag,
+                     nullptr, 0, stream);
+}
+
+extern "C" int segs_adam_step_device(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,
+                                     int nseg, double beta1, double beta2, double eps, int64_t* device_steps, int call_index,
+                                     float grad_scale, int zero_grad, const uint32_t* skip_flag, void* stream) {
+  if (!device_steps) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "null device step state");
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, segments, nseg, beta1, beta2, eps, 0, grad_scale, zero_grad, skip_flag,
+                     (long long*)device_steps, call_index, stream);
 }
 
 extern "C" int segs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,

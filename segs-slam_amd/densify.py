@@ -41,16 +41,35 @@ class AnchorDensifier:
         self._lib = model._lib
         self._alloc_stats(model.capacity)
 
+    STAT_NAMES = ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom")
+
     def _alloc_stats(self, capacity: int):
+        """The four accumulators are segments of ONE flat tensor (`_stats_flat`), and so is their keyframe-parallel shadow
+        `_delta_flat`: with N ranks every rank accumulates its own keyframe's increments there, and reduce_statistics() folds
+        the sum over ranks into the replicated accumulators with one all-reduce right before adjust_anchor."""
         f = dict(dtype=torch.float32, device=self.model.device)
         no = self.model.dims.n_offsets
-        old = getattr(self, "_stats", None)
+        old, old_delta = getattr(self, "_stats", None), getattr(self, "_delta", None)
         self._stats_capacity = capacity
-        self._stats = {"opacity_accum": torch.zeros(capacity, **f), "anchor_demon": torch.zeros(capacity, **f),
-                       "offset_gradient_accum": torch.zeros(capacity * no, **f), "offset_denom": torch.zeros(capacity * no, **f)}
-        if old is not None:
-            for k, t in old.items():
-                self._stats[k][:t.numel()] = t
+        sizes = (capacity, capacity, capacity * no, capacity * no)
+        self._stats_flat, self._delta_flat = torch.zeros(sum(sizes), **f), torch.zeros(sum(sizes), **f)
+        self._stats, self._delta, off = {}, {}, 0
+        for name, n in zip(self.STAT_NAMES, sizes):
+            self._stats[name], self._delta[name] = self._stats_flat[off:off + n], self._delta_flat[off:off + n]
+            off += n
+        for new, prev in ((self._stats, old), (self._delta, old_delta)):
+            if prev is not None:
+                for k, t in prev.items():
+                    new[k][:t.numel()] = t
+
+    def reduce_statistics(self, process_group=None):
+        """Fold every rank's increments since the last call into the replicated accumulators: one all-reduce(sum) of the
+        flat shadow, the same words on every rank, so adjust_anchor then runs bit-identically everywhere."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            dist.all_reduce(self._delta_flat, group=process_group)
+        self._stats_flat += self._delta_flat
+        self._delta_flat.zero_()
 
     # views over the live rows, shaped like the reference's tensors
     def stat(self, name):
@@ -62,11 +81,12 @@ class AnchorDensifier:
         return C.c_void_p(torch.cuda.current_stream(self.model.device).cuda_stream)
 
     def training_statis(self, neural: NeuralGaussians, visible_radii: torch.Tensor, radii: torch.Tensor, dL_dmean2D: torch.Tensor,
-                        skip_flag: Optional[C.c_void_p] = None):
+                        skip_flag: Optional[C.c_void_p] = None, into_delta: bool = False):
         """src/gaussian_model.cpp:1459-1503 in the candidate domain (called between start_stat and update_until).
-        `skip_flag`: device address of the resident rasterizer's overflow word; the pass is then dropped on the device."""
+        `skip_flag`: device address of the resident rasterizer's overflow word; the pass is then dropped on the device.
+        `into_delta`: keyframe-parallel ranks accumulate into the shadow that reduce_statistics() sums over ranks."""
         m = self.model
-        s = self._stats
+        s = self._delta if into_delta else self._stats
         st = self._lib.segs_training_statis_guarded(m.A, m.dims.n_offsets, _p(neural.neural_opacity), _p(visible_radii), _p(radii),
                                                     _p(dL_dmean2D), _p(s["opacity_accum"]), _p(s["anchor_demon"]),
                                                     _p(s["offset_gradient_accum"]), _p(s["offset_denom"]), skip_flag, self._stream())
@@ -144,12 +164,15 @@ class AnchorDensifier:
 
     def adjust_anchor(self, check_interval: Optional[int] = None, success_threshold: Optional[float] = None,
                       grad_threshold: Optional[float] = None, min_opacity: Optional[float] = None,
-                      rands: Optional[List[torch.Tensor]] = None, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+                      rands: Optional[List[torch.Tensor]] = None, generator: Optional[torch.Generator] = None,
+                      views_per_iteration: int = 1) -> torch.Tensor:
         """:1701-1762.  `rands` (one tensor of A*no uniforms per level) stands for torch::rand_like (:1568); drawn from
-        `generator` (shared seed on every rank) when absent.  Returns the prune mask."""
+        `generator` (shared seed on every rank) when absent.  Returns the prune mask.
+        `views_per_iteration`: keyframe-parallel training accumulates N keyframes per iteration, so the "seen in more than
+        this fraction of the window" thresholds (check_interval * success_threshold) count views, not iterations."""
         m, p = self.model, self.p
         no = m.dims.n_offsets
-        check_interval = p.update_interval if check_interval is None else check_interval
+        check_interval = (p.update_interval if check_interval is None else check_interval) * int(views_per_iteration)
         success_threshold = p.success_threshold if success_threshold is None else success_threshold
         grad_threshold = p.densify_grad_threshold if grad_threshold is None else grad_threshold
         min_opacity = p.min_opacity if min_opacity is None else min_opacity

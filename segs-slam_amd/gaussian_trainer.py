@@ -5,9 +5,10 @@ Mirror of the loop body of GaussianTrainer::trainingOnce (src/gaussian_trainer.c
 (means3D, scales, rotations, opacity, colors = 14 floats per Gaussian, one flat fp32 bucket).
 
 Keyframe-parallel training (new functionality: the reference is single-GPU, F3): one process
-per GPU, every rank holds a full replica, rank r renders keyframe r of the step; the only exchange is ONE
-all-reduce(sum) of the flat gradient bucket (RCCL over xGMI when the backend is "nccl"); the fused Adam then
-applies the same averaged gradient on every rank, so replicas stay bit-identical.
+per GPU, every rank holds a full replica, rank r renders keyframe r of the step; the only exchange is the one of
+keyframe_parallel.BucketExchange over the flat gradient bucket (RCCL over xGMI when the backend is "nccl"):
+reduce-scatter -> fused Adam on this rank's shard -> all-gather of the parameters (or, dense, one all-reduce and a full
+Adam on every rank); replicas stay bit-identical either way.
 
 The raster backend and the optimizer are injectable so that the distributed logic can be exercised on CPU
 (gloo, world_size 2) in tests; the product wiring is `TrainerStep.on_gpu(...)` = HIP engine + fused HIP Adam.
@@ -50,8 +51,38 @@ def expon_lr(step: int, lr_init: float, lr_final: float, max_steps: int) -> floa
     return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
 
 
+class DeviceStepCount:
+    """Step count of one set of torch::optim::Adam parameter groups, kept on the device (segs_adam_step_device,
+    include/segs_train.h): two int64 words used in turn, `calls` says which one the next launch reads.  A guarded step that
+    the device drops does not advance it, and the host never has to find out."""
+
+    def __init__(self, device):
+        self.words = torch.zeros(2, dtype=torch.int64, device=device)
+        self.calls = 0
+
+    def clone(self) -> "DeviceStepCount":
+        c = DeviceStepCount(self.words.device)
+        c.words.copy_(self.words)
+        c.calls = self.calls
+        return c
+
+    def value(self) -> int:
+        """Steps taken so far (synchronises; for tests and checkpoints)."""
+        return int(self.words[self.calls & 1].item())
+
+
+def field_segments(lrs: Dict[str, float], P: int):
+    """(offset, count, lr) of the five per-Gaussian fields inside the flat bucket (raster_engine.FIELDS order)."""
+    out, off = [], 0
+    for name, n in FIELDS:
+        out.append((off, P * n, float(lrs[name])))
+        off += P * n
+    return out
+
+
 class FusedAdam:
-    """segs_adam_step over the flat bucket (include/segs_train.h)."""
+    """segs_adam_step_device over the flat bucket (include/segs_train.h): one launch, step count on the device, optionally
+    guarded by a device word (the all-reduced overflow word of the resident rasterizer) and restricted to a shard."""
 
     def __init__(self, n_params: int, device, opt: OptimizationParams):
         from . import _capi
@@ -60,20 +91,28 @@ class FusedAdam:
         self.opt = opt
         self.exp_avg = torch.zeros(n_params, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(n_params, dtype=torch.float32, device=device)
-        self.step_count = 0
+        self.count = DeviceStepCount(device)
 
-    def step(self, params_flat: torch.Tensor, grads_flat: torch.Tensor, lrs: Dict[str, float], P: int, grad_scale: float):
-        self.step_count += 1
-        segs = (self._capi.AdamSegment * len(FIELDS))()
-        off = 0
-        for i, (name, n) in enumerate(FIELDS):
-            segs[i].offset, segs[i].count, segs[i].lr = off, P * n, float(lrs[name])
-            off += P * n
+    @property
+    def step_count(self) -> int:
+        return self.count.value()
+
+    def step(self, params_flat: torch.Tensor, grads_flat: torch.Tensor, lrs: Dict[str, float], P: int, grad_scale: float,
+             exchange=None, guard: Optional[torch.Tensor] = None):
+        groups = field_segments(lrs, P)
+        if exchange is not None:
+            groups = exchange.clip_segments(groups) or [(0, 0, 0.0)]
+        segs = (self._capi.AdamSegment * len(groups))()
+        for i, (o, n, lr) in enumerate(groups):
+            segs[i].offset, segs[i].count, segs[i].lr = o, n, lr
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        st = self._lib.segs_adam_step(p(params_flat), p(grads_flat), p(self.exp_avg), p(self.exp_avg_sq), segs, len(FIELDS),
-                                      self.opt.beta1, self.opt.beta2, self.opt.eps, self.step_count, float(grad_scale), 1,
-                                      C.c_void_p(torch.cuda.current_stream(params_flat.device).cuda_stream))
-        self._capi.check(st, "segs_adam_step")
+        call = self.count.calls
+        self.count.calls += 1
+        st = self._lib.segs_adam_step_device(p(params_flat), p(grads_flat), p(self.exp_avg), p(self.exp_avg_sq), segs, len(groups),
+                                             self.opt.beta1, self.opt.beta2, self.opt.eps, p(self.count.words), call,
+                                             float(grad_scale), 1, p(guard) if guard is not None else None,
+                                             C.c_void_p(torch.cuda.current_stream(params_flat.device).cuda_stream))
+        self._capi.check(st, "segs_adam_step_device")
 
 
 class FusedL1SSIM:
@@ -105,20 +144,25 @@ class TorchAdam:
         self.exp_avg_sq = torch.zeros(n_params, dtype=torch.float32, device=device)
         self.step_count = 0
 
-    def step(self, params_flat, grads_flat, lrs, P, grad_scale):
+    def step(self, params_flat, grads_flat, lrs, P, grad_scale, exchange=None, guard=None):
+        """`exchange`: update only this rank's shard (moments outside it are not kept current, as in FusedAdam)."""
         o = self.opt
+        if guard is not None and int(guard.reshape(-1)[0]) != 0:
+            grads_flat.zero_()
+            return
         self.step_count += 1
         bc1 = 1.0 - o.beta1 ** self.step_count
         bc2 = 1.0 - o.beta2 ** self.step_count
-        g = grads_flat * grad_scale
-        self.exp_avg.mul_(o.beta1).add_(g, alpha=1 - o.beta1)
-        self.exp_avg_sq.mul_(o.beta2).addcmul_(g, g, value=1 - o.beta2)
-        denom = (self.exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(o.eps)
-        off = 0
-        for name, n in FIELDS:
-            sl = slice(off, off + P * n)
-            params_flat[sl].addcdiv_(self.exp_avg[sl], denom[sl], value=-(lrs[name] / bc1))
-            off += P * n
+        groups = field_segments(lrs, P)
+        if exchange is not None:
+            groups = exchange.clip_segments(groups)
+        for off, cnt, lr in groups:
+            sl = slice(off, off + cnt)
+            g = grads_flat[sl] * grad_scale
+            self.exp_avg[sl].mul_(o.beta1).add_(g, alpha=1 - o.beta1)
+            self.exp_avg_sq[sl].mul_(o.beta2).addcmul_(g, g, value=1 - o.beta2)
+            denom = (self.exp_avg_sq[sl].sqrt() / math.sqrt(bc2)).add_(o.eps)
+            params_flat[sl].addcdiv_(self.exp_avg[sl], denom, value=-(lr / bc1))
         grads_flat.zero_()
 
 
@@ -127,15 +171,19 @@ class TrainerStep:
     render the keyframe, call dL_fn(image) -> (loss, dL_dimage) and leave parameter gradients in `grads_flat`."""
 
     def __init__(self, params_flat: torch.Tensor, P: int, render_backward: Callable, optimizer, opt: OptimizationParams,
-                 grads_flat: torch.Tensor, process_group=None):
+                 grads_flat: torch.Tensor, process_group=None, sharded_optimizer: bool = True):
+        import inspect
+        from .keyframe_parallel import BucketExchange
         assert params_flat.numel() == FLOATS_PER_GAUSSIAN * P and grads_flat.numel() == params_flat.numel()
         self.params_flat, self.grads_flat, self.P = params_flat, grads_flat, P
         self.params = split_flat(params_flat, P)
         self.render_backward, self.optimizer, self.opt = render_backward, optimizer, opt
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self.exchange = BucketExchange(params_flat.numel(), params_flat.device, process_group, sharded=sharded_optimizer)
+        self.world, self.rank = self.exchange.world, self.exchange.rank
         self.iteration = 0
+        # a backend that knows an overflow word (the HIP engine) takes a hook it calls right after its forward
+        self._backend_takes_hook = render_backward is not None and "after_forward" in inspect.signature(render_backward).parameters
 
     def learning_rates(self, iteration: int) -> Dict[str, float]:
         o = self.opt  # updateLearningRate (src/gaussian_model.cpp:874-998): only the position group is scheduled
@@ -159,18 +207,28 @@ class TrainerStep:
         return (step * self.world + self.rank) % n_keyframes
 
     def training_once(self, keyframes, gt_images) -> torch.Tensor:
+        """Nothing here waits for the device: a pass whose instance count outgrew some rank's resident capacity is dropped by
+        every rank on the device (the optimizer is guarded by the all-reduced overflow word and its step count lives there);
+        the rank concerned re-sizes its scratch at its next forward."""
         self.iteration += 1
         lrs = self.learning_rates(self.iteration)
         k = self.keyframe_for(self.iteration - 1, len(keyframes))
-        loss = self.render_backward(self.params, keyframes[k], lambda im: self.loss_and_grad(im, gt_images[k]))
-        if self.world > 1:
-            dist.all_reduce(self.grads_flat, group=self.pg)  # sum over keyframes of this step
-        self.optimizer.step(self.params_flat, self.grads_flat, lrs, self.P, 1.0 / self.world)
+        ex = self.exchange
+        dL_fn = lambda im: self.loss_and_grad(im, gt_images[k])  # noqa: E731
+        if self._backend_takes_hook:
+            loss = self.render_backward(self.params, keyframes[k], dL_fn, after_forward=ex.reduce_flag_async)
+        else:
+            loss = self.render_backward(self.params, keyframes[k], dL_fn)
+            ex.reduce_flag_async(None)
+        flag = ex.wait_flag()
+        ex.reduce_gradients(self.grads_flat)  # sum over the keyframes of this step
+        self.optimizer.step(self.params_flat, self.grads_flat, lrs, self.P, 1.0 / self.world, exchange=ex, guard=flag)
+        ex.gather(self.params_flat)
         return loss
 
     # ---- product wiring -------------------------------------------------------------------------------
     @staticmethod
-    def on_gpu(scene, device, opt: Optional[OptimizationParams] = None, process_group=None):
+    def on_gpu(scene, device, opt: Optional[OptimizationParams] = None, process_group=None, sharded_optimizer: bool = True):
         """HIP raster engine + fused HIP Adam over a segs_slam_amd.scenes.Scene's Gaussians."""
         import numpy as np
         from .raster_engine import RasterEngine
@@ -185,23 +243,20 @@ class TrainerStep:
             views[name].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
         bg = torch.from_numpy(scene.bg).to(device)
 
-        def render_backward(params, keyframe, dL_fn):
+        def render_backward(params, keyframe, dL_fn, after_forward=None):
             view, proj, campos, tanx, tany = keyframe
+            # (a forward that finds the previous pass overflowed goes through the synchronising path and re-sizes the scratch)
             image = eng.forward(bg, params["means3D"], params["colors"], params["opacity"], params["scales"],
                                 params["rotations"], view, proj, campos, tanx, tany)
+            if after_forward is not None:
+                status = getattr(eng, "_status", None)
+                after_forward(status[3:4] if (status is not None and eng._last_resident) else None)
             loss, dL = dL_fn(image)
             eng.backward(dL)
-            if not eng.check(raise_on_overflow=False):
-                # the instance count outgrew the resident capacity (the map changed): redo this keyframe through the
-                # synchronising path, which re-sizes the scratch; gradients are fully overwritten by the second pass
-                image = eng.forward(bg, params["means3D"], params["colors"], params["opacity"], params["scales"],
-                                    params["rotations"], view, proj, campos, tanx, tany)
-                loss, dL = dL_fn(image)
-                eng.backward(dL)
             return loss
 
         step = TrainerStep(params_flat, P, render_backward, FusedAdam(params_flat.numel(), device, opt), opt, eng.grads_flat,
-                           process_group)
+                           process_group, sharded_optimizer=sharded_optimizer)
         step.engine = eng
         step.fused_loss = FusedL1SSIM(cam.height, cam.width, device, opt.lambda_dssim)
         return step

@@ -1,0 +1,136 @@
+"""The one exchange of a keyframe-parallel training step, over torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Every rank holds a full replica of the flat parameter bucket and renders its own keyframe; per step the ranks exchange
+
+  * the FLAG word: the resident rasterizer's overflow word (status[3], segs_raster.h) of each rank, summed.  It is known as
+    soon as the forward's binning has run, so its (tiny) all-reduce is issued asynchronously right after the forward and
+    hides behind the loss and the whole backward.  The summed word is what guards statistics and optimizer ON THE DEVICE
+    (segs_training_statis_guarded, segs_adam_step_device): every replica drops the same steps and no rank synchronises
+    with its device to find out.
+  * the GRADIENT bucket, either
+      dense:    all_reduce(sum) of the whole bucket, every rank runs the fused Adam over all of it; or
+      sharded:  reduce_scatter(sum) -> rank r owns flat range [r*L/N, (r+1)*L/N) of the bucket, runs the fused Adam on that
+                range only (1/N of the 28 B/parameter optimizer traffic, 1/N of the moments kept current) and the updated
+                parameters travel back with one all_gather.  Same bytes per link as the ring all-reduce (reduce-scatter +
+                all-gather IS a ring all-reduce), N times less HBM traffic in the optimizer.
+Replicas stay bit-identical in both modes: every rank ends the step with the same all-reduced (or all-gathered) words.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring moves 2 (N-1)/N * bytes over ONE link pair per hop, so the
+exchange of B bytes costs about 2 (N-1)/N * B / 153 GB/s when RCCL rings over single links, and up to 7x less when it
+stripes rings over all links of the fully connected node (DESIGN.md section 6 prices both).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def _group_info(process_group) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(process_group), dist.get_rank(process_group)
+    return 1, 0
+
+
+class BucketExchange:
+    """Gradient / parameter exchange over one flat fp32 bucket of `n` elements (see module docstring)."""
+
+    ALIGN = 4      # shard boundaries fall on 16-byte boundaries (float4 accesses of the fused Adam)
+
+    def __init__(self, n: int, device, process_group=None, sharded: bool = True):
+        self.pg = process_group
+        self.world, self.rank = _group_info(process_group)
+        self.n = int(n)
+        self.device = torch.device(device)
+        self.sharded = bool(sharded) and self.world > 1
+        per = -(-self.n // self.world)
+        self.shard_len = -(-per // self.ALIGN) * self.ALIGN
+        self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._flag_work = None
+        # gloo (only used to rehearse the N > 1 path, on the CPU or with every rank on one GPU) has no tensor-shaped
+        # reduce-scatter / all-gather for device tensors: same result from an all-reduce + slice and a list all-gather
+        self._emulate = (self.world > 1 and self.device.type == "cuda" and dist.get_backend(process_group) != "nccl")
+        if self.sharded:
+            f = dict(dtype=torch.float32, device=self.device)
+            # staging in equal-sized shards: the collectives need world * shard_len elements, the bucket has n
+            self._send = torch.zeros(self.shard_len * self.world, **f) if self.shard_len * self.world != self.n else None
+            self._shard = torch.zeros(self.shard_len, **f)
+            self._full = torch.zeros(self.shard_len * self.world, **f) if self._send is not None else None
+
+    # ---- ranges
+    def shard_range(self, rank: Optional[int] = None) -> Tuple[int, int]:
+        """[lo, hi) of the bucket this rank updates (the whole bucket when not sharded)."""
+        if not self.sharded:
+            return 0, self.n
+        r = self.rank if rank is None else rank
+        lo = min(r * self.shard_len, self.n)
+        return lo, min(lo + self.shard_len, self.n)
+
+    def clip_segments(self, segments: Sequence[Tuple[int, int, float]]) -> List[Tuple[int, int, float]]:
+        """(offset, count, lr) Adam segments intersected with this rank's shard."""
+        lo, hi = self.shard_range()
+        out = []
+        for off, cnt, lr in segments:
+            a, b = max(off, lo), min(off + cnt, hi)
+            if b > a:
+                out.append((a, b - a, lr))
+        return out
+
+    # ---- flag
+    def reduce_flag_async(self, local_flag: Optional[torch.Tensor]):
+        """Start the all-reduce of this step's overflow word (a 1-element int32 device tensor, or None for 0)."""
+        if local_flag is None:
+            self.flag.zero_()
+        else:
+            self.flag.copy_(local_flag.reshape(1))
+        self._flag_work = dist.all_reduce(self.flag, group=self.pg, async_op=True) if self.world > 1 else None
+
+    def wait_flag(self) -> torch.Tensor:
+        """Make the current stream wait for the flag; returns the device word (non-zero: some rank's pass is invalid)."""
+        if self._flag_work is not None:
+            self._flag_work.wait()
+            self._flag_work = None
+        return self.flag
+
+    # ---- gradients
+    def reduce_gradients(self, grads: torch.Tensor):
+        """dense: grads <- sum over ranks (in place).  sharded: grads[lo:hi] <- sum over ranks; the rest of the bucket still
+        holds this rank's own contribution and must be cleared by the caller before the next backward accumulates."""
+        assert grads.numel() == self.n
+        if self.world == 1:
+            return
+        if not self.sharded:
+            dist.all_reduce(grads, group=self.pg)
+            return
+        if self._emulate:
+            dist.all_reduce(grads, group=self.pg)       # (leaves the whole bucket reduced; the caller clears it anyway)
+            return
+        src = grads
+        if self._send is not None:
+            self._send[:self.n].copy_(grads)
+            src = self._send
+        lo, hi = self.shard_range()
+        dist.reduce_scatter_tensor(self._shard, src, group=self.pg)
+        grads[lo:hi].copy_(self._shard[:hi - lo])
+
+    # ---- parameters
+    def gather(self, bucket: torch.Tensor):
+        """bucket <- concatenation of every rank's shard (parameters after the sharded Adam; moments before a densification)."""
+        if not self.sharded:
+            return
+        assert bucket.numel() == self.n
+        lo, hi = self.shard_range()
+        self._shard.zero_()
+        self._shard[:hi - lo].copy_(bucket[lo:hi])
+        if self._emulate:
+            parts = [torch.empty_like(self._shard) for _ in range(self.world)]
+            dist.all_gather(parts, self._shard, group=self.pg)
+            for r, part in enumerate(parts):
+                a, b = self.shard_range(r)
+                bucket[a:b].copy_(part[:b - a])
+        elif self._full is None:
+            dist.all_gather_into_tensor(bucket, self._shard, group=self.pg)
+        else:
+            dist.all_gather_into_tensor(self._full, self._shard, group=self.pg)
+            bucket.copy_(self._full[:self.n])

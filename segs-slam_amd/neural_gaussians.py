@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 
 from . import _capi
-from .gaussian_trainer import FusedL1SSIM, expon_lr
+from .gaussian_trainer import DeviceStepCount, FusedL1SSIM, expon_lr
 from .raster_engine import RasterEngine
 
 
@@ -335,9 +335,14 @@ class ScaffoldTrainerStep:
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         self.iteration = 0
         # torch::optim::Adam keeps one step count per parameter; they only diverge at densification iterations, where
-        # the re-created anchor tensors have no gradient and are skipped by the optimizer (src/gaussian_model.cpp:1677)
-        self.anchor_steps = 0
-        self.mlp_steps = 0
+        # the re-created anchor tensors have no gradient and are skipped by the optimizer (src/gaussian_model.cpp:1677).
+        # Both counts live on the device (a guarded step that is dropped there must not advance them); the anchor groups
+        # share the MLPs' count until the first densification.
+        self._mlp_count = DeviceStepCount(dev)
+        self._anchor_count = None
+        # N > 1: reduce-scatter -> Adam on this rank's shard -> all-gather (keyframe_parallel.BucketExchange); False = dense
+        # all-reduce and a full Adam on every rank
+        self.sharded_optimizer = True
         self.densifier = None            # densify.AnchorDensifier, see enable_densification()
         self.densify_generator = None
         self.keyframe_selector = None    # keyframe_window.SlidingWindowKeyframes: the mapper's walk instead of round-robin
@@ -383,21 +388,22 @@ class ScaffoldTrainerStep:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.model.device).cuda_stream)
 
-    def _adam(self, groups, step: int):
+    def _adam(self, groups, count: "DeviceStepCount", guard):
+        """Fused Adam over `groups` (restricted to this rank's shard of the bucket when the optimizer is sharded), guarded by
+        the summed overflow word, step count on the device."""
+        groups = self._exchange().clip_segments(groups)
+        call = count.calls
+        count.calls += 1                 # the launch below always happens (an empty shard still advances the count)
         if not groups:
-            return
+            groups = [(0, 0, 0.0)]
         segs = (_capi.AdamSegment * len(groups))()
         for i, (o, n, lr) in enumerate(groups):
             segs[i].offset, segs[i].count, segs[i].lr = o, n, float(lr)
         m = self.model
-        # guarded by the rasterizer's overflow word: an iteration whose instance count outgrew the resident capacity is
-        # dropped on the device; the host learns of it at the next forward (RasterEngine.check) and re-sizes the scratch
-        status = getattr(self.engine, "_status", None)
-        guard = C.c_void_p(status.data_ptr() + 12) if (status is not None and self.world == 1) else None
-        st = self._lib.segs_adam_step_guarded(_p(m.params), _p(m.grads), _p(m.exp_avg), _p(m.exp_avg_sq), segs, len(groups),
-                                              self.opt.beta1, self.opt.beta2, self.opt.eps, step, 1.0 / self.world, 1, guard,
-                                              self._stream())
-        _capi.check(st, "segs_adam_step_guarded")
+        st = self._lib.segs_adam_step_device(_p(m.params), _p(m.grads), _p(m.exp_avg), _p(m.exp_avg_sq), segs, len(groups),
+                                             self.opt.beta1, self.opt.beta2, self.opt.eps, _p(count.words), call,
+                                             1.0 / self.world, 1, guard, self._stream())
+        _capi.check(st, "segs_adam_step_device")
 
     def learning_rates(self, it: int) -> Dict[str, float]:
         """updateLearningRate (src/gaussian_model.cpp:874-915); anchor/offset scaled by spatial_lr_scale (:637,640)."""
@@ -442,12 +448,18 @@ class ScaffoldTrainerStep:
         return self.engine.forward(self.bg, ng.means3D, ng.colors, ng.opacity, ng.scales, ng.rotations, kf.view, kf.proj,
                                    kf.campos, kf.tanfovx, kf.tanfovy)
 
-    def _forward_backward(self, kf: Keyframe, gt: torch.Tensor):
+    def _forward_backward(self, kf: Keyframe, gt: torch.Tensor, exchange=None):
         if self.model.A == 0:
             # every anchor was pruned: the reference's rasterizer short-circuits P == 0 to a zero image
             # (src/rasterize_points.cu:81) and nothing receives a gradient
+            if exchange is not None:
+                exchange.reduce_flag_async(None)
             return self.loss_fn(torch.zeros(3, self.H, self.W, device=self.model.device), gt)[0]
         image = self.render(kf)
+        if exchange is not None:
+            # the overflow word is final once the forward's binning has run: its all-reduce hides behind loss and backward
+            status = getattr(self.engine, "_status", None)
+            exchange.reduce_flag_async(status[3:4] if (status is not None and self.engine._last_resident) else None)
         mask = None
         if self.row_mask:
             mask, gt = self._row_mask_of(gt)
@@ -482,6 +494,11 @@ class ScaffoldTrainerStep:
         return (step * self.world + self.rank) % n_keyframes
 
     def training_once(self, keyframes: List[Keyframe], gt_images: List[torch.Tensor]) -> torch.Tensor:
+        """One mapper iteration.  Nothing in it waits for the device except the densification iterations (adjust_anchor
+        sizes tensors on the host): a pass whose instance count outgrew the rasterizer's resident capacity on ANY rank is
+        dropped on the device by every rank -- statistics and optimizer are guarded by the all-reduced overflow word, the Adam
+        step counts live on the device and do not advance -- and the rank that overflowed re-sizes its scratch at its next
+        forward.  The loss returned for such an iteration comes from an invalid image."""
         self.iteration += 1
         lrs = self.learning_rates(self.iteration)
         if self.keyframe_selector is not None:
@@ -489,44 +506,64 @@ class ScaffoldTrainerStep:
             k = self.keyframe_selector.use_for_ranks(self.world)[self.rank]
         else:
             k = self.keyframe_for(self.iteration - 1, len(keyframes))
-        loss = self._forward_backward(keyframes[k], gt_images[k])
+        ex = self._exchange()
         d = self.densifier
         in_stat_window = d is not None and self.model.A > 0 and d.p.start_stat < self.iteration < d.p.update_until  # gaussian_mapper.cpp:961-968
         adjust_now = in_stat_window and self.iteration > d.p.update_from and self.iteration % d.p.update_interval == 0
-        if (self.world > 1 or adjust_now) and self.model.A > 0:
-            # ranks must agree on whether the step counts, and adjust_anchor reads the statistics on the host: resolve the
-            # overflow word here (one synchronisation) and redo an invalid pass through the re-sizing path.  On all other
-            # single-rank iterations nothing waits for the device: statistics and optimizer are guarded by that word on the
-            # device, an overflowed pass is dropped and the next forward re-sizes the scratch.
-            if not self.engine.check(raise_on_overflow=False):
+        loss = self._forward_backward(keyframes[k], gt_images[k], ex)
+        flag = ex.wait_flag()
+        if adjust_now:
+            # adjust_anchor reads tensor sizes on the host and must see a valid pass on every rank: resolve the summed
+            # overflow word here (the one synchronisation of a densification iteration) and redo the pass while it is set
+            for _ in range(3):
+                if int(flag.item()) == 0:
+                    break
+                self.engine.check(raise_on_overflow=False)     # the rank that overflowed re-calibrates in its next forward
                 self.model.grads.zero_()
-                loss = self._forward_backward(keyframes[k], gt_images[k])
-        if self.world > 1:
-            dist.all_reduce(self.model.grads, group=self.pg)
+                loss = self._forward_backward(keyframes[k], gt_images[k], ex)
+                flag = ex.wait_flag()
+            else:
+                raise RuntimeError("resident rasterizer kept overflowing its re-sized scratch")
+        guard = C.c_void_p(flag.data_ptr())
+        ex.reduce_gradients(self.model.grads)
         adjusted = False
         if in_stat_window:
-            status = getattr(self.engine, "_status", None)
-            guard = C.c_void_p(status.data_ptr() + 12) if (status is not None and self.world == 1) else None
-            d.training_statis(self.neural, self.visible_radii, self.engine.radii, self.engine.dL_dmean2D, guard)
+            d.training_statis(self.neural, self.visible_radii, self.engine.radii, self.engine.dL_dmean2D, guard,
+                              into_delta=self.world > 1)
             if adjust_now:
-                d.adjust_anchor(generator=self.densify_generator)
+                if ex.sharded:      # moments are only current inside each rank's shard: make them whole before rows move
+                    ex.gather(self.model.exp_avg)
+                    ex.gather(self.model.exp_avg_sq)
+                d.reduce_statistics(self.pg)
+                d.adjust_anchor(generator=self.densify_generator, views_per_iteration=self.world)
                 adjusted = True
         groups = self.model.adam_groups(lrs)
         anchor_groups, mlp_groups = groups[:4], groups[4:]
-        self.mlp_steps += 1
         if adjusted:
             # the six anchor tensors were re-created by adjust_anchor: no gradient, skipped by Adam this iteration
+            # (src/gaussian_model.cpp:1677), so from here on their step count lags the MLPs'
             for name in self.model.widths:
                 self.model.grad(name).zero_()
-            self._adam(mlp_groups, self.mlp_steps)
+            if self._anchor_count is None:
+                self._anchor_count = self._mlp_count.clone()
+            self._adam(mlp_groups, self._mlp_count, guard)
+        elif self._anchor_count is None:
+            self._adam(groups, self._mlp_count, guard)
         else:
-            self.anchor_steps += 1
-            if self.anchor_steps == self.mlp_steps:
-                self._adam(groups, self.mlp_steps)
-            else:
-                self._adam(anchor_groups, self.anchor_steps)
-                self._adam(mlp_groups, self.mlp_steps)
+            self._adam(anchor_groups, self._anchor_count, guard)
+            self._adam(mlp_groups, self._mlp_count, guard)
+        if ex.sharded:
+            ex.gather(self.model.params)
+            self.model.grads.zero_()      # outside this rank's shard the bucket still holds its own contribution
         return loss
+
+    def _exchange(self):
+        """The step's BucketExchange over the model's flat bucket (rebuilt when densification re-sized the bucket)."""
+        from .keyframe_parallel import BucketExchange
+        ex = getattr(self, "_ex", None)
+        if ex is None or ex.n != self.model.params.numel():
+            ex = self._ex = BucketExchange(self.model.params.numel(), self.model.device, self.pg, sharded=self.sharded_optimizer)
+        return ex
 
 
 def init_mlps(dims: ModelDims, generator: torch.Generator) -> Dict[str, torch.Tensor]:

@@ -54,6 +54,7 @@ class RasterEngine:
         # SEGS_RASTER_KEEP_DEAD_INSTANCES: resident forwards bin the reference's full bounding squares (R == R_reference)
         self.flags = (1 if skip_nonpositive_opacity else 0) | (2 if keep_dead_instances else 0)
         self.R_reference = 0
+        self.R_live = 0
         self.capacity = 0
         self._status_host = None
         self.P, self.W, self.H = int(P), int(width), int(height)   # P = allocated rows; P_active <= P are rasterized
@@ -103,6 +104,7 @@ class RasterEngine:
             self._status_event.synchronize()
             self._status_pending = False
             self.R = int(self._status_host[0])
+            self.R_live = int(self._status_host[1])    # instances the tile kernels walk (dead ones dropped by the first sort pass)
             if int(self._status_host[3]) != 0:
                 need = self.R
                 self.capacity = 0  # next forward goes through the synchronising path and sizes the scratch anew
@@ -133,7 +135,7 @@ class RasterEngine:
         if self.resident and self.capacity > 0:
             self._lib.segs_raster_set_status_mirror(C.c_void_p(self._status_host.data_ptr()))
             st = self._lib.segs_rasterize_forward_resident(
-                p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
+                p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
                 None, p(colors), p(opacity), p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix),
                 p(campos), float(tanfovx), float(tanfovy), p(self.out_color), p(self.radii), p(self._status), self._stream())
             _capi.check(st, "segs_rasterize_forward_resident")
@@ -169,7 +171,7 @@ class RasterEngine:
         g = self.grads
         if getattr(self, "_last_resident", False):
             st = self._lib.segs_rasterize_backward_resident(
-                p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
+                p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
                 None, p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix), p(campos),
                 float(tanfovx), float(tanfovy), p(self.radii), p(dL_dout_color), p(self.dL_dmean2D), p(self.dL_dconic),
                 p(g["opacity"]), p(g["colors"]), p(g["means3D"]), p(self.dL_dcov3D), None, p(g["scales"]), p(g["rotations"]),

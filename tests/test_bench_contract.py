@@ -45,3 +45,20 @@ def test_bench_stdout_stays_one_json_line_with_rccl_initialised():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["raster", "trainer"])
+def test_bench_starts_its_own_ranks_without_a_launcher(mode):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (how the driver calls it) must start its N ranks
+    itself and still print one JSON line.  Rehearsed here with two gloo ranks sharing the one GPU of the box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c1", "--steps", "3",
+                          "--warmup", "2", "--backend", "gloo", "--rehearse-on-one-gpu", "--mode", mode], capture_output=True,
+                         text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]

@@ -139,7 +139,7 @@ def test_trainer_keeps_running_through_densification():
         sizes.append(model.A)
         assert np.isfinite(float(loss))
     assert sizes[-1] != 3000, sizes[::5]      # the map changed size and the step kept running
-    assert step.mlp_steps == 31 and step.anchor_steps == 28   # anchor tensors skipped by Adam at the 3 densify iterations
+    assert step._mlp_count.value() == 31 and step._anchor_count.value() == 28   # anchor tensors skipped by Adam at the 3 densify iterations
 
 
 def test_trainer_survives_a_map_pruned_to_nothing():

@@ -56,7 +56,7 @@ def _params(sc):
     return flat
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, sharded):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -67,31 +67,41 @@ def _worker(rank, world, port, out_dir):
     flat = _params(sc)
     grads = torch.zeros_like(flat)
     opt = OptimizationParams()
-    step = TrainerStep(flat, sc.P, _oracle_backend(sc, grads, sc.P), TorchAdam(flat.numel(), "cpu", opt), opt, grads)
-    assert step.world == world and step.keyframe_for(0, 2) == rank
+    step = TrainerStep(flat, sc.P, _oracle_backend(sc, grads, sc.P), TorchAdam(flat.numel(), "cpu", opt), opt, grads,
+                       sharded_optimizer=sharded)
+    assert step.world == world and step.keyframe_for(0, 2) == rank and step.exchange.sharded == sharded
     # capture the reduced gradient before Adam clears it
     reduced = {}
     orig = step.optimizer.step
 
-    def spy(p, g, lrs, P, scale):
+    def spy(p, g, lrs, P, scale, exchange=None, guard=None):
         reduced["g"] = g.clone()
         reduced["scale"] = scale
-        return orig(p, g, lrs, P, scale)
+        return orig(p, g, lrs, P, scale, exchange=exchange, guard=guard)
     step.optimizer.step = spy
     loss = step.training_once(cams, gts)
+    lo, hi = step.exchange.shard_range()
     np.save(os.path.join(out_dir, f"params_{rank}.npy"), flat.numpy())
     np.save(os.path.join(out_dir, f"reduced_{rank}.npy"), reduced["g"].numpy())
+    np.save(os.path.join(out_dir, f"shard_{rank}.npy"), np.array([lo, hi]))
     assert reduced["scale"] == 0.5 and np.isfinite(float(loss))
     dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_summed_gradients(tmp_path):
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("sharded", [False, True], ids=["dense_allreduce", "reduce_scatter_sharded_adam_allgather"])
+def test_two_rank_step_matches_summed_gradients(tmp_path, sharded):
+    port = 29500 + (os.getpid() % 2000) + (7 if sharded else 0)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), sharded), nprocs=2, join=True)
     p0, p1 = np.load(tmp_path / "params_0.npy"), np.load(tmp_path / "params_1.npy")
     assert np.array_equal(p0, p1), "replicas diverged"
     r0, r1 = np.load(tmp_path / "reduced_0.npy"), np.load(tmp_path / "reduced_1.npy")
-    assert np.array_equal(r0, r1)
+    if sharded:
+        # each rank holds the summed gradient of its own shard only; the shards tile the bucket
+        (lo0, hi0), (lo1, hi1) = np.load(tmp_path / "shard_0.npy"), np.load(tmp_path / "shard_1.npy")
+        assert lo0 == 0 and hi0 == lo1 and hi1 == r0.size and lo1 % 4 == 0
+        r0 = np.concatenate([r0[lo0:hi0], r1[lo1:hi1]])
+    else:
+        assert np.array_equal(r0, r1)
 
     # single-process reference: sum of the two single-keyframe oracle gradients, then one Adam step at scale 1/2
     from segs_slam_amd.gaussian_trainer import OptimizationParams, TorchAdam, TrainerStep

@@ -333,3 +333,36 @@ def test_resident_depth_key_range_overflow_falls_back_to_the_exact_path():
     for _ in range(3):
         eng2.forward(*a, cam.tanfovx, cam.tanfovy)
     assert eng2._last_resident and eng2.check(raise_on_overflow=False)
+
+
+def test_resident_engine_survives_a_shrinking_active_row_count():
+    """A map that shrinks inside pre-sized buffers (adjust_anchor pruning rows): the resident geometry buffer is carved up
+    for the rows it was ALLOCATED for, so the self-cleaned accumulator rows do not move when P_active changes.  With the
+    layout keyed by P_active (the bug) a shrink by more than ~5 % laid the accumulators over stale depth-range words and
+    Bin records of the previous layout and the gradients of hundreds of Gaussians were garbage."""
+    from segs_slam_amd.raster_engine import RasterEngine
+    sc = scenes.make_scene(40_000, 320, 240, 260.0, 260.0, seed=29)
+    sc.scales *= 2.0
+    cam = sc.camera
+    a = [_t(x) for x in (sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, sc.rotations, cam.world_view_transform,
+                         cam.full_proj_transform, cam.camera_center)]
+    dL = _t(sc.dL_dout_color)
+    eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=True)
+    for _ in range(3):                       # full size: calibrate, then resident passes leave their scratch behind
+        eng.forward(*a, cam.tanfovx, cam.tanfovy)
+        eng.backward(dL)
+    assert eng.check() and eng._last_resident
+    for frac in (0.93, 0.8, 0.55, 0.97):     # shrink past the 4.4 % and 13 % marks of the old layout, then grow again
+        n = int(sc.P * frac)
+        eng.set_active(n)
+        for _ in range(2):
+            img = eng.forward(*a, cam.tanfovx, cam.tanfovy).clone()
+            eng.backward(dL)
+        assert eng.check() and eng._last_resident
+        got = {k: v[:n].cpu().numpy().copy() for k, v in eng.grads.items()}
+        ref = RasterEngine(n, cam.width, cam.height, DEV, resident=False)      # reference-shaped path on the first n rows
+        want_img = ref.forward(a[0], *[x[:n].contiguous() for x in a[1:6]], *a[6:], cam.tanfovx, cam.tanfovy)
+        ref.backward(dL)
+        assert torch.equal(img, want_img), frac
+        for k, v in ref.grads.items():
+            assert_grad_close(f"{k}@{frac}", got[k], v.cpu().numpy())

@@ -22,7 +22,13 @@ def main():
                 k = (row["Dispatch_Id"], row["Counter_Name"])
                 per_dispatch[k] += float(row["Counter_Value"])  # rows may be split per XCD/instance
                 names[row["Dispatch_Id"]] = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+            # The first step of a bench run is the calibrating one (reference-shaped forward with its full instance lists):
+            # everything up to and including the first tile backward is left out, the averages describe resident steps.
+            first_bwd = [int(d) for d, n in names.items() if n.endswith("render_bwd_kernel")]
+            cut = min(first_bwd) if (first_bwd and os.environ.get("PMC_KEEP_FIRST_STEP") is None) else -1
             for (disp, cname), v in per_dispatch.items():
+                if int(disp) <= cut:
+                    continue
                 a = acc[names[disp]][cname]
                 a[0] += v
                 a[1] += 1
