@@ -271,12 +271,20 @@ __device__ __forceinline__ void pixel_role(BwdLds& L, int nb, int lane, float px
     const float2 q2 = *reinterpret_cast<const float2*>(&L.rec[sl][2]);
     const float dx = q0.x - pxf, dy = q0.y - pyf;
     const float power2 = dx * (q0.z * dx + q0.w * dy) + (q1.x * dy) * dy;
+#ifdef ABLATE_NO_TRANS
+    const float ar = q1.y * (power2 * 0.001f + 1.0f);
+#else
     const float ar = q1.y * fast_exp2(power2);  // o * G
+#endif
     // alpha = min(0.99, ar) >= 1/255  <=>  ar >= 1/255
     const bool ok = __float_as_uint(q2.y) < last_contributor && power2 <= 0.0f && ar >= 1.0f / 255.0f;
     const float aw = ok ? ar : 0.f;      // o * G (the clamp at 0.99 is not differentiated, backward.cu:497); 0 on skipped pairs
     const float ae = fminf(0.99f, aw);   // alpha; 0 makes every update below a no-op
+#ifdef ABLATE_NO_TRANS
+    const float rinv = 1.f + ae;
+#else
     const float rinv = fast_rcp(1.f - ae);
+#endif
     T = T * rinv;                        // T / (1 - alpha)
     // The colour accumulated behind this Gaussian enters only through its dot product with dL/dpixel, so ONE running
     // scalar accd = sum_ch accum_ch * g_ch replaces the three accumulators of backward.cu:513-516:
@@ -372,6 +380,9 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
       if (use_bg) pixel_role<true>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, accd);
       else pixel_role<false>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, accd);
       wave_lds_fence();
+#ifdef ABLATE_NO_GAUSS_ROLE
+      continue;
+#endif
       // ---------------- (2) Gaussian role: lane = (part, gs): slot gs, pixels part*16 .. part*16+15
       // Moments are taken about the quadrant pixel NEAREST to the Gaussian's centre (cx, cy in 0..7), not about the
       // quadrant corner: for a centre inside the quadrant |gxr - cx| <= 0.5, so the later shift to centre-relative
@@ -435,7 +446,9 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
         const int slot = 4 * j + part;
         if (slot < nb && gs < 9) {
           const uint32_t id = __float_as_uint(reinterpret_cast<const float*>(&L.rec[slot][2])[2]);
+#ifndef ABLATE_NO_ATOMICS
           atomicAdd(gacc + (size_t)id * GACC_DWORDS + gs, mom[slot][gs]);
+#endif
         }
       }
       wave_lds_fence();

@@ -537,6 +537,7 @@ class ScaffoldTrainerStep:
                 d.reduce_statistics(self.pg)
                 d.adjust_anchor(generator=self.densify_generator, views_per_iteration=self.world)
                 adjusted = True
+                ex = self._exchange()      # the bucket may have been re-sized: new shard ranges (the moments are whole here)
         groups = self.model.adam_groups(lrs)
         anchor_groups, mlp_groups = groups[:4], groups[4:]
         if adjusted:

@@ -139,7 +139,10 @@ def test_trainer_keeps_running_through_densification():
         sizes.append(model.A)
         assert np.isfinite(float(loss))
     assert sizes[-1] != 3000, sizes[::5]      # the map changed size and the step kept running
-    assert step._mlp_count.value() == 31 and step._anchor_count.value() == 28   # anchor tensors skipped by Adam at the 3 densify iterations
+    # anchor tensors are skipped by Adam at the 3 densify iterations; a pass right after the map grew may outgrow the resident
+    # scratch and is then dropped ON THE DEVICE (both counts stay put), so the counts say how many steps were really taken
+    mlp, anchor = step._mlp_count.value(), step._anchor_count.value()
+    assert mlp - anchor == 3 and 28 <= mlp <= 31, (mlp, anchor)
 
 
 def test_trainer_survives_a_map_pruned_to_nothing():
