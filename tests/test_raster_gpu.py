@@ -12,8 +12,12 @@ Tolerances, stated once:
     in the last bits, so a decision that close to its threshold may legitimately flip; such pixels are
     reported by the oracle (gso_unstable_pixels) and must be < 1 % of the image.
   * gradients: dL_dout_color is zeroed on those pixels for BOTH sides, then
-    |gpu - ref| <= 1e-4 * |ref| + 1e-5 * max|ref| per tensor (float atomics sum in arbitrary order; the
-    oracle sums in double).
+    |gpu - ref| <= 1e-4 * |ref| + 1e-6 * max|ref| per tensor (float atomics sum in arbitrary order; the
+    oracle sums in double).  The floor stands for SURVEY 8c's absolute 1e-7: the synthetic scenes' dL/dimage is
+    U(-1,1)/(3HW), so gradient magnitudes scale with the image size and a fixed absolute floor would mean something
+    different at every resolution; 1e-6 of the tensor's largest entry is tighter than 1e-7 absolute wherever max|ref| < 0.1
+    (every tensor of every scene here).  profiles/r02_grad_error.txt lists, per tensor and workload, the fraction of entries
+    inside the pure 1e-4 relative bound and the largest error over max|ref| (tools/grad_error_report.py).
 """
 import numpy as np
 import pytest
@@ -92,8 +96,11 @@ def assert_forward_parity(sc, o, g, R):
     return unstable
 
 
+GRAD_REL, GRAD_FLOOR = 1e-4, 1e-6
+
+
 def assert_grad_close(name, a, b):
-    tol = 1e-4 * np.abs(b) + 1e-5 * (np.abs(b).max() + 1e-30)
+    tol = GRAD_REL * np.abs(b) + GRAD_FLOOR * (np.abs(b).max() + 1e-30)
     bad = np.abs(a - b) > tol
     assert not bad.any(), (name, int(bad.sum()), float(np.abs(a - b).max()), float(np.abs(b).max()))
 
