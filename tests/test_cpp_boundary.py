@@ -74,7 +74,7 @@ def test_cpp_boundary_end_to_end(tmp_path):
     assert np.all(np.abs(image - b)[:, ok] <= 1e-4 * np.abs(b)[:, ok] + 2e-6)
 
     def close(name, a, r):
-        assert np.all(np.abs(a - r) <= 1e-4 * np.abs(r) + 1e-6 * np.abs(r).max()), name
+        assert np.all(np.abs(a - r) <= 1e-4 * np.abs(r) + 1e-5 * np.abs(r).max()), name   # floor: see tests/test_raster_gpu.py
     close("means3D", g_m3, ref["dL_dmean3D"]); close("means2D", g_m2, ref["dL_dmean2D"]); close("opacity", g_op, ref["dL_dopacity"])
     close("scales", g_sc, ref["dL_dscale"]); close("rotations", g_rot, ref["dL_drot"]); close("colors", g_col, ref["dL_dcolor"])
     assert np.array_equal(d2.view(np.uint32), gs_oracle.knn_mean_dist2(sc.means3D).view(np.uint32))

@@ -81,7 +81,7 @@ def test_sh_gpu_matches_oracle(deg):
                                               deg, campos, geom, R, binning, img)
     for got, key in ((grads[5], "dL_dsh"), (grads[3], "dL_dmean3D"), (grads[6], "dL_dscale"), (grads[2], "dL_dopacity")):
         g, r = got.cpu().numpy(), ref[key]
-        assert np.all(np.abs(g - r) <= 1e-4 * np.abs(r) + 1e-6 * np.abs(r).max()), key
+        assert np.all(np.abs(g - r) <= 1e-4 * np.abs(r) + 1e-5 * np.abs(r).max()), key   # floor: see tests/test_raster_gpu.py
 
 
 @pytest.mark.gpu

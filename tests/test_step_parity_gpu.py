@@ -11,11 +11,12 @@ Reference chain (TEST ONLY; each piece is the restatement that already pins its 
                                                                           src/gaussian_model.cpp:620-690, src/gaussian_mapper.cpp:1027-1030
 against ScaffoldTrainerStep.training_once / TrainerStep.training_once (the HIP path through the C ABI).
 
-Tolerances: loss 1e-5 relative; bucket gradient 1e-4 relative with a floor of 1e-6 * max|ref| per tensor (float atomics sum in
+Tolerances: loss 1e-5 relative; bucket gradient 1e-4 relative with a floor of 1e-5 * max|ref| per tensor (float atomics sum in
 arbitrary order, the oracle in double); parameter UPDATE after two steps 1e-3 relative wherever both steps' gradients are more
 than rounding noise (Adam with eps 1e-15 turns noise into full-size steps; the first step alone only tests signs).  As in the
 raster tests, dL/dimage is zeroed on BOTH sides on the few pixels whose compositing decisions sit within 1e-5 of a threshold
-(the oracle reports them; v_exp_f32 and glibc expf differ in the last bits there).
+(the oracle reports them; v_exp_f32 and glibc expf differ in the last bits there) -- here together with every pixel whose
+11x11 SSIM window contains one, because the loss gradient of a pixel reads the image over that window.
 """
 import numpy as np
 import pytest
@@ -35,11 +36,22 @@ def _kf(cam, dev, pose7=(0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0)):
                        torch.tensor(pose7, dtype=torch.float32, device=dev), cam.tanfovx, cam.tanfovy)
 
 
-def _grad_check(name, got, ref, rel=1e-4, floor=1e-6):
+def _grad_check(name, got, ref, rel=1e-4, floor=1e-5):
+    """Same bar as tests/test_raster_gpu.py::assert_grad_close (where the floor is derived from measurements)."""
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    err = np.abs(got - ref)
     tol = rel * np.abs(ref) + floor * (np.abs(ref).max() + 1e-300)
-    bad = np.abs(got - ref) > tol
-    assert not bad.any(), (name, int(bad.sum()), bad.size, float(np.abs(got - ref).max()), float(np.abs(ref).max()))
+    bad = err > tol
+    assert not bad.any(), (name, int(bad.sum()), bad.size, float(err.max()), float(np.abs(ref).max()))
+    nz = ref != 0
+    if nz.sum() >= 1000:
+        assert float((err[nz] <= rel * np.abs(ref[nz])).mean()) >= 0.98, (name, float((err[nz] <= rel * np.abs(ref[nz])).mean()))
+
+
+def _dilate(unstable: torch.Tensor) -> torch.Tensor:
+    """Pixels whose 11x11 SSIM window (include/loss_utils.h:51-124) contains an unstable pixel: there the two sides' images may
+    legitimately differ, and with them dL/dimage of every pixel of the window."""
+    return torch.nn.functional.max_pool2d(unstable[None, None].float(), 11, stride=1, padding=5)[0, 0] > 0
 
 
 class ReferenceScaffoldStep:
@@ -92,7 +104,7 @@ class ReferenceScaffoldStep:
         self.o.forward(np.zeros(3, dtype=np.float32), f32(xyz), f32(color), f32(opacity), f32(scaling), 1.0, f32(rot),
                        cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.height, cam.width)
         image = torch.from_numpy(self.o.get("out_color"))
-        self.unstable = torch.from_numpy(self.o.unstable_pixels(1e-5))
+        self.unstable = _dilate(torch.from_numpy(self.o.unstable_pixels(1e-5)))
         img = image.double().requires_grad_(True)
         g64 = gt.cpu().double()
         self.reg = scaling.prod(1).mean() if self.reg_w else torch.zeros((), dtype=torch.float64)
@@ -186,7 +198,7 @@ def test_scaffold_training_once_matches_reference_chain(cfg):
         ref.sync_params(model)
         p_before = model.params.cpu().numpy().copy()
         loss_ref, image_ref, unstable = ref.forward(gt, pose7)
-        assert unstable.float().mean() < 0.01
+        assert unstable.float().mean() < 0.1
         mask_dev.copy_((~unstable).float().to(dev))
         grads_ref = ref.backward()
         captured.clear()
@@ -245,8 +257,8 @@ def test_config4_trainer_step_gradients_match_oracle():
     o = gs_oracle.Oracle()
     o.forward(sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, 1.0, sc.rotations, cam.world_view_transform,
               cam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.height, cam.width)
-    unstable = torch.from_numpy(o.unstable_pixels(1e-5))
-    assert unstable.float().mean() < 0.01
+    unstable = _dilate(torch.from_numpy(o.unstable_pixels(1e-5)))
+    assert unstable.float().mean() < 0.1
     img = torch.from_numpy(o.get("out_color")).double().requires_grad_(True)
     g64 = gt.cpu().double()
     lam = step.opt.lambda_dssim
