@@ -180,9 +180,12 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ incl, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
     const uint32_t* __restrict__ n_dev /* resident mode: R lives on the device, `R` is the capacity */,
-    int mark_dead /* instances that reach no quadrant get DEAD_KEY: the first tile-id pass drops them */) {
+    int mark_dead /* instances that reach no quadrant get DEAD_KEY: the first tile-id pass drops them */,
+    const uint32_t* __restrict__ ng_dev /* resident mode: Gaussians left in `order` after the depth sort dropped the culled ones */) {
   __shared__ uint32_t s_incl[EMIT_SLOTS + 1];
   if (n_dev) R = (int)min(*n_dev, (uint32_t)R);
+  if (ng_dev) P = (int)min(*ng_dev, (uint32_t)P);
+  if (P <= 0) return;
   __shared__ uint32_t s_idx[EMIT_SLOTS + 1];
   __shared__ uint2 s_bin[EMIT_SLOTS + 1];                              // rect min (x | y << 16), rect max
   __shared__ __attribute__((aligned(16))) float s_geo[EMIT_SLOTS + 1][8];  // x, y, A, B | C, k, -B/C, -B/A
@@ -267,40 +270,70 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {  // number of set bits o
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Count matrix: block_hist[d * nblocks + b] = number of keys of workgroup b's 2048-key tile with digit d.
-// BITS = 8 everywhere except the depth sort of the resident forward, whose 27 significant key bits take three 9-bit
-// passes instead of four 8-bit ones (the passes over P keys are bound by their launch count, not by bytes).
+// Digit counts of one pass, in two levels.  A workgroup walks a CHUNK of COUNT_CHUNK consecutive 2048-key tiles and keeps a
+// running per-digit count: for every tile it writes the count of each digit in the chunk's EARLIER tiles,
+//     tile_prefix[b * NDIG + d]            (tile-major: one coalesced 1-2 KB row per tile, read back coalesced by the scatter)
+// and at the end the chunk's totals, chunk_hist[d * nchunks + c] (digit-major rows for radix_scan_kernel).  Only that small
+// matrix -- COUNT_CHUNK times fewer columns than one column per tile -- goes through the row scan.  (One column per tile,
+// digit-major, cost 14 x write amplification -- one dword per 64-B line -- and a 10 us scan launch per pass at 3 M Gaussians.)
+// BITS = 8 everywhere except the depth sort, whose 26-27 significant key bits take three 9-bit passes instead of four
+// 8-bit ones (the passes over P keys are bound by their launch count, not by bytes).
+constexpr int COUNT_CHUNK = SORT_COUNT_CHUNK_TILES;   // gs_layout.h
 template <typename K, int BITS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __restrict__ keys, int n, int shift,
                                                                     uint32_t dmin, int dbits,
-                                                                    uint32_t* __restrict__ block_hist, int nblocks,
+                                                                    uint32_t* __restrict__ tile_prefix, uint32_t* __restrict__ chunk_hist,
+                                                                    int nblocks, int nchunks,
                                                                     const uint32_t* __restrict__ n_dev, int drop_dead) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   constexpr int NDIG = 1 << BITS;
+  constexpr int DPT = NDIG / SORT_THREADS;
   __shared__ uint32_t cnt[4][NDIG];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int i = tid; i < 4 * NDIG; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
-  __syncthreads();
-  const size_t wave_base = (size_t)blockIdx.x * SORT_TILE + (size_t)wv * (SORT_TILE / 4);
   uint32_t* my = cnt[wv];
-  K kreg[SORT_ITEMS_PER_THREAD];
+  uint32_t running[DPT];
 #pragma unroll
-  for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {  // all loads in flight before the first use
-    const size_t i = wave_base + (size_t)r * 64 + lane;
-    kreg[r] = i < (size_t)n ? keys[i] : (K)0;
-  }
-  // Counting needs no ranks: one LDS atomic per key into the wave's private histogram.  Lanes with equal digits
-  // serialise inside the LDS (worst case, one digit for the whole wave, about the cost of the 8-ballot peer match the
-  // scatter needs for its stable ranks), spread digits cost a few cycles: 21.8 -> 9 us on the R-sized pass.
+  for (int j = 0; j < DPT; j++) running[j] = 0u;
+  K kreg[SORT_ITEMS_PER_THREAD], knext[SORT_ITEMS_PER_THREAD];
+  const int b0 = blockIdx.x * COUNT_CHUNK;
+  auto load_tile = [&](int b, K* dst) {
+    const size_t wave_base = (size_t)b * SORT_TILE + (size_t)wv * (SORT_TILE / 4);
 #pragma unroll
-  for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
-    const size_t i = wave_base + (size_t)r * 64 + lane;
-    if (i < (size_t)n && !(drop_dead && kreg[r] == (K)DEAD_KEY_OF(K))) atomicAdd(&my[digit_of<BITS>(kreg[r], shift, km)], 1u);
+    for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {  // all loads in flight before the first use
+      const size_t i = wave_base + (size_t)r * 64 + lane;
+      dst[r] = (b < nblocks && i < (size_t)n) ? keys[i] : (K)DEAD_KEY_OF(K);
+    }
+  };
+  load_tile(b0, kreg);
+  for (int t = 0; t < COUNT_CHUNK; t++) {
+    const int b = b0 + t;
+    if (b >= nblocks) break;
+    for (int i = tid; i < 4 * NDIG; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
+    if (t + 1 < COUNT_CHUNK) load_tile(b + 1, knext);      // next tile's keys in flight while this one is counted
+    __syncthreads();
+    // Counting needs no ranks: one LDS atomic per key into the wave's private histogram.  Lanes with equal digits
+    // serialise inside the LDS (worst case, one digit for the whole wave, about the cost of the 8-ballot peer match the
+    // scatter needs for its stable ranks), spread digits cost a few cycles.
+    const size_t wave_base = (size_t)b * SORT_TILE + (size_t)wv * (SORT_TILE / 4);
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
+      const size_t i = wave_base + (size_t)r * 64 + lane;
+      if (i < (size_t)n && !(drop_dead && kreg[r] == (K)DEAD_KEY_OF(K))) atomicAdd(&my[digit_of<BITS>(kreg[r], shift, km)], 1u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const int d = tid * DPT + j;
+      tile_prefix[(size_t)b * NDIG + d] = running[j];
+      running[j] += cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) kreg[r] = knext[r];
   }
-  __syncthreads();
-  for (int d = tid; d < NDIG; d += SORT_THREADS)
-    block_hist[(size_t)d * nblocks + blockIdx.x] = cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
+#pragma unroll
+  for (int j = 0; j < DPT; j++) chunk_hist[(size_t)(tid * DPT + j) * nchunks + blockIdx.x] = running[j];
 }
 
 // Row d of the count matrix -> exclusive scan in place; row total -> digit_totals[d].  Grid = one workgroup per digit.
@@ -342,9 +375,9 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ 
 template <typename K, int BITS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, K* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, int n, int shift, uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist,
-    const uint32_t* __restrict__ digit_totals, int nblocks, const uint32_t* __restrict__ n_dev, int drop_dead,
-    uint32_t* __restrict__ n_live_out) {
+    uint32_t* __restrict__ vals_out, int n, int shift, uint32_t dmin, int dbits, const uint32_t* __restrict__ tile_prefix,
+    const uint32_t* __restrict__ chunk_prefix /* chunk_hist after radix_scan_kernel */, const uint32_t* __restrict__ digit_totals,
+    int nblocks, int nchunks, const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   constexpr int NDIG = 1 << BITS;
@@ -427,7 +460,9 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   for (int j = 0; j < DPT; j++) {
     const int d = tid * DPT + j;
     local_start[d] = lstart;
-    gdelta[d] = (int32_t)(gstart + block_hist[(size_t)d * nblocks + blockIdx.x] - lstart);
+    // keys with digit d: in smaller digits' runs (gstart), in earlier chunks, in earlier tiles of this chunk
+    gdelta[d] = (int32_t)(gstart + chunk_prefix[(size_t)d * nchunks + blockIdx.x / COUNT_CHUNK] +
+                          tile_prefix[(size_t)blockIdx.x * NDIG + d] - lstart);
     lstart += run[j]; gstart += tot[j];
   }
   // with dead keys dropped the tile holds fewer than nvalid entries, and the pass leaves sum(digit_totals) of them in all
@@ -458,9 +493,11 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 }
 
 #define SEGS_INSTANTIATE_RADIX(K, BITS)                                                                                          \
-  template __global__ void radix_count_kernel<K, BITS>(const K*, int, int, uint32_t, int, uint32_t*, int, const uint32_t*, int); \
+  template __global__ void radix_count_kernel<K, BITS>(const K*, int, int, uint32_t, int, uint32_t*, uint32_t*, int, int,       \
+                                                       const uint32_t*, int);                                                  \
   template __global__ void radix_scatter_kernel<K, BITS>(const K*, const uint32_t*, K*, uint32_t*, int, int, uint32_t, int,      \
-                                                         const uint32_t*, const uint32_t*, int, const uint32_t*, int, uint32_t*);
+                                                         const uint32_t*, const uint32_t*, const uint32_t*, int, int,               \
+                                                         const uint32_t*, int, uint32_t*);
 SEGS_INSTANTIATE_RADIX(uint64_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 9)
@@ -542,10 +579,12 @@ __global__ void __launch_bounds__(256) make_depth_keys_kernel(int P, const BinIn
 // it in `sorted_touched` for ordered_offsets_kernel, which then reads it coalesced: the two random gathers of this pair
 // of kernels were 80 MB of fetch at 500 k Gaussians and 0.13 ms at 3 M.
 __global__ void __launch_bounds__(256) ordered_block_sums_kernel(int P, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ order,
-                                                                 uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched) {
+                                                                 uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched,
+                                                                 const uint32_t* __restrict__ ng_dev /* entries of `order` that are valid, or null = P */) {
   __shared__ uint32_t wave_sums[4];
   const int slot = blockIdx.x * 256 + threadIdx.x;
-  uint32_t s = slot < P ? touched[order[slot]] : 0u;
+  const int ng = ng_dev ? (int)min(*ng_dev, (uint32_t)P) : P;
+  uint32_t s = slot < ng ? touched[order[slot]] : 0u;
   if (slot < P) sorted_touched[slot] = s;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);

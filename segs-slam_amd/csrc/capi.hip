@@ -6,6 +6,7 @@
 // cudaMemcpy at :281) -> K7 duplicate -> K8 radix sort -> K9 ranges -> K10 render.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -99,7 +100,8 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
   uint32_t* n_live = (uint32_t*)(bin + L.n_live);
   const int passes = (end_bit + BITS - 1) / BITS;
   int side = passes & 1;
-  uint32_t* block_hist = (uint32_t*)(bin + L.block_hist);
+  uint32_t* tile_prefix = (uint32_t*)(bin + L.tile_prefix);
+  uint32_t* chunk_hist = (uint32_t*)(bin + L.chunk_hist);
   uint32_t* digit_totals = (uint32_t*)(bin + L.digit_totals);
   for (int p = 0; p < passes; p++) {
     const K* kin = (const K*)(bin + L.keys[side]);
@@ -110,16 +112,16 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     const int drop = drop_dead && p == 0;
     const uint32_t* n_in = (drop_dead && p > 0) ? n_live : n_dev;
     { PROF(K_RADIX_COUNT);
-    radix_count_kernel<K, BITS><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, block_hist, L.nblocks, n_in, drop);
+    radix_count_kernel<K, BITS><<<L.nchunks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, L.nchunks, n_in, drop);
     }
     LAUNCH_TRY("radix_count_kernel");
     { PROF(K_RADIX_SCAN);
-    radix_scan_kernel<<<1 << BITS, 256, 0, st>>>(block_hist, L.nblocks, digit_totals);
+    radix_scan_kernel<<<1 << BITS, 256, 0, st>>>(chunk_hist, L.nchunks, digit_totals);
     }
     LAUNCH_TRY("radix_scan_kernel");
     { PROF(K_RADIX_SCATTER);
-    radix_scatter_kernel<K, BITS><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, block_hist, digit_totals, L.nblocks,
-                                                              n_in, drop, drop ? n_live : nullptr);
+    radix_scatter_kernel<K, BITS><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist, digit_totals,
+                                                              L.nblocks, L.nchunks, n_in, drop, drop ? n_live : nullptr);
     }
     LAUNCH_TRY("radix_scatter_kernel");
     side ^= 1;
@@ -190,14 +192,17 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
                                                       ranges, (int)(gx * gy));
   }
   LAUNCH_TRY("make_depth_keys_kernel");
-  int rc = nine_bit_depth ? sort_pairs<uint32_t, 9>(gbin, GL, P, dbits, dmin, dbits, st)
-                          : sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st);
+  // resident mode (K1 wrote the keys): culled Gaussians carry the all-ones key and are dropped by the first depth pass
+  const bool drop_culled = depth_keys_ready;
+  int rc = nine_bit_depth ? sort_pairs<uint32_t, 9>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled)
+                          : sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled);
   if (rc) return rc;
   const uint32_t* order = (const uint32_t*)(gbin + GL.vals[0]);
+  const uint32_t* ng_dev = drop_culled ? (const uint32_t*)(gbin + GL.n_live) : nullptr;
   // (2)
   uint32_t* sums2 = (uint32_t*)(bin + GS.block_sums);
   { PROF(K_SCAN);
-  ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.touched(), order, sums2, G.offsets());
+  ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.touched(), order, sums2, G.offsets(), ng_dev);
   }
   LAUNCH_TRY("ordered_block_sums_kernel");
   const int tpasses = (bit + 7) / 8;
@@ -209,7 +214,7 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   { PROF(K_DUPLICATE);
   duplicate_with_keys_kernel<<<(n_cap + 511) / 512, 256, 0, st>>>(P, n_cap, G.bin(), G.rec(), order, G.offsets(),
                                                                     (uint32_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev,
-                                                                    drop_dead ? 1 : 0);
+                                                                    drop_dead ? 1 : 0, ng_dev);
   }
   LAUNCH_TRY("duplicate_with_keys_kernel");
   // (3)

@@ -89,10 +89,12 @@ inline ImageLayout image_layout(int W, int H) {
 constexpr int SORT_ITEMS_PER_THREAD = 8;
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_TILE = SORT_ITEMS_PER_THREAD * SORT_THREADS;  // 2048 items per workgroup
+constexpr int SORT_COUNT_CHUNK_TILES = 4;                         // tiles per workgroup of radix_count_kernel (binning.hip)
 constexpr int SORT_MAX_DIGITS = 512;                             // count-matrix rows: 8-bit passes use 256 of them, 9-bit passes all
 
 struct BinningLayout {
-  size_t keys[2], vals[2], block_hist, digit_totals, n_live, total;
+  size_t keys[2], vals[2], tile_prefix, chunk_hist, digit_totals, n_live, total;
+  int nchunks;
   int R, nblocks;
 };
 // Mirrors BinningState::fromChunk (rasterizer_impl.cu:181-194): ping-pong key/value arrays + sort temp.
@@ -104,7 +106,11 @@ inline BinningLayout binning_layout(int R) {
   size_t o = 0;
   for (int i = 0; i < 2; i++) { b.keys[i] = o; o = align_up(o + (size_t)R * 8); }
   for (int i = 0; i < 2; i++) { b.vals[i] = o; o = align_up(o + (size_t)R * 4); }
-  b.block_hist = o;   o = align_up(o + (size_t)SORT_MAX_DIGITS * (b.nblocks > 0 ? b.nblocks : 1) * 4);
+  // per-tile digit offsets inside their chunk, tile-major [nblocks][digits]; per-chunk digit counts, digit-major
+  // [digits][nchunks] (scanned in place by radix_scan_kernel)
+  b.nchunks = (b.nblocks + SORT_COUNT_CHUNK_TILES - 1) / SORT_COUNT_CHUNK_TILES;
+  b.tile_prefix = o;  o = align_up(o + (size_t)SORT_MAX_DIGITS * (b.nblocks > 0 ? b.nblocks : 1) * 4);
+  b.chunk_hist = o;   o = align_up(o + (size_t)SORT_MAX_DIGITS * (b.nchunks > 0 ? b.nchunks : 1) * 4);
   b.digit_totals = o; o = align_up(o + SORT_MAX_DIGITS * 4);
   b.n_live = o;       o = align_up(o + 4);   // entries left after the first pass dropped the dead keys (sort_pairs)
   b.total = o + ALIGN;

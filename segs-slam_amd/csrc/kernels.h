@@ -54,17 +54,19 @@ __global__ void ordered_offsets_kernel(int P, const uint32_t* __restrict__ block
 __global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
-                                           const uint32_t* __restrict__ n_dev, int mark_dead);
+                                           const uint32_t* __restrict__ n_dev, int mark_dead, const uint32_t* __restrict__ ng_dev);
 constexpr uint32_t PREPROCESS_TIGHT_RECT = 0x80000000u;   // internal flag bit of preprocess_fwd_kernel (resident forward)
 constexpr uint32_t DEAD_KEY = 0xFFFFFFFFu;   // tile-id key of an instance that reaches no quadrant of its tile
 template <typename K, int BITS>   // K = uint32_t (the pipeline's own sorts) or uint64_t (segs_sort_pairs); BITS per digit: 8 or 9
 __global__ void radix_count_kernel(const K* __restrict__ keys, int n, int shift, uint32_t dmin, int dbits,
-                                   uint32_t* __restrict__ block_hist, int nblocks, const uint32_t* __restrict__ n_dev, int drop_dead);
+                                   uint32_t* __restrict__ tile_prefix, uint32_t* __restrict__ chunk_hist, int nblocks, int nchunks,
+                                   const uint32_t* __restrict__ n_dev, int drop_dead);
 __global__ void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_totals);
 template <typename K, int BITS>
 __global__ void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                      K* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
-                                     uint32_t dmin, int dbits, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_totals, int nblocks,
+                                     uint32_t dmin, int dbits, const uint32_t* __restrict__ tile_prefix, const uint32_t* __restrict__ chunk_prefix,
+                                     const uint32_t* __restrict__ digit_totals, int nblocks, int nchunks,
                                      const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out);
 __global__ void identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges,
                                             const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ status,
@@ -90,7 +92,8 @@ __global__ void rebuild_keys_kernel(int R, const uint32_t* __restrict__ tile_key
 __global__ void make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, uint32_t dcull, uint32_t* __restrict__ keys,
                                        uint32_t* __restrict__ vals, uint2* __restrict__ ranges, int num_tiles);
 __global__ void ordered_block_sums_kernel(int P, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ order,
-                                          uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched);
+                                          uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched,
+                                          const uint32_t* __restrict__ ng_dev);
 __global__ void point_offsets_kernel(int P, const BinInfo* __restrict__ bin, uint32_t* __restrict__ offsets);
 __global__ void strip_mask_kernel(int n, const uint32_t* __restrict__ vals, uint32_t* __restrict__ out);
 

@@ -366,11 +366,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     touched_dense[idx] = b.tiles_touched;
     if (depth_keys) {   // resident mode: what make_depth_keys_kernel would write (32-bit depth keys, culled = 0xFFFFFFFF)
       // The resident depth sort looks at DEPTH_KEY_BITS bits above the near plane's bit pattern (three 9-bit passes).
-      // Gaussians without instances take the largest key of that range so that they sort to the END (the emitter relies
-      // on every owner inside a slot range having at least one instance); a binned depth that reaches it -- beyond
-      // 0.2 * 2^16 = 13 107 -- would alias: flag the step, the host redoes it through the exact path.
-      constexpr uint32_t KEY_LAST = DEPTH_KEY_MIN + ((1u << DEPTH_KEY_BITS) - 1u);
-      depth_keys[idx] = b.tiles_touched ? b.depth_bits : KEY_LAST;
+      // Gaussians without instances carry the all-ones key: the FIRST pass gives them no histogram count and no rank, so the
+      // later passes, the depth-ordered prefix and the emitter's searches only see the binned ones (30 % fewer at 3 M).  A
+      // binned depth beyond the key range -- 0.2 * 2^16 = 13 107 -- flags the step; the host redoes it through the exact path.
+      depth_keys[idx] = b.tiles_touched ? b.depth_bits : 0xFFFFFFFFu;
       depth_vals[idx] = (uint32_t)idx;
       if (depth_overflow && b.tiles_touched && (b.depth_bits - DEPTH_KEY_MIN) >= ((1u << DEPTH_KEY_BITS) - 1u)) *depth_overflow = 1u;
     }
