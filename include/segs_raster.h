@@ -82,7 +82,8 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx,
 
 /* CudaRasterizer::Rasterizer::backward (cuda_rasterizer/rasterizer.h:80-108, rasterizer_impl.cu:397-490).
  * Every output row is written by this call (the caller does not have to zero them, unlike the reference's
- * torch::zeros at src/rasterize_points.cu:149-157).  dL_dconic is (P,2,2); dL_dmean2D is (P,3). */
+ * torch::zeros at src/rasterize_points.cu:149-157).  dL_dconic is (P,2,2); dL_dmean2D is (P,3).  dL_dconic (an internal
+ * product of the reference's backward) and, without cov3D_precomp, dL_dcov3D may be NULL: they are then not written. */
 int segs_rasterize_backward(int P, int D, int M, int R,
                             const float* background, int width, int height,
                             const float* means3D, const float* shs, const float* colors_precomp,

@@ -121,7 +121,11 @@ __device__ __forceinline__ uint32_t quadrant_mask(float cx, float cy, float A, f
 // Inclusive offsets of tiles_touched in DEPTH order (one per sorted slot): block prefix from scan_block_sums_kernel
 // plus an in-workgroup scan.
 __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ incl /* in: tiles_touched in depth order (ordered_block_sums_kernel); out: inclusive offsets */,
-                                                              uint32_t* __restrict__ total_out) {
+                                                              uint32_t* __restrict__ total_out,
+                                                              const uint32_t* __restrict__ ng_dev /* slots that hold a binned Gaussian, or null = P */) {
+  // workgroups wholly behind the binned Gaussians have nothing to scan (the emitter never looks there); the last one still
+  // reports the total
+  if (ng_dev && (uint32_t)blockIdx.x * 256u >= *ng_dev && blockIdx.x != gridDim.x - 1) return;
   // Every workgroup sums the (unscanned) sums of the workgroups before it on its own -- P/256 values, a few loads per
   // thread -- instead of a separate single-workgroup scan kernel between the two passes (one launch less).
   __shared__ uint32_t wave_tot[4], red[4];
@@ -372,12 +376,17 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ 
 }
 
 // Stable scatter of one 2048-key tile (SORT_TILE).
-template <typename K, int BITS>
+// vals_in == nullptr: the value of entry i is i itself (first pass of an index sort: no iota array is written or read).
+// AUX (last pass of the depth sort): aux_out[position of entry i] = aux_in[value of entry i], i.e. tiles_touched arrives in
+// depth order with the final scatter, whose other work covers the gather's latency; the depth-ordered prefix then reads it
+// coalesced.  (A separate gather kernel took 29 us at 3 M; carrying the payload through all three passes cost 37 us.)
+template <typename K, int BITS, bool AUX>
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, K* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int n, int shift, uint32_t dmin, int dbits, const uint32_t* __restrict__ tile_prefix,
     const uint32_t* __restrict__ chunk_prefix /* chunk_hist after radix_scan_kernel */, const uint32_t* __restrict__ digit_totals,
-    int nblocks, int nchunks, const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out) {
+    int nblocks, int nchunks, const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out,
+    const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   constexpr int NDIG = 1 << BITS;
@@ -385,6 +394,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   static_assert(NDIG % SORT_THREADS == 0 && BITS <= 11, "digit | rank << BITS must fit the rank of 2048 keys");
   __shared__ K s_keys[SORT_TILE];
   __shared__ uint32_t s_vals[SORT_TILE];
+  __shared__ uint32_t s_aux[AUX ? SORT_TILE : 1];
   __shared__ uint32_t cnt[4][NDIG];       // per-wave running digit counters, then per-wave bases
   __shared__ uint32_t local_start[NDIG];  // start of digit run inside the tile
   __shared__ int32_t gdelta[NDIG];        // global position - local position, per digit
@@ -399,6 +409,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 
   K key[SORT_ITEMS_PER_THREAD];
   uint32_t val[SORT_ITEMS_PER_THREAD];
+  uint32_t aux[AUX ? SORT_ITEMS_PER_THREAD : 1];
   uint32_t drank[SORT_ITEMS_PER_THREAD];  // digit | wave-local rank << BITS ; 0xFFFFFFFF = invalid
   volatile uint32_t* my = cnt[wv];
 #pragma unroll
@@ -406,7 +417,8 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const size_t i = wave_base + (size_t)r * 64 + lane;
     const bool valid = i < (size_t)n;
     key[r] = valid ? keys_in[i] : (K)0;
-    val[r] = valid ? vals_in[i] : 0u;
+    val[r] = vals_in ? (valid ? vals_in[i] : 0u) : (uint32_t)i;
+    if (AUX) aux[r] = valid ? aux_in[val[r]] : 0u;
   }
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
@@ -477,6 +489,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
       const uint32_t pos = local_start[d] + cnt[wv][d] + (drank[r] >> BITS);
       s_keys[pos] = key[r];
       s_vals[pos] = val[r];
+      if (AUX) s_aux[pos] = aux[r];
     }
   }
   __syncthreads();
@@ -488,6 +501,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
       const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of<BITS>(k, shift, km)]);
       keys_out[gp] = k;
       vals_out[gp] = s_vals[lp];
+      if (AUX) aux_out[gp] = s_aux[lp];
     }
   }
 }
@@ -495,13 +509,20 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 #define SEGS_INSTANTIATE_RADIX(K, BITS)                                                                                          \
   template __global__ void radix_count_kernel<K, BITS>(const K*, int, int, uint32_t, int, uint32_t*, uint32_t*, int, int,       \
                                                        const uint32_t*, int);                                                  \
-  template __global__ void radix_scatter_kernel<K, BITS>(const K*, const uint32_t*, K*, uint32_t*, int, int, uint32_t, int,      \
-                                                         const uint32_t*, const uint32_t*, const uint32_t*, int, int,               \
-                                                         const uint32_t*, int, uint32_t*);
+  template __global__ void radix_scatter_kernel<K, BITS, false>(const K*, const uint32_t*, K*, uint32_t*, int, int, uint32_t, int, \
+                                                                const uint32_t*, const uint32_t*, const uint32_t*, int, int,        \
+                                                                const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*);
 SEGS_INSTANTIATE_RADIX(uint64_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 9)
 #undef SEGS_INSTANTIATE_RADIX
+#define SEGS_INSTANTIATE_AUX(BITS)                                                                                                     \
+  template __global__ void radix_scatter_kernel<uint32_t, BITS, true>(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, int, int, \
+                                                                      uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, \
+                                                                      int, int, const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*);
+SEGS_INSTANTIATE_AUX(8)
+SEGS_INSTANTIATE_AUX(9)
+#undef SEGS_INSTANTIATE_AUX
 
 // ---------------------------------------------------------------------------------------------
 // K9 (rasterizer_impl.cu:116-138).  The range table is zeroed by make_depth_keys_kernel earlier in the same stream
@@ -572,19 +593,18 @@ __global__ void __launch_bounds__(256) make_depth_keys_kernel(int P, const BinIn
   if (i >= P) return;
   const uint4 b = reinterpret_cast<const uint4*>(bin)[i];
   keys[i] = b.w ? b.x : dcull;   // culled Gaussians sort strictly after every visible one
-  vals[i] = (uint32_t)i;
+  (void)vals;                    // the sort's first pass takes the index itself as the value
 }
-// Per-workgroup sums of tiles_touched taken in depth order (feeds scan_block_sums_kernel for the emitter).
-// Gathers tiles_touched into depth order ONCE (from the dense 4-byte array, not from the 16-byte BinInfo rows) and leaves
-// it in `sorted_touched` for ordered_offsets_kernel, which then reads it coalesced: the two random gathers of this pair
-// of kernels were 80 MB of fetch at 500 k Gaussians and 0.13 ms at 3 M.
+// Per-workgroup sums of tiles_touched taken in depth order (feeds ordered_offsets_kernel for the emitter).  `touched` is
+// either already in depth order (`order` == nullptr: it rode along with the depth sort as the scatter's aux payload) or is
+// gathered into depth order here ONCE and left in `sorted_touched` for ordered_offsets_kernel.
 __global__ void __launch_bounds__(256) ordered_block_sums_kernel(int P, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ order,
                                                                  uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched,
                                                                  const uint32_t* __restrict__ ng_dev /* entries of `order` that are valid, or null = P */) {
   __shared__ uint32_t wave_sums[4];
   const int slot = blockIdx.x * 256 + threadIdx.x;
   const int ng = ng_dev ? (int)min(*ng_dev, (uint32_t)P) : P;
-  uint32_t s = slot < ng ? touched[order[slot]] : 0u;
+  uint32_t s = slot < ng ? (order ? touched[order[slot]] : touched[slot]) : 0u;
   if (slot < P) sorted_touched[slot] = s;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);

@@ -93,9 +93,13 @@ uint32_t getHigherMsb(uint32_t n) {
 // `passes & 1` of the ping-pong pair so that the result lands in side 0.
 // drop_dead: entries whose key is all ones are left out by the FIRST pass (they take no histogram count and no rank), so
 // every later pass -- and the caller, through *n_live -- works on the survivors only: a stable partition for free.
+// iota_vals: the values of the input are 0..n-1 and are not read (nor need they have been written).
+// aux_in / aux_final (32-bit keys only): the LAST pass also writes aux_final[position] = aux_in[value] (a gather by the
+// sorted values, fused into the scatter).
 template <typename K, int BITS = 8>
 int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t dmin, int dbits, hipStream_t st,
-               const uint32_t* n_dev = nullptr, bool drop_dead = false) {
+               const uint32_t* n_dev = nullptr, bool drop_dead = false, bool iota_vals = false, const uint32_t* aux_in = nullptr,
+               uint32_t* aux_final = nullptr) {
   if (n <= 0) return SEGS_OK;
   uint32_t* n_live = (uint32_t*)(bin + L.n_live);
   const int passes = (end_bit + BITS - 1) / BITS;
@@ -119,9 +123,23 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     radix_scan_kernel<<<1 << BITS, 256, 0, st>>>(chunk_hist, L.nchunks, digit_totals);
     }
     LAUNCH_TRY("radix_scan_kernel");
+    if (iota_vals && p == 0) vin = nullptr;
     { PROF(K_RADIX_SCATTER);
-    radix_scatter_kernel<K, BITS><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist, digit_totals,
-                                                              L.nblocks, L.nchunks, n_in, drop, drop ? n_live : nullptr);
+    if constexpr (sizeof(K) == 4) {
+      if (aux_in && p == passes - 1) {
+        radix_scatter_kernel<K, BITS, true><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
+                                                                        digit_totals, L.nblocks, L.nchunks, n_in, drop,
+                                                                        drop ? n_live : nullptr, aux_in, aux_final);
+      } else {
+        radix_scatter_kernel<K, BITS, false><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
+                                                                         digit_totals, L.nblocks, L.nchunks, n_in, drop,
+                                                                         drop ? n_live : nullptr, nullptr, nullptr);
+      }
+    } else {
+      radix_scatter_kernel<K, BITS, false><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
+                                                                       digit_totals, L.nblocks, L.nchunks, n_in, drop,
+                                                                       drop ? n_live : nullptr, nullptr, nullptr);
+    }
     }
     LAUNCH_TRY("radix_scatter_kernel");
     side ^= 1;
@@ -194,21 +212,23 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   LAUNCH_TRY("make_depth_keys_kernel");
   // resident mode (K1 wrote the keys): culled Gaussians carry the all-ones key and are dropped by the first depth pass
   const bool drop_culled = depth_keys_ready;
-  int rc = nine_bit_depth ? sort_pairs<uint32_t, 9>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled)
-                          : sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled);
+  // the values are the Gaussian indices 0..P-1 (never materialised); the last pass leaves tiles_touched in depth order in
+  // G.offsets(), where ordered_offsets_kernel turns it into the inclusive offsets in place
+  int rc = nine_bit_depth ? sort_pairs<uint32_t, 9>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), G.offsets())
+                          : sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), G.offsets());
   if (rc) return rc;
   const uint32_t* order = (const uint32_t*)(gbin + GL.vals[0]);
   const uint32_t* ng_dev = drop_culled ? (const uint32_t*)(gbin + GL.n_live) : nullptr;
   // (2)
   uint32_t* sums2 = (uint32_t*)(bin + GS.block_sums);
   { PROF(K_SCAN);
-  ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.touched(), order, sums2, G.offsets(), ng_dev);
+  ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.offsets(), nullptr, sums2, G.offsets(), ng_dev);
   }
   LAUNCH_TRY("ordered_block_sums_kernel");
   const int tpasses = (bit + 7) / 8;
   const int side = tpasses & 1;
   { PROF(K_SCAN);
-  ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, sums2, G.offsets(), total_out);
+  ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, sums2, G.offsets(), total_out, ng_dev);
   }
   LAUNCH_TRY("ordered_offsets_kernel");
   { PROF(K_DUPLICATE);
@@ -345,7 +365,8 @@ static int rasterize_backward_impl(int P, int D, int M, int R, const float* back
   if (shs && (!campos || !dL_dsh || M <= 0)) return fail(SEGS_ERR_INVALID_ARGUMENT, "SH path needs campos, dL_dsh and M > 0");
   if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background || !means3D || !viewmatrix || !projmatrix)
     return fail(SEGS_ERR_INVALID_ARGUMENT, "null required pointer");
-  if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+  // dL_dconic (the tile kernel's internal product) and dL_dcov3D (of use only with cov3D_precomp) may be null: not written
+  if (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || (cov3D_precomp && !dL_dcov3D))
     return fail(SEGS_ERR_INVALID_ARGUMENT, "null gradient output");
   if (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))
     return fail(SEGS_ERR_INVALID_ARGUMENT, "need scales+rotations (+ their gradient outputs) or cov3D_precomp");

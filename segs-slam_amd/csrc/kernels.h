@@ -50,7 +50,7 @@ __global__ void preprocess_bwd_kernel(
 __global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, const uint32_t* __restrict__ depth_range,
                                        uint32_t* __restrict__ total);
 __global__ void ordered_offsets_kernel(int P, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ incl,
-                                       uint32_t* __restrict__ total_out);
+                                       uint32_t* __restrict__ total_out, const uint32_t* __restrict__ ng_dev);
 __global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
@@ -62,12 +62,13 @@ __global__ void radix_count_kernel(const K* __restrict__ keys, int n, int shift,
                                    uint32_t* __restrict__ tile_prefix, uint32_t* __restrict__ chunk_hist, int nblocks, int nchunks,
                                    const uint32_t* __restrict__ n_dev, int drop_dead);
 __global__ void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_totals);
-template <typename K, int BITS>
+template <typename K, int BITS, bool AUX>
 __global__ void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                      K* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n, int shift,
                                      uint32_t dmin, int dbits, const uint32_t* __restrict__ tile_prefix, const uint32_t* __restrict__ chunk_prefix,
                                      const uint32_t* __restrict__ digit_totals, int nblocks, int nchunks,
-                                     const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out);
+                                     const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out,
+                                     const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out);
 __global__ void identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges,
                                             const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ status,
                                             uint32_t* __restrict__ status_mirror, const uint32_t* __restrict__ n_live);

@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       // later passes, the depth-ordered prefix and the emitter's searches only see the binned ones (30 % fewer at 3 M).  A
       // binned depth beyond the key range -- 0.2 * 2^16 = 13 107 -- flags the step; the host redoes it through the exact path.
       depth_keys[idx] = b.tiles_touched ? b.depth_bits : 0xFFFFFFFFu;
-      depth_vals[idx] = (uint32_t)idx;
+      (void)depth_vals;   // the sort's first pass takes the index itself as the value (no iota array)
       if (depth_overflow && b.tiles_touched && (b.depth_bits - DEPTH_KEY_MIN) >= ((1u << DEPTH_KEY_BITS) - 1u)) *depth_overflow = 1u;
     }
   }
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
       dop = a1.y != 0.f ? a1.y / op : 0.f;
     }
     dL_dmean2D[3 * (size_t)idx + 0] = g2x; dL_dmean2D[3 * (size_t)idx + 1] = g2y; dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
-    reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcw);
+    if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcw);   // internal product: optional
     dL_dopacity[idx] = dop;
     dL_dcolor[3 * (size_t)idx + 0] = a1.z; dL_dcolor[3 * (size_t)idx + 1] = a1.w; dL_dcolor[3 * (size_t)idx + 2] = a8;
     dcol0 = a1.z; dcol1 = a1.w; dcol2 = a8;
@@ -578,8 +578,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) dL_dmean3D[3 * (size_t)idx + k] = out_mean[k];
+  if (dL_dcov3D) {   // only a caller that passed cov3D_precomp has a use for it
 #pragma unroll
-  for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = out_cov[k];
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = out_cov[k];
+  }
   if (dL_dscale) {
 #pragma unroll
     for (int k = 0; k < 3; k++) dL_dscale[3 * (size_t)idx + k] = out_scale[k];

@@ -48,7 +48,7 @@ class RasterEngine:
     reports an overflow if R ever outgrew it."""
 
     def __init__(self, P: int, width: int, height: int, device="cuda:0", resident: bool = False,
-                 skip_nonpositive_opacity: bool = False, keep_dead_instances: bool = False):
+                 skip_nonpositive_opacity: bool = False, keep_dead_instances: bool = False, want_cov3D_grad: bool = False):
         self.resident = bool(resident)
         # SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY (segs_raster.h): candidate-domain inputs of segs_neural_forward
         # SEGS_RASTER_KEEP_DEAD_INSTANCES: resident forwards bin the reference's full bounding squares (R == R_reference)
@@ -66,8 +66,9 @@ class RasterEngine:
         self.grads_flat = torch.zeros((FLOATS_PER_GAUSSIAN * self.P,), **f)
         self.grads = split_flat(self.grads_flat, self.P)
         self.dL_dmean2D = torch.zeros((self.P, 3), **f)
-        self.dL_dconic = torch.zeros((self.P, 2, 2), **f)
-        self.dL_dcov3D = torch.zeros((self.P, 6), **f)
+        # dL/dcov3D has no consumer when the Gaussians come as scales + rotations (the training path): written on request only;
+        # dL/dconic, the tile backward's internal product, is never materialised here (40 B per Gaussian less to write)
+        self.dL_dcov3D = torch.zeros((self.P, 6), **f) if want_cov3D_grad else None
         self.geom, self.binning, self.img = (_GrowBuffer(self.device) for _ in range(3))
         self.R = 0
         self._lib = _capi.lib()
@@ -168,13 +169,14 @@ class RasterEngine:
          scale_modifier) = self._last
         assert dL_dout_color.is_contiguous() and dL_dout_color.dtype == torch.float32
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        pn = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         g = self.grads
         if getattr(self, "_last_resident", False):
             st = self._lib.segs_rasterize_backward_resident(
                 p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
                 None, p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix), p(campos),
-                float(tanfovx), float(tanfovy), p(self.radii), p(dL_dout_color), p(self.dL_dmean2D), p(self.dL_dconic),
-                p(g["opacity"]), p(g["colors"]), p(g["means3D"]), p(self.dL_dcov3D), None, p(g["scales"]), p(g["rotations"]),
+                float(tanfovx), float(tanfovy), p(self.radii), p(dL_dout_color), p(self.dL_dmean2D), None,
+                p(g["opacity"]), p(g["colors"]), p(g["means3D"]), pn(self.dL_dcov3D), None, p(g["scales"]), p(g["rotations"]),
                 self._stream())
             _capi.check(st, "segs_rasterize_backward_resident")
             return g
@@ -182,7 +184,7 @@ class RasterEngine:
             self.P_active, 0, 0, self.R, p(bg), self.W, self.H, p(means3D), None, p(colors), p(scales), float(scale_modifier),
             p(rotations), None, p(viewmatrix), p(projmatrix), p(campos), float(tanfovx), float(tanfovy), p(self.radii),
             p(self.geom.tensor), p(self.binning.tensor), p(self.img.tensor), p(dL_dout_color), p(self.dL_dmean2D),
-            p(self.dL_dconic), p(g["opacity"]), p(g["colors"]), p(g["means3D"]), p(self.dL_dcov3D), None, p(g["scales"]),
+            None, p(g["opacity"]), p(g["colors"]), p(g["means3D"]), pn(self.dL_dcov3D), None, p(g["scales"]),
             p(g["rotations"]), self._stream())
         _capi.check(st, "segs_rasterize_backward")
         return g

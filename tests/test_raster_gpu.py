@@ -295,7 +295,7 @@ def test_resident_engine_matches_sync_path():
     dL = _t(sc.dL_dout_color)
     outs = []
     for resident, keep in ((False, False), (True, True), (True, False)):
-        eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=resident, keep_dead_instances=keep)
+        eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=resident, keep_dead_instances=keep, want_cov3D_grad=True)
         for it in range(3):  # resident: first call calibrates through the sync path, the rest are no-sync
             img = eng.forward(a["bg"], a["m"], a["c"], a["o"], a["s"], a["r"], a["v"], a["p"], a["cp"], cam.tanfovx, cam.tanfovy).clone()
             eng.backward(dL)

@@ -43,7 +43,7 @@ def main():
         print(f"== {wl}: P={sc.P} R={o.R} unstable pixels={int(unstable.sum())} ({unstable.mean():.2e} of the image)")
         print(f"{'tensor':12s} {'path':9s} {'within 1e-4 rel':>16s} {'within test bound':>18s} {'max err / max|ref|':>19s}")
         for resident in (False, True):
-            eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=resident)
+            eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=resident, want_cov3D_grad=True)
             for _ in range(2):
                 eng.forward(*a, cam.tanfovx, cam.tanfovy)
                 eng.backward(t(dL))
