@@ -1,9 +1,11 @@
 // points.hip -- simple-knn, operate_points, stereo_vision kernels (include/segs_points.h) for gfx950.
-//   K16/K17 reference: third_party/simple-knn/simple_knn.cu:45-220
+//   K16/K17 reference: third_party/simple-knn/simple_knn.cu:45-220 (what it computes: the mean of the three smallest squared
+//           distances from every point to the others -- an exact 3-NN query, so any exact search gives the same numbers)
 //   K18     reference: src/operate_points.cu:38-71, cuda_rasterizer/operate_points.h:39-178
 //   K19     reference: src/stereo_vision.cu:39-134, cuda_rasterizer/stereo_vision.h:39-54
-// Cold paths (initialisation / loop-closure helpers): written for correctness and coalescing, not tuned further.
-// Built with -ffp-contract=off: results are bit-identical to the CPU oracle.
+// simple-knn here is a workgroup-cooperative search over LDS tiles (see knn_query_kernel); the rest are cold elementwise
+// kernels.  Built with -ffp-contract=off: distances are formed as dx*dx + dy*dy + dz*dz like the reference's, so the
+// results are bit-identical to the CPU oracle.
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cstdint>
@@ -14,7 +16,6 @@
 #pragma clang fp contract(off)
 
 namespace {
-constexpr int BOX_SIZE = 1024;  // simple_knn.cu:12
 
 // ---------------------------------------------------------------- simple-knn
 // bounding box with the reference's init {0,0,0} for both reductions (simple_knn.cu:191-199): the box always
@@ -62,68 +63,128 @@ __global__ void __launch_bounds__(256) morton_kernel(int P, const float* __restr
   keys[idx] = (uint64_t)(x | (y << 1) | (z << 2));
   vals[idx] = (uint32_t)idx;
 }
-// gather points into Morton order (float4: xyz + original index bits) and build the per-1024 boxes (simple_knn.cu:78-117)
-__global__ void __launch_bounds__(BOX_SIZE) box_minmax_kernel(int P, const float* __restrict__ pts, const uint32_t* __restrict__ order,
-                                                              float4* __restrict__ sorted, float* __restrict__ boxes) {
-  __shared__ float red[6][BOX_SIZE];
-  const int idx = blockIdx.x * BOX_SIZE + threadIdx.x;
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+// ---- exact 3-nearest-neighbour search, MI355X-shaped.
+// The reference gives every point its own serial walk over all 1024-point boxes and, for each box it cannot reject, over the
+// box's points in global memory (simple_knn.cu:147-183).  Here the points are cut into boxes of 256 consecutive points of the
+// Morton order -- one box = one workgroup = one LDS tile -- and a WORKGROUP searches for its 256 query points together:
+//   (A) every lane takes its three best among the workgroup's own tile; R = the largest third-best of the workgroup;
+//   (B) the lanes test 256 candidate boxes at a time (AABB-to-AABB gap against R, one box per lane), the hits are compacted
+//       with ballots, and each hit box is pulled into LDS ONCE with coalesced 16-byte loads and scanned by all lanes as
+//       broadcast reads, each lane first checking the box against its own third-best; R is re-tightened as it goes.
+// Spatially coherent queries share almost all their candidate boxes, so a box's points are fetched once per workgroup, not
+// once per point.  The pruning bounds are deflated by 1e-6 so that rounding can only make a lane look at a box too many.
+constexpr int KNN_BOX = 256;
+constexpr float KNN_FAR = 3.0e38f;
+
+// gather the points into Morton order (float4: xyz + original index bits) and take each 256-point box's bounds
+__global__ void __launch_bounds__(KNN_BOX) knn_gather_boxes_kernel(int P, const float* __restrict__ pts, const uint32_t* __restrict__ order,
+                                                                   float4* __restrict__ sorted, float* __restrict__ boxes) {
+  __shared__ float red[4][6];
+  const int idx = blockIdx.x * KNN_BOX + threadIdx.x;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   if (idx < P) {
     const uint32_t o = order[idx];
     const float x = pts[3 * (size_t)o], y = pts[3 * (size_t)o + 1], z = pts[3 * (size_t)o + 2];
     sorted[idx] = make_float4(x, y, z, __uint_as_float(o));
-    mn[0] = mx[0] = x; mn[1] = mx[1] = y; mn[2] = mx[2] = z;
+    lo[0] = hi[0] = x; lo[1] = hi[1] = y; lo[2] = hi[2] = z;
   }
-  for (int k = 0; k < 3; k++) { red[k][threadIdx.x] = mn[k]; red[3 + k][threadIdx.x] = mx[k]; }
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; k++) { red[threadIdx.x >> 6][k] = lo[k]; red[threadIdx.x >> 6][3 + k] = hi[k]; }
   __syncthreads();
-  for (int off = BOX_SIZE / 2; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off)
-      for (int k = 0; k < 3; k++) {
-        red[k][threadIdx.x] = fminf(red[k][threadIdx.x], red[k][threadIdx.x + off]);
-        red[3 + k][threadIdx.x] = fmaxf(red[3 + k][threadIdx.x], red[3 + k][threadIdx.x + off]);
-      }
-    __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    const float a = red[0][k], b = red[1][k], c = red[2][k], d = red[3][k];
+    boxes[blockIdx.x * 6 + k] = k < 3 ? fminf(fminf(a, b), fminf(c, d)) : fmaxf(fmaxf(a, b), fmaxf(c, d));
   }
-  if (threadIdx.x < 6) boxes[blockIdx.x * 6 + threadIdx.x] = red[threadIdx.x][0];
 }
-__device__ __forceinline__ float distBoxPoint(const float* b, float3 p) {  // simple_knn.cu:119-129
-  float dx = 0.f, dy = 0.f, dz = 0.f;
-  if (p.x < b[0] || p.x > b[3]) dx = fminf(fabsf(p.x - b[0]), fabsf(p.x - b[3]));
-  if (p.y < b[1] || p.y > b[4]) dy = fminf(fabsf(p.y - b[1]), fabsf(p.y - b[4]));
-  if (p.z < b[2] || p.z > b[5]) dz = fminf(fabsf(p.z - b[2]), fabsf(p.z - b[5]));
-  return dx * dx + dy * dy + dz * dz;
-}
-__device__ __forceinline__ void updateKBest3(float3 ref, float4 point, float* knn) {  // simple_knn.cu:131-145
-  const float dx = point.x - ref.x, dy = point.y - ref.y, dz = point.z - ref.z;
-  float dist = dx * dx + dy * dy + dz * dz;
+
+__device__ __forceinline__ void keep_best3(float dist, float* best) {   // best[0] <= best[1] <= best[2]
 #pragma unroll
   for (int j = 0; j < 3; j++)
-    if (knn[j] > dist) { const float t = knn[j]; knn[j] = dist; dist = t; }
+    if (best[j] > dist) { const float t = best[j]; best[j] = dist; dist = t; }
 }
-__global__ void __launch_bounds__(256) box_mean_dist_kernel(int P, const float4* __restrict__ sorted, const float* __restrict__ boxes,
-                                                            float* __restrict__ dists) {  // simple_knn.cu:147-183
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= P) return;
-  const float4 me = sorted[idx];
-  const float3 point = make_float3(me.x, me.y, me.z);
+__device__ __forceinline__ float gap2_point_box(const float* b, float x, float y, float z) {   // squared distance point -> AABB
+  const float dx = fmaxf(0.f, fmaxf(b[0] - x, x - b[3])), dy = fmaxf(0.f, fmaxf(b[1] - y, y - b[4])), dz = fmaxf(0.f, fmaxf(b[2] - z, z - b[5]));
+  return dx * dx + dy * dy + dz * dz;
+}
+__device__ __forceinline__ float block_max(float v, float* s_red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+}
+
+__global__ void __launch_bounds__(KNN_BOX) knn_query_kernel(int P, const float4* __restrict__ sorted, const float* __restrict__ boxes,
+                                                            int nboxes, float* __restrict__ dists) {
+  __shared__ float4 tile[KNN_BOX];
+  __shared__ float s_red[4];
+  __shared__ int s_hits[KNN_BOX];
+  __shared__ int s_wave_n[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int qb = blockIdx.x;
+  const int q = qb * KNN_BOX + tid;
+  const bool valid = q < P;
+  const float4 me = valid ? sorted[q] : make_float4(0.f, 0.f, 0.f, 0.f);
   float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
-  for (int i = max(0, idx - 3); i <= min(P - 1, idx + 3); i++) {
-    if (i == idx) continue;
-    updateKBest3(point, sorted[i], best);
-  }
-  const float reject = best[2];
-  best[0] = FLT_MAX; best[1] = FLT_MAX; best[2] = FLT_MAX;
-  const int nboxes = (P + BOX_SIZE - 1) / BOX_SIZE;
-  for (int b = 0; b < nboxes; b++) {
-    const float dist = distBoxPoint(boxes + 6 * b, point);
-    if (dist > reject || dist > best[2]) continue;
-    const int hi = min(P, (b + 1) * BOX_SIZE);
-    for (int i = b * BOX_SIZE; i < hi; i++) {
-      if (i == idx) continue;
-      updateKBest3(point, sorted[i], best);
+
+  auto scan_tile = [&](int count, int self) {     // all lanes read the same LDS word: broadcast
+    for (int j = 0; j < count; j++) {
+      const float4 p = tile[j];
+      const float dx = p.x - me.x, dy = p.y - me.y, dz = p.z - me.z;
+      const float d = dx * dx + dy * dy + dz * dz;
+      if (j != self) keep_best3(d, best);
     }
+  };
+  // (A) the workgroup's own box
+  tile[tid] = me;
+  __syncthreads();
+  const int own = min(KNN_BOX, P - qb * KNN_BOX);
+  if (valid) scan_tile(own, tid);
+  float R = block_max(valid ? best[2] : 0.f, s_red);
+  float qbox[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) qbox[k] = boxes[qb * 6 + k];
+
+  // (B) every other box that can hold a point closer than R to some point of this workgroup's box
+  for (int base = 0; base < nboxes; base += KNN_BOX) {
+    const int b = base + tid;
+    bool hit = false;
+    if (b < nboxes && b != qb) {
+      const float* bb = boxes + 6 * (size_t)b;
+      const float gx = fmaxf(0.f, fmaxf(bb[0] - qbox[3], qbox[0] - bb[3])), gy = fmaxf(0.f, fmaxf(bb[1] - qbox[4], qbox[1] - bb[4])),
+                  gz = fmaxf(0.f, fmaxf(bb[2] - qbox[5], qbox[2] - bb[5]));
+      hit = (gx * gx + gy * gy + gz * gz) * 0.999999f <= R;
+    }
+    const uint64_t m = __ballot(hit);
+    if (lane == 0) s_wave_n[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+    for (int w = 0; w < 4; w++) { if (w < wv) off += s_wave_n[w]; total += s_wave_n[w]; }
+    if (hit) s_hits[off + __popcll(m & ((1ull << lane) - 1ull))] = b;
+    __syncthreads();
+    for (int h = 0; h < total; h++) {
+      const int hb = s_hits[h];
+      const int src = hb * KNN_BOX + tid;
+      const float4 mine = src < P ? sorted[src] : make_float4(KNN_FAR, KNN_FAR, KNN_FAR, 0.f);
+      __syncthreads();          // everyone is done with the previous tile
+      tile[tid] = mine;
+      __syncthreads();
+      if (valid && gap2_point_box(boxes + 6 * (size_t)hb, me.x, me.y, me.z) * 0.999999f <= best[2])
+        scan_tile(min(KNN_BOX, P - hb * KNN_BOX), -1);
+    }
+    if (total > 0) R = block_max(valid ? best[2] : 0.f, s_red);   // the bound only ever tightens
+    __syncthreads();
   }
-  dists[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
+  if (valid) dists[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
 }
 
 // ---------------------------------------------------------------- operate_points
@@ -237,7 +298,7 @@ struct KnnLayout { size_t bbox, partial, keys, vals, keys_o, vals_o, sorted, box
 KnnLayout knn_layout(int P) {
   using segs::align_up;
   KnnLayout l{};
-  const int nboxes = (P + BOX_SIZE - 1) / BOX_SIZE;
+  const int nboxes = (P + KNN_BOX - 1) / KNN_BOX;
   size_t o = 0;
   l.bbox = o;      o = align_up(o + 64);
   l.partial = o;   o = align_up(o + 256 * 6 * 4);
@@ -274,10 +335,10 @@ int segs_knn_mean_dist2(int P, const float* points, float* mean_dists, char* tem
   int rc = segs_sort_pairs((const uint64_t*)(base + L.keys), (const uint32_t*)(base + L.vals), (uint64_t*)(base + L.keys_o),
                            (uint32_t*)(base + L.vals_o), P, 30, base + L.sort_temp, stream);
   if (rc) return rc;
-  const int nboxes = (P + BOX_SIZE - 1) / BOX_SIZE;
-  box_minmax_kernel<<<nboxes, BOX_SIZE, 0, st>>>(P, points, (const uint32_t*)(base + L.vals_o), (float4*)(base + L.sorted),
-                                                 (float*)(base + L.boxes)); LAUNCH_OK();
-  box_mean_dist_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, (const float4*)(base + L.sorted), (const float*)(base + L.boxes), mean_dists); LAUNCH_OK();
+  const int nboxes = (P + KNN_BOX - 1) / KNN_BOX;
+  knn_gather_boxes_kernel<<<nboxes, KNN_BOX, 0, st>>>(P, points, (const uint32_t*)(base + L.vals_o), (float4*)(base + L.sorted),
+                                                      (float*)(base + L.boxes)); LAUNCH_OK();
+  knn_query_kernel<<<nboxes, KNN_BOX, 0, st>>>(P, (const float4*)(base + L.sorted), (const float*)(base + L.boxes), nboxes, mean_dists); LAUNCH_OK();
   return SEGS_OK;
 }
 

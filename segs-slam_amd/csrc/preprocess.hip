@@ -24,6 +24,7 @@
 #include <cstdint>
 #include "gs_layout.h"
 #include "kernels.h"
+#include "sh_color.h"
 
 #pragma clang fp contract(off)
 
@@ -185,112 +186,6 @@ __device__ __forceinline__ Projected project_gaussian(float3 p, float3 scale, fl
 }
 
 
-// ---- spherical harmonics: SH -> RGB (forward.cu:20-71) and its backward (backward.cu:20-139).  Off the live
-// SEGS-SLAM path (the renderer always passes colors_precomp, src/gaussian_renderer.cpp:86-99); kept for API parity.
-// glm::vec3 semantics: componentwise ops, dot summed left to right.
-__device__ const float SH_C0 = 0.28209479177387814f;
-__device__ const float SH_C1 = 0.4886025119029199f;
-__device__ const float SH_C2[] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
-__device__ const float SH_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
-                                  -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
-struct v3 { float x, y, z; };
-__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ v3 operator*(float s, v3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ v3 operator*(v3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ v3 operator/(v3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
-__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ float length(v3 a) { return sqrtf(dot(a, a)); }
-__device__ __forceinline__ v3 ldv3(const float* p) { return {p[0], p[1], p[2]}; }
-
-__device__ v3 sh_to_rgb(int idx, int deg, int max_coeffs, float3 mean, const float* campos_, const float* shs, uint32_t* clamp_bits) {
-  v3 pos = {mean.x, mean.y, mean.z};
-  v3 campos = {campos_[0], campos_[1], campos_[2]};
-  v3 dir = pos - campos;
-  dir = dir / length(dir);
-  const float* shp = shs + (size_t)idx * max_coeffs * 3;
-#define SH(k) ldv3(shp + 3 * (k))
-  v3 result = SH_C0 * SH(0);
-  if (deg > 0) {
-    float x = dir.x, y = dir.y, z = dir.z;
-    result = result - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
-    if (deg > 1) {
-      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-      result = result + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) + SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
-               SH_C2[3] * xz * SH(7) + SH_C2[4] * (xx - yy) * SH(8);
-      if (deg > 2) {
-        result = result + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
-                 SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) + SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
-                 SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
-                 SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
-      }
-    }
-  }
-  result = result + v3{0.5f, 0.5f, 0.5f};
-  *clamp_bits = (result.x < 0 ? 1u : 0u) | (result.y < 0 ? 2u : 0u) | (result.z < 0 ? 4u : 0u);
-  return {fmaxf(result.x, 0.0f), fmaxf(result.y, 0.0f), fmaxf(result.z, 0.0f)};
-}
-
-__device__ __forceinline__ v3 dnormvdv(v3 v, v3 dv) {  // auxiliary.h:109-120
-  float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
-  float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-  v3 r;
-  r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
-  r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
-  r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
-  return r;
-}
-
-// returns the contribution to dL_dmean (backward.cu:138); writes the active rows of dL_dsh
-__device__ v3 sh_to_rgb_backward(int idx, int deg, int max_coeffs, float3 mean, const float* campos_, const float* shs,
-                                 uint32_t clamp_bits, v3 dL_dRGB, float* dL_dshs) {
-  v3 pos = {mean.x, mean.y, mean.z};
-  v3 campos = {campos_[0], campos_[1], campos_[2]};
-  v3 dir_orig = pos - campos;
-  v3 dir = dir_orig / length(dir_orig);
-  const float* shp = shs + (size_t)idx * max_coeffs * 3;
-  dL_dRGB.x *= (clamp_bits & 1u) ? 0 : 1; dL_dRGB.y *= (clamp_bits & 2u) ? 0 : 1; dL_dRGB.z *= (clamp_bits & 4u) ? 0 : 1;
-  v3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
-  float x = dir.x, y = dir.y, z = dir.z;
-  float* out = dL_dshs + (size_t)idx * max_coeffs * 3;
-#define ST(k, val) do { const v3 _v = (val); out[3 * (k)] = _v.x; out[3 * (k) + 1] = _v.y; out[3 * (k) + 2] = _v.z; } while (0)
-  float dRGBdsh0 = SH_C0;
-  ST(0, dRGBdsh0 * dL_dRGB);
-  if (deg > 0) {
-    float dRGBdsh1 = -SH_C1 * y, dRGBdsh2 = SH_C1 * z, dRGBdsh3 = -SH_C1 * x;
-    ST(1, dRGBdsh1 * dL_dRGB); ST(2, dRGBdsh2 * dL_dRGB); ST(3, dRGBdsh3 * dL_dRGB);
-    dRGBdx = -SH_C1 * SH(3); dRGBdy = -SH_C1 * SH(1); dRGBdz = SH_C1 * SH(2);
-    if (deg > 1) {
-      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-      float dRGBdsh4 = SH_C2[0] * xy, dRGBdsh5 = SH_C2[1] * yz, dRGBdsh6 = SH_C2[2] * (2.f * zz - xx - yy);
-      float dRGBdsh7 = SH_C2[3] * xz, dRGBdsh8 = SH_C2[4] * (xx - yy);
-      ST(4, dRGBdsh4 * dL_dRGB); ST(5, dRGBdsh5 * dL_dRGB); ST(6, dRGBdsh6 * dL_dRGB); ST(7, dRGBdsh7 * dL_dRGB); ST(8, dRGBdsh8 * dL_dRGB);
-      dRGBdx = dRGBdx + (SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8));
-      dRGBdy = dRGBdy + (SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8));
-      dRGBdz = dRGBdz + (SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7));
-      if (deg > 2) {
-        float dRGBdsh9 = SH_C3[0] * y * (3.f * xx - yy), dRGBdsh10 = SH_C3[1] * xy * z, dRGBdsh11 = SH_C3[2] * y * (4.f * zz - xx - yy);
-        float dRGBdsh12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), dRGBdsh13 = SH_C3[4] * x * (4.f * zz - xx - yy);
-        float dRGBdsh14 = SH_C3[5] * z * (xx - yy), dRGBdsh15 = SH_C3[6] * x * (xx - 3.f * yy);
-        ST(9, dRGBdsh9 * dL_dRGB); ST(10, dRGBdsh10 * dL_dRGB); ST(11, dRGBdsh11 * dL_dRGB); ST(12, dRGBdsh12 * dL_dRGB);
-        ST(13, dRGBdsh13 * dL_dRGB); ST(14, dRGBdsh14 * dL_dRGB); ST(15, dRGBdsh15 * dL_dRGB);
-        dRGBdx = dRGBdx + (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
-                           SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
-                           SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy));
-        dRGBdy = dRGBdy + (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz + SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) +
-                           SH_C3[3] * SH(12) * -3.f * 2.f * yz + SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz +
-                           SH_C3[6] * SH(15) * -3.f * 2.f * xy);
-        dRGBdz = dRGBdz + (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz + SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
-                           SH_C3[4] * SH(13) * 4.f * 2.f * xz + SH_C3[5] * SH(14) * (xx - yy));
-      }
-    }
-  }
-#undef ST
-#undef SH
-  v3 dL_ddir = {dot(dRGBdx, dL_dRGB), dot(dRGBdy, dL_dRGB), dot(dRGBdz, dL_dRGB)};
-  return dnormvdv(dir_orig, dL_ddir);
-}
-
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ colors,
@@ -350,8 +245,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       const float op = opacities[idx];
       if (!colors) {  // forward.cu:241-247
         uint32_t cb;
-        const v3 c3 = sh_to_rgb(idx, D, M, p, cam_pos, shs, &cb);
-        col = make_float3(c3.x, c3.y, c3.z);
+        col = sh::to_rgb(idx, D, M, p, cam_pos, shs, &cb);
         clamped[idx] = cb;
       }
       float4* r4 = reinterpret_cast<float4*>(rec + (size_t)idx * REC_DWORDS);
@@ -426,8 +320,50 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
   present[idx] = (p_view.z <= 0.2f) ? 0 : 1;
 }
 
-// Fused K12 + K13.  gacc rows hold the tile kernel's per-Gaussian sums (gs_layout.h); if gacc is null the
-// caller supplied dL_dmean2D / dL_dconic directly (test hook for the bit-exactness check).
+// Workgroup-coalesced store of row `tid` of a (P,3) float array: LDS transpose + three dword sweeps (the mirror of
+// load_row3; per-lane 12-byte rows written as three strided dwords filled only a third of every store instruction).
+__device__ __forceinline__ void store_row3(float* __restrict__ a, int P, float* lds /*768 floats*/, float x, float y, float z) {
+  const int tid = threadIdx.x;
+  lds[3 * tid] = x; lds[3 * tid + 1] = y; lds[3 * tid + 2] = z;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * 768;
+  const size_t lim = (size_t)P * 3;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const size_t i = base + k * 256 + tid;
+    if (i < lim) a[i] = lds[k * 256 + tid];
+  }
+  __syncthreads();
+}
+
+// ---- Backward of the per-Gaussian stage: the reference's computeCov2DCUDA + preprocessCUDA + computeCov3D backward
+// (backward.cu:144-274, 346-396, 278-341) as ONE pass, derived here from the forward map rather than transcribed:
+//
+//   t  = Wv p + tv                        view space; t.xy/t.z clamped to +-1.3 tan(fov/2)      (forward.cu:74-113)
+//   J  = [[fx/tz, 0, -fx tx/tz^2], [0, fy/tz, -fy ty/tz^2]]                   M2 = J Wv   (2x3)
+//   L  = R(q) diag(s),  s = mod * scale,  Sigma = L L^T                       U  = M2 L   (2x3)
+//   C  = U U^T + 0.3 I  = [[a, b], [b, c]]                                    conic Q = adj(C) / det
+//
+// Given the tile kernel's  G = [[gA, gB], [gB, gC]]  (dL/dconic with the off-diagonal stored once, backward.cu:545-549):
+//   Dc    = dL/dC = -k adj(C) G adj(C),   k = 1 / (det^2 + 1e-7)             (the reference's guarded 1/det^2, :205)
+//   dL/dSigma = M2^T Dc M2                 -> dL_dcov3D (off-diagonals doubled: six unique entries)
+//   dL/dM2    = 2 Dc (U L^T)               -> dL/dJ = dL/dM2 Wv^T -> dL/dt  (a clamped coordinate passes nothing, :175-176)
+//   dL/dL     = 2 M2^T (Dc U)              -> dL/ds_k = sum_i R_ik dL/dL_ik  (w.r.t. the MODIFIED scale s: the reference
+//                                             applies no chain factor for mod, :316-320),  dL/dR_ik = s_k dL/dL_ik -> dL/dq
+//                                             through R(q) with q taken as given (no normalisation Jacobian, :340)
+//   dL/dp     = Wv^T dL/dt  +  d(ndc.xy)/dp^T (g2x, g2y),   ndc = (PV p).xy / ((PV p).w + 1e-7)                 (:370-387)
+// The factorisation through U = M2 L never forms Sigma when scales and rotations are given.
+struct Sym2 { float xx, xy, yy; };
+
+__device__ __forceinline__ void quat_rows(float4 q, float R[3][3]) {   // standard rotation matrix of (r, x, y, z), rows
+  const float r = q.x, x = q.y, y = q.z, z = q.w;
+  R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z);       R[0][2] = 2.f * (x * z + r * y);
+  R[1][0] = 2.f * (x * y + r * z);       R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+  R[2][0] = 2.f * (x * z - r * y);       R[2][1] = 2.f * (y * z + r * x);       R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// gacc rows hold the tile kernel's per-Gaussian sums (gs_layout.h); if gacc is null the caller supplied dL_dmean2D /
+// dL_dconic directly (segs_debug_preprocess_backward: this stage alone against the oracle).
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ scales,
     const float* __restrict__ rotations, float mod, const float* __restrict__ cov3D_precomp,
@@ -440,151 +376,178 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     float* __restrict__ dL_dsh, int clean_gacc /* write zeros back over the consumed accumulator row (resident backward) */) {
   __shared__ float lds[768];
   const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < P;
   const float3 mean = load_row3(means3D, P, lds);
   float3 scale = make_float3(0, 0, 0);
   if (scales) scale = load_row3(scales, P, lds);
-  if (idx >= P) return;
+  const bool binned = live && radii[idx] > 0;
 
-  float g2x, g2y, gcx, gcy, gcw;
-  float dcol0 = 0.f, dcol1 = 0.f, dcol2 = 0.f;
+  // ---- what arrives from the tile kernel
+  float g2x = 0.f, g2y = 0.f;            // dL/dmean2D, NDC-scaled (backward.cu:541-542)
+  Sym2 G{0.f, 0.f, 0.f};                 // dL/dconic
+  float dcol0 = 0.f, dcol1 = 0.f, dcol2 = 0.f, dop = 0.f;
   if (gacc) {
-    // Rows hold raw moments from the tile kernel (render.hip): Mx My Mxx Mxy | Myy S0 Sr Sg | Sb, sums over the
-    // (pixel, Gaussian) pairs of w=dL_dG*G times 1, dx, dy, ...; the reference's per-pair terms
-    // (backward.cu:541-554) are linear in them:
-    //   dL_dmean2D.x = sum dL_dG*(-G dx A - G dy B)*(W/2) = -(A Mx + B My) W/2,  .y = -(C My + B Mx) H/2
-    //   dL_dconic    = -0.5 (Mxx, Mxy, Myy);   dL_dopacity = sum G dL_dalpha = S0 / o
-    const float4* a = reinterpret_cast<const float4*>(gacc + (size_t)idx * GACC_DWORDS);
-    const float4 a0 = a[0], a1 = a[1];
-    const float a8 = gacc[(size_t)idx * GACC_DWORDS + 8];
-    if (clean_gacc && radii[idx] > 0) {   // only binned Gaussians' rows can have been touched by the tile kernel
-      float4* z = reinterpret_cast<float4*>(gacc + (size_t)idx * GACC_DWORDS);
-      z[0] = make_float4(0.f, 0.f, 0.f, 0.f); z[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      gacc[(size_t)idx * GACC_DWORDS + 8] = 0.f;
-    }
-    float dop = 0.f;
-    g2x = 0.f; g2y = 0.f; gcx = 0.f; gcy = 0.f; gcw = 0.f;
-    if (radii[idx] > 0) {
+    // Rows hold raw moments (render.hip): Mx My Mxx Mxy | Myy S0 Sr Sg | Sb = sums over the (pixel, Gaussian) pairs of
+    // w = dL/dG * G times 1, dx, dy, dx^2, ...; the reference's per-pair terms (backward.cu:541-554) are linear in them:
+    //   dL/dmean2D.x = -(A Mx + B My) W/2,  .y = -(C My + B Mx) H/2,  dL/dconic = -(Mxx, Mxy, Myy)/2,  dL/dopacity = S0 / o
+    if (binned) {
+      float4* row = reinterpret_cast<float4*>(gacc + (size_t)idx * GACC_DWORDS);
+      const float4 a0 = row[0], a1 = row[1];
+      const float a8 = gacc[(size_t)idx * GACC_DWORDS + 8];
+      if (clean_gacc) {   // only binned Gaussians' rows can have been touched by the tile kernel
+        row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gacc[(size_t)idx * GACC_DWORDS + 8] = 0.f;
+      }
       const float4 q2 = reinterpret_cast<const float4*>(rec_in + (size_t)idx * REC_DWORDS)[2];  // b, A, B, C
       const float op = rec_in[(size_t)idx * REC_DWORDS + REC_O];
       g2x = -(q2.y * a0.x + q2.z * a0.y) * (0.5f * img_w);
       g2y = -(q2.w * a0.y + q2.z * a0.x) * (0.5f * img_h);
-      gcx = -0.5f * a0.z; gcy = -0.5f * a0.w; gcw = -0.5f * a1.x;
+      G.xx = -0.5f * a0.z; G.xy = -0.5f * a0.w; G.yy = -0.5f * a1.x;
       dop = a1.y != 0.f ? a1.y / op : 0.f;
+      dcol0 = a1.z; dcol1 = a1.w; dcol2 = a8;
     }
-    dL_dmean2D[3 * (size_t)idx + 0] = g2x; dL_dmean2D[3 * (size_t)idx + 1] = g2y; dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
-    if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(gcx, gcy, 0.f, gcw);   // internal product: optional
-    dL_dopacity[idx] = dop;
-    dL_dcolor[3 * (size_t)idx + 0] = a1.z; dL_dcolor[3 * (size_t)idx + 1] = a1.w; dL_dcolor[3 * (size_t)idx + 2] = a8;
-    dcol0 = a1.z; dcol1 = a1.w; dcol2 = a8;
-  } else {
+    store_row3(dL_dmean2D, P, lds, g2x, g2y, 0.f);
+    store_row3(dL_dcolor, P, lds, dcol0, dcol1, dcol2);
+    if (live) {
+      if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(G.xx, G.xy, 0.f, G.yy);   // internal product: optional
+      dL_dopacity[idx] = dop;
+    }
+  } else if (live) {
     g2x = dL_dmean2D[3 * (size_t)idx + 0]; g2y = dL_dmean2D[3 * (size_t)idx + 1];
-    gcx = dL_dconic[4 * (size_t)idx + 0]; gcy = dL_dconic[4 * (size_t)idx + 1]; gcw = dL_dconic[4 * (size_t)idx + 3];
+    G.xx = dL_dconic[4 * (size_t)idx + 0]; G.xy = dL_dconic[4 * (size_t)idx + 1]; G.yy = dL_dconic[4 * (size_t)idx + 3];
   }
 
   float out_mean[3] = {0, 0, 0}, out_cov[6] = {0, 0, 0, 0, 0, 0}, out_scale[3] = {0, 0, 0}, out_rot[4] = {0, 0, 0, 0};
-  if (radii[idx] > 0) {
-    float4 rot = make_float4(0, 0, 0, 0);
-    float cov3D[6];
-    if (cov3D_precomp) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) cov3D[k] = cov3D_precomp[(size_t)6 * idx + k];
-    } else {
-      rot = reinterpret_cast<const float4*>(rotations)[idx];
-      computeCov3D(scale, mod, rot, cov3D);
-    }
-    // ---- K12: backward.cu:160-273
-    const float3 dL_dconic3 = make_float3(gcx, gcy, gcw);
-    Cov2DTerms q;
-    float3 abc = computeCov2D(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view, &q);
+  if (binned) {
+    // ---- forward quantities again (cheaper than storing them: 36 B of inputs against ~30 floats of intermediates)
+    const float tx0 = view[0] * mean.x + view[4] * mean.y + view[8] * mean.z + view[12];
+    const float ty0 = view[1] * mean.x + view[5] * mean.y + view[9] * mean.z + view[13];
+    const float tz = view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14];
     const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-    const float x_grad_mul = q.txtz < -limx || q.txtz > limx ? 0 : 1;
-    const float y_grad_mul = q.tytz < -limy || q.tytz > limy ? 0 : 1;
-    const mat3& T = q.T; const mat3& Wm = q.W; const mat3& Vrk = q.Vrk; const float3 t = q.t;
-    float a = abc.x, b = abc.y, c = abc.z;
-    float denom = a * c - b * b;
-    float dL_da = 0, dL_db = 0, dL_dc = 0;
-    float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-    if (denom2inv != 0) {
-      dL_da = denom2inv * (-c * c * dL_dconic3.x + 2 * b * c * dL_dconic3.y + (denom - a * c) * dL_dconic3.z);
-      dL_dc = denom2inv * (-a * a * dL_dconic3.z + 2 * a * b * dL_dconic3.y + (denom - a * c) * dL_dconic3.x);
-      dL_db = denom2inv * 2 * (b * c * dL_dconic3.x - (denom + 2 * b * b) * dL_dconic3.y + a * b * dL_dconic3.z);
-      out_cov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
-      out_cov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
-      out_cov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
-      out_cov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][1] * dL_dc;
-      out_cov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][2] * dL_dc;
-      out_cov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2 * T.m[1][1] * T.m[1][2] * dL_dc;
-    }
-    float dL_dT00 = 2 * (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_da +
-                    (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_db;
-    float dL_dT01 = 2 * (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_da +
-                    (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_db;
-    float dL_dT02 = 2 * (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_da +
-                    (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_db;
-    float dL_dT10 = 2 * (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc +
-                    (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_db;
-    float dL_dT11 = 2 * (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc +
-                    (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_db;
-    float dL_dT12 = 2 * (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc +
-                    (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_db;
-    float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
-    float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
-    float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
-    float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
-    float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
-    float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-    float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-    float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
-    // transformVec4x3Transpose (auxiliary.h:90-98)
-    float k12x = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz;
-    float k12y = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz;
-    float k12z = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
-    // ---- K13: backward.cu:370-387
-    float4 m_hom = transformPoint4x4(mean, proj);
-    float m_w = 1.0f / (m_hom.w + 0.0000001f);
-    float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
-    float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-    float dmx = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
-    float dmy = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
-    float dmz = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
-    out_mean[0] = k12x + dmx; out_mean[1] = k12y + dmy; out_mean[2] = k12z + dmz;  // "dL_dmeans[idx] += dL_dmean" (:387)
-    if (shs && gacc) {  // backward.cu:390-391 (needs the summed dL_dcolor of this Gaussian)
-      const v3 g = sh_to_rgb_backward(idx, D, M, mean, cam_pos, shs, clamped[idx], v3{dcol0, dcol1, dcol2}, dL_dsh);
-      out_mean[0] = out_mean[0] + g.x; out_mean[1] = out_mean[1] + g.y; out_mean[2] = out_mean[2] + g.z;
-    }
-    // ---- computeCov3D backward: backward.cu:278-341 (no quaternion-normalisation Jacobian, F5b)
-    if (scales) {
-      const float r = rot.x, x = rot.y, y = rot.z, z = rot.w;
-      mat3 Rm = quat_to_R(rot);
-      mat3 S = mk(1, 0, 0, 0, 1, 0, 0, 0, 1);
-      const float3 s = make_float3(mod * scale.x, mod * scale.y, mod * scale.z);
-      S.m[0][0] = s.x; S.m[1][1] = s.y; S.m[2][2] = s.z;
-      mat3 M = mul(S, Rm);
-      const float* g = out_cov;
-      mat3 dL_dSigma = mk(g[0], 0.5f * g[1], 0.5f * g[2], 0.5f * g[1], g[3], 0.5f * g[4], 0.5f * g[2], 0.5f * g[4], g[5]);
-      mat3 dL_dM = mul(smul(2.0f, M), dL_dSigma);
-      mat3 Rt = transpose(Rm);
-      mat3 dL_dMt = transpose(dL_dM);
-      out_scale[0] = Rt.m[0][0] * dL_dMt.m[0][0] + Rt.m[0][1] * dL_dMt.m[0][1] + Rt.m[0][2] * dL_dMt.m[0][2];
-      out_scale[1] = Rt.m[1][0] * dL_dMt.m[1][0] + Rt.m[1][1] * dL_dMt.m[1][1] + Rt.m[1][2] * dL_dMt.m[1][2];
-      out_scale[2] = Rt.m[2][0] * dL_dMt.m[2][0] + Rt.m[2][1] * dL_dMt.m[2][1] + Rt.m[2][2] * dL_dMt.m[2][2];
+    const float rx = tx0 / tz, ry = ty0 / tz;
+    const bool free_x = !(rx < -limx || rx > limx), free_y = !(ry < -limy || ry > limy);
+    const float tx = fminf(limx, fmaxf(-limx, rx)) * tz, ty = fminf(limy, fmaxf(-limy, ry)) * tz;
+    const float iz = 1.f / tz, iz2 = iz * iz;
+    const float J00 = h_x * iz, J02 = -h_x * tx * iz2, J11 = h_y * iz, J12 = -h_y * ty * iz2;
+    float M2[2][3];   // M2 = J Wv,  Wv[i][j] = view[4 j + i]
 #pragma unroll
-      for (int k = 0; k < 3; k++) { dL_dMt.m[0][k] *= s.x; dL_dMt.m[1][k] *= s.y; dL_dMt.m[2][k] *= s.z; }
-      out_rot[0] = 2 * z * (dL_dMt.m[0][1] - dL_dMt.m[1][0]) + 2 * y * (dL_dMt.m[2][0] - dL_dMt.m[0][2]) + 2 * x * (dL_dMt.m[1][2] - dL_dMt.m[2][1]);
-      out_rot[1] = 2 * y * (dL_dMt.m[1][0] + dL_dMt.m[0][1]) + 2 * z * (dL_dMt.m[2][0] + dL_dMt.m[0][2]) + 2 * r * (dL_dMt.m[1][2] - dL_dMt.m[2][1]) - 4 * x * (dL_dMt.m[2][2] + dL_dMt.m[1][1]);
-      out_rot[2] = 2 * x * (dL_dMt.m[1][0] + dL_dMt.m[0][1]) + 2 * r * (dL_dMt.m[2][0] - dL_dMt.m[0][2]) + 2 * z * (dL_dMt.m[1][2] + dL_dMt.m[2][1]) - 4 * y * (dL_dMt.m[2][2] + dL_dMt.m[0][0]);
-      out_rot[3] = 2 * r * (dL_dMt.m[0][1] - dL_dMt.m[1][0]) + 2 * x * (dL_dMt.m[2][0] + dL_dMt.m[0][2]) + 2 * y * (dL_dMt.m[1][2] + dL_dMt.m[2][1]) - 4 * z * (dL_dMt.m[1][1] + dL_dMt.m[0][0]);
+    for (int j = 0; j < 3; j++) {
+      M2[0][j] = J00 * view[4 * j] + J02 * view[4 * j + 2];
+      M2[1][j] = J11 * view[4 * j + 1] + J12 * view[4 * j + 2];
+    }
+    float R[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, s3[3] = {0, 0, 0};
+    float4 q = make_float4(0, 0, 0, 0);
+    float E[2][3];    // E = M2 Sigma (= U L^T)
+    float U[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    float a, b, c;
+    if (cov3D_precomp) {
+      const float* cv = cov3D_precomp + (size_t)6 * idx;
+      const float S[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) E[r][j] = M2[r][0] * S[0][j] + M2[r][1] * S[1][j] + M2[r][2] * S[2][j];
+      a = E[0][0] * M2[0][0] + E[0][1] * M2[0][1] + E[0][2] * M2[0][2] + 0.3f;
+      b = E[0][0] * M2[1][0] + E[0][1] * M2[1][1] + E[0][2] * M2[1][2];
+      c = E[1][0] * M2[1][0] + E[1][1] * M2[1][1] + E[1][2] * M2[1][2] + 0.3f;
+    } else {
+      q = reinterpret_cast<const float4*>(rotations)[idx];
+      quat_rows(q, R);
+      s3[0] = mod * scale.x; s3[1] = mod * scale.y; s3[2] = mod * scale.z;
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) U[r][k] = (M2[r][0] * R[0][k] + M2[r][1] * R[1][k] + M2[r][2] * R[2][k]) * s3[k];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) E[r][j] = U[r][0] * R[j][0] * s3[0] + U[r][1] * R[j][1] * s3[1] + U[r][2] * R[j][2] * s3[2];
+      a = U[0][0] * U[0][0] + U[0][1] * U[0][1] + U[0][2] * U[0][2] + 0.3f;
+      b = U[0][0] * U[1][0] + U[0][1] * U[1][1] + U[0][2] * U[1][2];
+      c = U[1][0] * U[1][0] + U[1][1] * U[1][1] + U[1][2] * U[1][2] + 0.3f;
+    }
+    // ---- Dc = -k adj(C) G adj(C)
+    const float det = a * c - b * b;
+    const float k = 1.0f / (det * det + 0.0000001f);
+    const float h0 = c * G.xx - b * G.xy, h1 = c * G.xy - b * G.yy;     // rows of adj(C) G
+    const float h2 = a * G.xy - b * G.xx, h3 = a * G.yy - b * G.xy;
+    Sym2 Dc;
+    Dc.xx = -k * (h0 * c - h1 * b);
+    Dc.xy = -k * (h1 * a - h0 * b);
+    Dc.yy = -k * (h3 * a - h2 * b);
+    float DM[2][3];   // Dc M2
+#pragma unroll
+    for (int j = 0; j < 3; j++) { DM[0][j] = Dc.xx * M2[0][j] + Dc.xy * M2[1][j]; DM[1][j] = Dc.xy * M2[0][j] + Dc.yy * M2[1][j]; }
+    if (dL_dcov3D || cov3D_precomp) {   // dL/dSigma = M2^T Dc M2, six unique entries
+      const int ii[6] = {0, 0, 0, 1, 1, 2}, jj[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
+        const float v = M2[0][ii[e]] * DM[0][jj[e]] + M2[1][ii[e]] * DM[1][jj[e]];
+        out_cov[e] = ii[e] == jj[e] ? v : 2.f * v;
+      }
+    }
+    // ---- through M2 = J Wv to t, then to the mean
+    float dM2[2][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      dM2[0][j] = 2.f * (Dc.xx * E[0][j] + Dc.xy * E[1][j]);
+      dM2[1][j] = 2.f * (Dc.xy * E[0][j] + Dc.yy * E[1][j]);
+    }
+    // dL/dJ[r][i] = sum_j dM2[r][j] Wv[i][j]; only the four structural entries of J
+    const float dJ00 = dM2[0][0] * view[0] + dM2[0][1] * view[4] + dM2[0][2] * view[8];
+    const float dJ02 = dM2[0][0] * view[2] + dM2[0][1] * view[6] + dM2[0][2] * view[10];
+    const float dJ11 = dM2[1][0] * view[1] + dM2[1][1] * view[5] + dM2[1][2] * view[9];
+    const float dJ12 = dM2[1][0] * view[2] + dM2[1][1] * view[6] + dM2[1][2] * view[10];
+    const float iz3 = iz2 * iz;
+    const float dtx = free_x ? -h_x * iz2 * dJ02 : 0.f;
+    const float dty = free_y ? -h_y * iz2 * dJ12 : 0.f;
+    const float dtz = -h_x * iz2 * dJ00 - h_y * iz2 * dJ11 + 2.f * h_x * tx * iz3 * dJ02 + 2.f * h_y * ty * iz3 * dJ12;
+    // projection term: ndc = hom.xy * w,  w = 1 / (hom.w + 1e-7)
+    const float hx = proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12];
+    const float hy = proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13];
+    const float hw = proj[3] * mean.x + proj[7] * mean.y + proj[11] * mean.z + proj[15];
+    const float w = 1.0f / (hw + 0.0000001f);
+    const float ux = hx * w * w, uy = hy * w * w;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const float from_cov = view[4 * j] * dtx + view[4 * j + 1] * dty + view[4 * j + 2] * dtz;
+      const float from_proj = (proj[4 * j] * w - proj[4 * j + 3] * ux) * g2x + (proj[4 * j + 1] * w - proj[4 * j + 3] * uy) * g2y;
+      out_mean[j] = from_cov + from_proj;
+    }
+    if (shs && gacc) {  // backward.cu:390-391 (needs the summed dL_dcolor of this Gaussian)
+      const float3 g = sh::backward(idx, D, M, mean, cam_pos, shs, clamped[idx], make_float3(dcol0, dcol1, dcol2), dL_dsh);
+      out_mean[0] += g.x; out_mean[1] += g.y; out_mean[2] += g.z;
+    }
+    // ---- scales and rotation: dL/dL = 2 M2^T (Dc U)
+    if (scales) {
+      float DU[2][3];
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) { DU[0][kk] = Dc.xx * U[0][kk] + Dc.xy * U[1][kk]; DU[1][kk] = Dc.xy * U[0][kk] + Dc.yy * U[1][kk]; }
+      float GR[3][3];   // dL/dR
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) {
+        float ds = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const float dLik = 2.f * (M2[0][i] * DU[0][kk] + M2[1][i] * DU[1][kk]);
+          ds += R[i][kk] * dLik;
+          GR[i][kk] = dLik * s3[kk];
+        }
+        out_scale[kk] = ds;
+      }
+      const float r = q.x, x = q.y, y = q.z, z = q.w;
+      out_rot[0] = 2.f * (z * (GR[1][0] - GR[0][1]) + y * (GR[0][2] - GR[2][0]) + x * (GR[2][1] - GR[1][2]));
+      out_rot[1] = 2.f * (y * (GR[0][1] + GR[1][0]) + z * (GR[0][2] + GR[2][0]) + r * (GR[2][1] - GR[1][2])) - 4.f * x * (GR[1][1] + GR[2][2]);
+      out_rot[2] = 2.f * (x * (GR[0][1] + GR[1][0]) + r * (GR[0][2] - GR[2][0]) + z * (GR[1][2] + GR[2][1])) - 4.f * y * (GR[0][0] + GR[2][2]);
+      out_rot[3] = 2.f * (r * (GR[1][0] - GR[0][1]) + x * (GR[0][2] + GR[2][0]) + y * (GR[1][2] + GR[2][1])) - 4.f * z * (GR[0][0] + GR[1][1]);
     }
   }
-#pragma unroll
-  for (int k = 0; k < 3; k++) dL_dmean3D[3 * (size_t)idx + k] = out_mean[k];
+  store_row3(dL_dmean3D, P, lds, out_mean[0], out_mean[1], out_mean[2]);
+  if (dL_dscale) store_row3(dL_dscale, P, lds, out_scale[0], out_scale[1], out_scale[2]);
+  if (!live) return;
   if (dL_dcov3D) {   // only a caller that passed cov3D_precomp has a use for it
 #pragma unroll
-    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = out_cov[k];
-  }
-  if (dL_dscale) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) dL_dscale[3 * (size_t)idx + k] = out_scale[k];
+    for (int e = 0; e < 6; e++) dL_dcov3D[6 * (size_t)idx + e] = out_cov[e];
   }
   if (dL_drot) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(out_rot[0], out_rot[1], out_rot[2], out_rot[3]);
 }

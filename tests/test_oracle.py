@@ -154,3 +154,22 @@ def test_backward_finite_difference_scalar():
                 assert abs(fd - an) / abs(fd) < 0.05, (name, gi, fd, an)
                 checked += 1
     assert checked >= 3
+
+
+def test_oracle_per_gaussian_backward_matches_float64_derivation():
+    """K12 + K13 + cov3D backward of the oracle (backward.cu's expression order, float32) against a float64 evaluation of the
+    stage derived from the forward map in matrix form (oracle/preprocess_backward_f64.py): a second, independent pin of the
+    per-Gaussian backward next to the autograd check above.  Float32 rounding only: 1e-5 relative + 4e-6 of max."""
+    from oracle.preprocess_backward_f64 import stage_f64
+    from segs_slam_amd import scenes
+    for seed, mult in ((3, 3.0), (8, 1.0)):
+        sc = scenes.make_scene(2000, 96, 64, 80.0, 80.0, seed=seed)
+        sc.scales *= mult
+        o, ref = gs_oracle.run_scene(sc)
+        cam = sc.camera
+        truth = stage_f64(sc.means3D, sc.scales, sc.rotations, cam.world_view_transform, cam.full_proj_transform, cam.width,
+                          cam.height, cam.tanfovx, cam.tanfovy, ref["dL_dmean2D"], ref["dL_dconic"], o.get("radii"))
+        for k, want in truth.items():
+            err = np.abs(ref[k].astype(np.float64) - want)
+            assert np.abs(want).max() > 0
+            assert np.all(err <= 1e-5 * np.abs(want) + 4e-6 * np.abs(want).max()), (k, float(err.max()), float(np.abs(want).max()))

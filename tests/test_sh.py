@@ -73,7 +73,8 @@ def test_sh_gpu_matches_oracle(deg):
     assert R == o.R and np.array_equal(radii.cpu().numpy(), o.get("radii"))
     st = rp.debug_state(sc.P, cam.width, cam.height, R, radii, geom, binning, img)
     vis = o.get("radii") > 0
-    assert np.array_equal(st["rgb"].cpu().numpy()[vis].view(np.uint32), o.get("rgb")[vis].view(np.uint32))  # SH -> RGB bit-exact
+    # SH -> RGB: the device evaluates a basis table and a dot product (sh_color.h), the oracle forward.cu's running sum
+    np.testing.assert_allclose(st["rgb"].cpu().numpy()[vis], o.get("rgb")[vis], rtol=2e-6, atol=2e-6)
     ok = ~unstable
     a, b = color.cpu().numpy(), o.get("out_color")
     assert np.all(np.abs(a - b)[:, ok] <= 1e-4 * np.abs(b)[:, ok] + 2e-6)
@@ -103,7 +104,7 @@ def test_project2_image_matches_oracle():
     vis = o.get("radii") > 0
     assert vis.sum() > 1000 and np.array_equal(radii.cpu().numpy(), o.get("radii"))
     assert np.array_equal(pts.cpu().numpy()[vis].view(np.uint32), o.get("means2D")[vis].view(np.uint32))
-    assert np.array_equal(col.cpu().numpy()[vis].view(np.uint32), o.get("rgb")[vis].view(np.uint32))
+    np.testing.assert_allclose(col.cpu().numpy()[vis], o.get("rgb")[vis], rtol=2e-6, atol=2e-6)
     # precomputed colours: positions and radii are unchanged
     pts2, radii2, _ = rp.RasterizeGaussiansprojectCUDA(bg, m3, t(sc.colors), op, sca, rot, 1.0, e, view, proj, cam.tanfovx,
                                                        cam.tanfovy, cam.height, cam.width, e, 0, campos, False)
