@@ -181,7 +181,7 @@ __device__ __forceinline__ int wave_lower_bound(const uint32_t* __restrict__ a, 
   return m ? lo + __ffsll((long long)m) - 1 : hi;
 }
 __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
-    int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec, const uint32_t* __restrict__ order,
+    int P, int R, const float* __restrict__ emit /* 32-byte emit records, gs_layout.h */, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ incl, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
     const uint32_t* __restrict__ n_dev /* resident mode: R lives on the device, `R` is the capacity */,
     int mark_dead /* instances that reach no quadrant get DEAD_KEY: the first tile-id pass drops them */,
@@ -206,16 +206,14 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
   const uint32_t excl0 = g_lo == 0 ? 0u : incl[g_lo - 1];
   for (int k = tid; k < n_own; k += 256) {
     const uint32_t idx = order[g_lo + k];
-    const uint4 b = reinterpret_cast<const uint4*>(bin)[idx];
-    s_idx[k] = idx; s_incl[k] = incl[g_lo + k]; s_bin[k] = make_uint2(b.y, b.z);
-    const float* r = rec + (size_t)idx * REC_DWORDS;
-    const float2 xy = *reinterpret_cast<const float2*>(r);
-    const float4 q2 = reinterpret_cast<const float4*>(r)[2];  // b, A, B, C
-    const float op = r[REC_O];
+    const float4* e = reinterpret_cast<const float4*>(emit + (size_t)idx * EMIT_DWORDS);   // ONE 32-byte gather per owner
+    const float4 e0 = e[0], e1 = e[1];   // x y A B | C opacity rect_min rect_max
+    s_idx[k] = idx; s_incl[k] = incl[g_lo + k]; s_bin[k] = make_uint2(__float_as_uint(e1.z), __float_as_uint(e1.w));
+    const float op = e1.y;
     float* g = s_geo[k];
-    g[0] = xy.x; g[1] = xy.y; g[2] = q2.y; g[3] = q2.z; g[4] = q2.w;
+    g[0] = e0.x; g[1] = e0.y; g[2] = e0.z; g[3] = e0.w; g[4] = e1.x;
     g[5] = (op * 255.0f > 1.0f) ? 2.0f * __logf(255.0f * op) * 1.0001f + 1e-3f : -1.0f;
-    g[6] = -q2.z / q2.w; g[7] = -q2.z / q2.y;   // once per Gaussian instead of once per instance
+    g[6] = -e0.w / e1.x; g[7] = -e0.w / e0.z;   // once per Gaussian instead of once per instance
   }
   __syncthreads();
 #pragma unroll
@@ -258,15 +256,18 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift, KeyMap km)
 template <int BITS>
 __device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, KeyMap km) { return ((key - km.dmin) >> shift) & ((1u << BITS) - 1u); }
 
-// Per-lane mask of the lanes (among `valid`) holding the same BITS-bit digit: one ballot per digit bit.
+// Per-lane mask of the lanes (among `valid`) holding the same digit: one ballot per digit bit that can be set (`nbits` <=
+// BITS, wave-uniform: the last pass of a sort usually has fewer significant bits than a full digit).
 template <int BITS>
-__device__ __forceinline__ uint64_t match_digit(uint32_t d, uint64_t valid) {
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, uint64_t valid, int nbits) {
   uint64_t peers = valid;
 #pragma unroll
   for (int bit = 0; bit < BITS; bit++) {
-    const bool set = (d >> bit) & 1u;
-    const uint64_t m = __ballot(set);
-    peers &= set ? m : ~m;
+    if (bit < nbits) {
+      const bool set = (d >> bit) & 1u;
+      const uint64_t m = __ballot(set);
+      peers &= set ? m : ~m;
+    }
   }
   return peers;
 }
@@ -386,7 +387,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     uint32_t* __restrict__ vals_out, int n, int shift, uint32_t dmin, int dbits, const uint32_t* __restrict__ tile_prefix,
     const uint32_t* __restrict__ chunk_prefix /* chunk_hist after radix_scan_kernel */, const uint32_t* __restrict__ digit_totals,
     int nblocks, int nchunks, const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out,
-    const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out) {
+    const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits /* significant bits of this pass's digit */) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   constexpr int NDIG = 1 << BITS;
@@ -426,7 +427,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const bool valid = i < (size_t)n && !(drop_dead && key[r] == (K)DEAD_KEY_OF(K));   // dead keys take no rank: dropped here
     const uint32_t d = valid ? digit_of<BITS>(key[r], shift, km) : 0u;
     const uint64_t vmask = __ballot(valid);
-    const uint64_t peers = match_digit<BITS>(d, vmask);
+    const uint64_t peers = match_digit<BITS>(d, vmask, nbits);
     const uint32_t below = mbcnt(peers);
     uint32_t old = 0;
     if (valid) old = my[d];
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
                                                        const uint32_t*, int);                                                  \
   template __global__ void radix_scatter_kernel<K, BITS, false>(const K*, const uint32_t*, K*, uint32_t*, int, int, uint32_t, int, \
                                                                 const uint32_t*, const uint32_t*, const uint32_t*, int, int,        \
-                                                                const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*);
+                                                                const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int);
 SEGS_INSTANTIATE_RADIX(uint64_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 9)
@@ -519,7 +520,7 @@ SEGS_INSTANTIATE_RADIX(uint32_t, 9)
 #define SEGS_INSTANTIATE_AUX(BITS)                                                                                                     \
   template __global__ void radix_scatter_kernel<uint32_t, BITS, true>(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, int, int, \
                                                                       uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, \
-                                                                      int, int, const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*);
+                                                                      int, int, const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int);
 SEGS_INSTANTIATE_AUX(8)
 SEGS_INSTANTIATE_AUX(9)
 #undef SEGS_INSTANTIATE_AUX

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -124,21 +125,22 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     }
     LAUNCH_TRY("radix_scan_kernel");
     if (iota_vals && p == 0) vin = nullptr;
+    const int nbits = std::min(BITS, end_bit - shift);   // the last pass may have fewer significant bits than a full digit
     { PROF(K_RADIX_SCATTER);
     if constexpr (sizeof(K) == 4) {
       if (aux_in && p == passes - 1) {
         radix_scatter_kernel<K, BITS, true><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                         digit_totals, L.nblocks, L.nchunks, n_in, drop,
-                                                                        drop ? n_live : nullptr, aux_in, aux_final);
+                                                                        drop ? n_live : nullptr, aux_in, aux_final, nbits);
       } else {
         radix_scatter_kernel<K, BITS, false><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                          digit_totals, L.nblocks, L.nchunks, n_in, drop,
-                                                                         drop ? n_live : nullptr, nullptr, nullptr);
+                                                                         drop ? n_live : nullptr, nullptr, nullptr, nbits);
       }
     } else {
       radix_scatter_kernel<K, BITS, false><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                        digit_totals, L.nblocks, L.nchunks, n_in, drop,
-                                                                       drop ? n_live : nullptr, nullptr, nullptr);
+                                                                       drop ? n_live : nullptr, nullptr, nullptr, nbits);
     }
     }
     LAUNCH_TRY("radix_scatter_kernel");
@@ -159,6 +161,7 @@ struct Geom {
   uint32_t* clamped() const { return (uint32_t*)(base + L.clamped); }
   float* gacc() const { return (float*)(base + L.gacc); }
   uint32_t* touched() const { return (uint32_t*)(base + L.touched); }
+  float* emit() const { return (float*)(base + L.emit); }
 };
 Geom geom_at(char* p, int P) { return Geom{geom_layout(P), align_ptr(p)}; }
 // Resident buffers are carved up for the `rows` they were ALLOCATED (and zero-filled) for, so that the self-cleaned
@@ -184,7 +187,7 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
                                                      proj, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, radii,
                                                      G.rec(), G.bin(), G.block_sums(), G.block_sums() + (G.L.nblocks + 1), shs, D, M, cam_pos,
                                                      G.clamped(), g_flags | extra_flags, depth_keys, depth_vals, ranges, (int)(gx * gy),
-                                                     depth_overflow, G.touched());
+                                                     depth_overflow, G.touched(), G.emit());
   }
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
@@ -232,7 +235,7 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   }
   LAUNCH_TRY("ordered_offsets_kernel");
   { PROF(K_DUPLICATE);
-  duplicate_with_keys_kernel<<<(n_cap + 511) / 512, 256, 0, st>>>(P, n_cap, G.bin(), G.rec(), order, G.offsets(),
+  duplicate_with_keys_kernel<<<(n_cap + 511) / 512, 256, 0, st>>>(P, n_cap, G.emit(), order, G.offsets(),
                                                                     (uint32_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev,
                                                                     drop_dead ? 1 : 0, ng_dev);
   }
@@ -393,11 +396,14 @@ static int rasterize_backward_impl(int P, int D, int M, int R, const float* back
   { PROF(K_PREPROCESS_BWD);
   preprocess_bwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, radii, cov3D_precomp ? nullptr : scales, rotations,
                                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
-                                                     tan_fovx, tan_fovy, G.gacc(), G.rec(), (float)width, (float)height, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                                                     dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, shs, D, M, campos, G.clamped(), dL_dsh,
-                                                     self_clean ? 1 : 0);
+                                                     tan_fovx, tan_fovy, G.gacc(), G.emit(), (float)width, (float)height, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                                                     dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, self_clean ? 1 : 0);
   }
   LAUNCH_TRY("preprocess_bwd_kernel");
+  if (shs) {   // SH colour branch (off the live SEGS-SLAM path): its own pass over the summed dL/dcolor
+    sh_backward_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, radii, shs, D, M, campos, G.clamped(), dL_dcolor, dL_dmean3D, dL_dsh);
+    LAUNCH_TRY("sh_backward_kernel");
+  }
   return SEGS_OK;
 }
 
@@ -508,7 +514,7 @@ int segs_debug_preprocess_backward(int P, int width, int height, const float* me
                                                          scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
                                                          tan_fovx, tan_fovy, nullptr, nullptr, (float)width, (float)height, const_cast<float*>(dL_dmean2D),
                                                          const_cast<float*>(dL_dconic), nullptr, nullptr, dL_dmean3D, dL_dcov3D,
-                                                         dL_dscale, dL_drot, nullptr, 0, 0, nullptr, nullptr, nullptr, 0);
+                                                         dL_dscale, dL_drot, 0);
   LAUNCH_TRY("preprocess_bwd_kernel");
   return SEGS_OK;
 }

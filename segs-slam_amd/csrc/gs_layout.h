@@ -30,6 +30,12 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr int REC_DWORDS = 16;
 enum RecField { REC_X = 0, REC_Y, REC_A2, REC_B2, REC_C2, REC_O, REC_R, REC_G, REC_B, REC_CA, REC_CB, REC_CC, REC_DEPTH };
 
+// Per-Gaussian EMIT record, 8 dwords = 32 B (written for binned Gaussians only): what the instance emitter and the
+// per-Gaussian backward gather by index -- one 32-byte access instead of a 16-byte Bin record plus a 64-byte render record:
+//  [0] x  [1] y  [2] A  [3] B   [4] C  [5] opacity  [6] rect_min (x | y << 16)  [7] rect_max (x | y << 16)
+// (A, B, C = the conic as the reference stores it, conic_opacity.xyz)
+constexpr int EMIT_DWORDS = 8;
+
 // Per-Gaussian bin record (uint4): depth bits, rect_min (x | y<<16), rect_max (x | y<<16), tiles_touched.
 struct BinInfo { uint32_t depth_bits, rect_min, rect_max, tiles_touched; };
 // The instance emitter (K7) tags each (Gaussian, tile) instance with a 4-bit mask of the 8x8 quadrants of the tile
@@ -49,7 +55,7 @@ constexpr size_t ALIGN = 256;
 inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
-  size_t rec, bin, offsets, radii_internal, block_sums, clamped, num_rendered, gacc, touched, total;
+  size_t rec, bin, offsets, radii_internal, block_sums, clamped, num_rendered, gacc, touched, emit, total;
   int P, nblocks;
 };
 // Mirrors GeometryState::fromChunk (rasterizer_impl.cu:155-170) in role, not in layout.
@@ -67,6 +73,7 @@ inline GeomLayout geom_layout(int P) {
   g.num_rendered = o;   o = align_up(o + 64);
   g.gacc = o;           o = align_up(o + (size_t)P * GACC_DWORDS * 4);
   g.touched = o;        o = align_up(o + (size_t)P * 4);  // tiles_touched once more, dense: the depth-ordered prefix gathers 4 B, not a 16-B BinInfo
+  g.emit = o;           o = align_up(o + (size_t)P * EMIT_DWORDS * 4);
   g.total = o + ALIGN;  // slack so the base pointer can be aligned up
   return g;
 }

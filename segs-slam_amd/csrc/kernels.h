@@ -20,7 +20,8 @@ __global__ void preprocess_fwd_kernel(
     int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
     uint32_t* __restrict__ depth_range, const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos,
     uint32_t* __restrict__ clamped, uint32_t flags, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ depth_vals,
-    uint2* __restrict__ ranges, int num_tiles, uint32_t* __restrict__ depth_overflow, uint32_t* __restrict__ touched_dense);
+    uint2* __restrict__ ranges, int num_tiles, uint32_t* __restrict__ depth_overflow, uint32_t* __restrict__ touched_dense,
+    float* __restrict__ emit);
 // Resident depth sort: every binned Gaussian has view depth > 0.2 (auxiliary.h:155), so its float bits exceed those of
 // 0.2f; 27 bits above that (16 binades: depths below 13 107.2) are sorted in three 9-bit passes.
 constexpr uint32_t DEPTH_KEY_MIN = 0x3E4CCCCDu;   // bits of 0.2f
@@ -39,19 +40,21 @@ __global__ void preprocess_bwd_kernel(
     int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ scales,
     const float* __restrict__ rotations, float mod, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ view, const float* __restrict__ proj, float h_x, float h_y, float tan_fovx, float tan_fovy,
-    float* __restrict__ gacc, const float* __restrict__ rec_in, float img_w, float img_h,
+    float* __restrict__ gacc, const float* __restrict__ emit_in, float img_w, float img_h,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
-    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-    const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, const uint32_t* __restrict__ clamped,
-    float* __restrict__ dL_dsh, int clean_gacc);
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, int clean_gacc);
+__global__ void sh_backward_kernel(int P, const float* __restrict__ means3D, const int* __restrict__ radii,
+                                   const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos,
+                                   const uint32_t* __restrict__ clamped, const float* __restrict__ dL_dcolor,
+                                   float* __restrict__ dL_dmean3D, float* __restrict__ dL_dsh);
 
 // ---- binning.hip
 __global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, const uint32_t* __restrict__ depth_range,
                                        uint32_t* __restrict__ total);
 __global__ void ordered_offsets_kernel(int P, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ incl,
                                        uint32_t* __restrict__ total_out, const uint32_t* __restrict__ ng_dev);
-__global__ void duplicate_with_keys_kernel(int P, int R, const BinInfo* __restrict__ bin, const float* __restrict__ rec,
+__global__ void duplicate_with_keys_kernel(int P, int R, const float* __restrict__ emit,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
                                            const uint32_t* __restrict__ n_dev, int mark_dead, const uint32_t* __restrict__ ng_dev);
@@ -68,7 +71,7 @@ __global__ void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32
                                      uint32_t dmin, int dbits, const uint32_t* __restrict__ tile_prefix, const uint32_t* __restrict__ chunk_prefix,
                                      const uint32_t* __restrict__ digit_totals, int nblocks, int nchunks,
                                      const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out,
-                                     const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out);
+                                     const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits);
 __global__ void identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges,
                                             const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ status,
                                             uint32_t* __restrict__ status_mirror, const uint32_t* __restrict__ n_live);

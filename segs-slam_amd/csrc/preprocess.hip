@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, uint32_t* __restrict__ clamped,
     uint32_t flags, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ depth_vals, uint2* __restrict__ ranges,
     int num_tiles, uint32_t* __restrict__ depth_overflow /* resident: set when a binned depth leaves the 27-bit key range */,
-    uint32_t* __restrict__ touched_dense) {
+    uint32_t* __restrict__ touched_dense, float* __restrict__ emit) {
   __shared__ float lds[768];
   __shared__ uint32_t wave_sums[4], wave_dmax[4], wave_dnmin[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -254,6 +254,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       r4[1] = make_float4((-0.5f * LOG2E) * g.conic.z, op, col.x, col.y);
       r4[2] = make_float4(col.z, g.conic.x, g.conic.y, g.conic.z);
       r4[3] = make_float4(g.depth, 0.f, 0.f, 0.f);
+      float4* e4 = reinterpret_cast<float4*>(emit + (size_t)idx * EMIT_DWORDS);   // gs_layout.h: the emitter's / backward's gather
+      e4[0] = make_float4(g.px, g.py, g.conic.x, g.conic.y);
+      e4[1] = make_float4(g.conic.z, op, __uint_as_float(b.rect_min), __uint_as_float(b.rect_max));
     }
     radii[idx] = g.radius;
     reinterpret_cast<uint4*>(bin)[idx] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
@@ -368,12 +371,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ scales,
     const float* __restrict__ rotations, float mod, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ view, const float* __restrict__ proj, float h_x, float h_y, float tan_fovx, float tan_fovy,
-    float* __restrict__ gacc, const float* __restrict__ rec_in, float img_w, float img_h,
+    float* __restrict__ gacc, const float* __restrict__ emit_in, float img_w, float img_h,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-    const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, const uint32_t* __restrict__ clamped,
-    float* __restrict__ dL_dsh, int clean_gacc /* write zeros back over the consumed accumulator row (resident backward) */) {
+    int clean_gacc /* write zeros back over the consumed accumulator row (resident backward) */) {
   __shared__ float lds[768];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const bool live = idx < P;
@@ -398,10 +400,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
         row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f);
         gacc[(size_t)idx * GACC_DWORDS + 8] = 0.f;
       }
-      const float4 q2 = reinterpret_cast<const float4*>(rec_in + (size_t)idx * REC_DWORDS)[2];  // b, A, B, C
-      const float op = rec_in[(size_t)idx * REC_DWORDS + REC_O];
-      g2x = -(q2.y * a0.x + q2.z * a0.y) * (0.5f * img_w);
-      g2y = -(q2.w * a0.y + q2.z * a0.x) * (0.5f * img_h);
+      const float4 e0 = reinterpret_cast<const float4*>(emit_in + (size_t)idx * EMIT_DWORDS)[0];   // x, y, A, B
+      const float2 e1 = reinterpret_cast<const float2*>(emit_in + (size_t)idx * EMIT_DWORDS)[2];   // C, opacity
+      const float cA = e0.z, cB = e0.w, cC = e1.x, op = e1.y;
+      g2x = -(cA * a0.x + cB * a0.y) * (0.5f * img_w);
+      g2y = -(cC * a0.y + cB * a0.x) * (0.5f * img_h);
       G.xx = -0.5f * a0.z; G.xy = -0.5f * a0.w; G.yy = -0.5f * a1.x;
       dop = a1.y != 0.f ? a1.y / op : 0.f;
       dcol0 = a1.z; dcol1 = a1.w; dcol2 = a8;
@@ -514,10 +517,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
       const float from_proj = (proj[4 * j] * w - proj[4 * j + 3] * ux) * g2x + (proj[4 * j + 1] * w - proj[4 * j + 3] * uy) * g2y;
       out_mean[j] = from_cov + from_proj;
     }
-    if (shs && gacc) {  // backward.cu:390-391 (needs the summed dL_dcolor of this Gaussian)
-      const float3 g = sh::backward(idx, D, M, mean, cam_pos, shs, clamped[idx], make_float3(dcol0, dcol1, dcol2), dL_dsh);
-      out_mean[0] += g.x; out_mean[1] += g.y; out_mean[2] += g.z;
-    }
     // ---- scales and rotation: dL/dL = 2 M2^T (Dc U)
     if (scales) {
       float DU[2][3];
@@ -550,6 +549,21 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     for (int e = 0; e < 6; e++) dL_dcov3D[6 * (size_t)idx + e] = out_cov[e];
   }
   if (dL_drot) reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(out_rot[0], out_rot[1], out_rot[2], out_rot[3]);
+}
+
+// SH colour branch only (callers that pass `shs`; off the live SEGS-SLAM path): dL/dsh and the view-direction term of
+// dL/dmean3D from the summed dL/dcolor (backward.cu:390-391), as a pass of its own so that its tables stay out of the
+// per-Gaussian backward every training step runs.
+__global__ void __launch_bounds__(256) sh_backward_kernel(int P, const float* __restrict__ means3D, const int* __restrict__ radii,
+                                                          const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos,
+                                                          const uint32_t* __restrict__ clamped, const float* __restrict__ dL_dcolor,
+                                                          float* __restrict__ dL_dmean3D, float* __restrict__ dL_dsh) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P || radii[idx] <= 0) return;
+  const float3 mean = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+  const float3 dcol = make_float3(dL_dcolor[3 * (size_t)idx], dL_dcolor[3 * (size_t)idx + 1], dL_dcolor[3 * (size_t)idx + 2]);
+  const float3 g = sh::backward(idx, D, M, mean, cam_pos, shs, clamped[idx], dcol, dL_dsh);
+  dL_dmean3D[3 * (size_t)idx] += g.x; dL_dmean3D[3 * (size_t)idx + 1] += g.y; dL_dmean3D[3 * (size_t)idx + 2] += g.z;
 }
 
 }  // namespace segs
