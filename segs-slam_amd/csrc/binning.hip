@@ -122,7 +122,8 @@ __device__ __forceinline__ uint32_t quadrant_mask(float cx, float cy, float A, f
 // plus an in-workgroup scan.
 __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ incl /* in: tiles_touched in depth order (ordered_block_sums_kernel); out: inclusive offsets */,
                                                               uint32_t* __restrict__ total_out,
-                                                              const uint32_t* __restrict__ ng_dev /* slots that hold a binned Gaussian, or null = P */) {
+                                                              const uint32_t* __restrict__ ng_dev /* slots that hold a binned Gaussian, or null = P */,
+                                                              uint32_t* __restrict__ first_owner, uint32_t owner_entries) {
   // workgroups wholly behind the binned Gaussians have nothing to scan (the emitter never looks there); the last one still
   // reports the total
   if (ng_dev && (uint32_t)blockIdx.x * 256u >= *ng_dev && blockIdx.x != gridDim.x - 1) return;
@@ -137,6 +138,7 @@ __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const uint3
   if (lane == 0) red[wv] = before;
   const int slot = blockIdx.x * 256 + tid;
   uint32_t x = slot < P ? incl[slot] : 0u;
+  const uint32_t t0 = x;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     uint32_t y = __shfl_up(x, off, 64);
@@ -148,44 +150,31 @@ __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const uint3
   for (int w = 0; w < wv; w++) base += wave_tot[w];
   if (slot < P) incl[slot] = base + x;
   if (total_out && blockIdx.x == gridDim.x - 1 && tid == 255) total_out[0] = base + x;   // R = inclusive total
+  // The emitter's workgroup k starts at instance slot k * EMIT_SLOTS: the Gaussian whose range [excl, incl) holds that slot
+  // says so here, which saves the emitter two 64-ary searches (eight dependent loads) per workgroup.
+  if (slot < P && first_owner && t0 != 0u) {
+    const uint32_t v = base + x, excl = v - t0;
+    for (uint32_t k = (excl + EMIT_SLOTS_PER_WG - 1) / EMIT_SLOTS_PER_WG; k * EMIT_SLOTS_PER_WG < v && k < owner_entries; k++)
+      first_owner[k] = (uint32_t)slot;
+  }
 }
 
 // The emitter is parallel over OUTPUT slots, not over Gaussians: workgroup b owns instances [b*512, (b+1)*512) of the
-// unsorted list, finds the Gaussians (in depth order) that own them by binary search in the inclusive offsets, stages
-// those owners once in LDS and lets every lane resolve its slot with an LDS binary search ("load-balanced search").
+// unsorted list, takes the Gaussians (in depth order) that own them from the first_owner table the prefix kernel left
+// (a 64-ary search in the inclusive offsets before: eight dependent loads per workgroup), stages those owners once in LDS
+// and lets every lane resolve its slot with an LDS binary search ("load-balanced search").
 // A Gaussian covering thousands of tiles is thereby spread over many workgroups instead of serialising one wave,
 // and all 12-byte pairs leave as coalesced stores.
 // 512 slots: 25 KB of LDS per workgroup -> 6 workgroups per CU.  1024 slots (49 KB, 3 per CU) left the LDS binary searches
 // without cover: 40 us against 34 us at 2.6 M instances; 256 slots pay the two global owner searches too often (40 us).
-constexpr int EMIT_SLOTS = 512;
-// First index g in [0, n) with a[g] > key (STRICT) or a[g] >= key, n if none; `a` ascending.  64-ary search by one wave:
-// every round the 64 lanes probe 64 evenly spaced elements at once and a ballot picks the segment (4 rounds of one
-// parallel load for n = 500 k instead of 19 dependent loads: the emitter workgroups were latency-bound on this search).
-template <bool STRICT>
-__device__ __forceinline__ int wave_lower_bound(const uint32_t* __restrict__ a, int n, uint32_t key) {
-  const int lane = threadIdx.x & 63;
-  int lo = 0, hi = n;                      // answer in [lo, hi]
-  while (hi - lo > 64) {
-    const int step = (hi - lo + 63) / 64;
-    const int p = min(lo + (lane + 1) * step - 1, hi - 1);
-    const uint32_t v = a[p];
-    const uint64_t m = __ballot(STRICT ? v > key : v >= key);
-    if (m == 0ull) return hi;              // even the last element fails
-    const int f = __ffsll((long long)m) - 1;
-    hi = min(hi, lo + (f + 1) * step - 1); // probe f satisfies the predicate: the answer is at most its index
-    lo = lo + f * step;                    // probe f-1 (index lo + f*step - 1) does not
-  }
-  const int p = lo + lane;
-  const bool ok = p < hi && (STRICT ? a[p] > key : a[p] >= key);
-  const uint64_t m = __ballot(ok);
-  return m ? lo + __ffsll((long long)m) - 1 : hi;
-}
+constexpr int EMIT_SLOTS = EMIT_SLOTS_PER_WG;   // gs_layout.h
 __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     int P, int R, const float* __restrict__ emit /* 32-byte emit records, gs_layout.h */, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ incl, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
     const uint32_t* __restrict__ n_dev /* resident mode: R lives on the device, `R` is the capacity */,
     int mark_dead /* instances that reach no quadrant get DEAD_KEY: the first tile-id pass drops them */,
-    const uint32_t* __restrict__ ng_dev /* resident mode: Gaussians left in `order` after the depth sort dropped the culled ones */) {
+    const uint32_t* __restrict__ ng_dev /* resident mode: Gaussians left in `order` after the depth sort dropped the culled ones */,
+    const uint32_t* __restrict__ first_owner /* ordered_offsets_kernel: owner of slot k * EMIT_SLOTS */) {
   __shared__ uint32_t s_incl[EMIT_SLOTS + 1];
   if (n_dev) R = (int)min(*n_dev, (uint32_t)R);
   if (ng_dev) P = (int)min(*ng_dev, (uint32_t)P);
@@ -196,9 +185,12 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
   const int tid = threadIdx.x;
   const uint32_t s0 = blockIdx.x * EMIT_SLOTS, s1 = min((uint32_t)R, s0 + EMIT_SLOTS);
   if (s0 >= (uint32_t)R) return;
-  // first owner: first g with incl[g] > s0; last owner: first g with incl[g] >= s1   (wave-uniform searches)
-  const int g_lo = wave_lower_bound<true>(incl, P, s0);
-  const int lo = wave_lower_bound<false>(incl, P, s1);
+  // first owner: first g with incl[g] > s0 -- the owner of this workgroup's first slot, left in the table by
+  // ordered_offsets_kernel; last owner: the owner of the NEXT workgroup's first slot can only be the same Gaussian or the one
+  // after the last owner here (every entry ahead of the zero-instance tail owns at least one slot), so it bounds the staging;
+  // the last workgroup stages up to the end.
+  const int g_lo = (int)first_owner[blockIdx.x];
+  const int lo = s1 < (uint32_t)R ? (int)first_owner[blockIdx.x + 1] : P - 1;
   // <= EMIT_SLOTS when every owner has at least one instance in range.  In resident mode a binned Gaussian whose depth key
   // reached the culled key (the step is then flagged through status[2] and redone) can leave zero-instance owners between
   // binned ones: the clamp keeps that flagged launch inside the LDS staging arrays.

@@ -224,6 +224,7 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   const uint32_t* ng_dev = drop_culled ? (const uint32_t*)(gbin + GL.n_live) : nullptr;
   // (2)
   uint32_t* sums2 = (uint32_t*)(bin + GS.block_sums);
+  uint32_t* first_owner = (uint32_t*)(bin + GS.first_owner);
   { PROF(K_SCAN);
   ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.offsets(), nullptr, sums2, G.offsets(), ng_dev);
   }
@@ -231,13 +232,14 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   const int tpasses = (bit + 7) / 8;
   const int side = tpasses & 1;
   { PROF(K_SCAN);
-  ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, sums2, G.offsets(), total_out, ng_dev);
+  ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, sums2, G.offsets(), total_out, ng_dev, first_owner,
+                                                      (uint32_t)(n_cap / EMIT_SLOTS_PER_WG + 2));
   }
   LAUNCH_TRY("ordered_offsets_kernel");
   { PROF(K_DUPLICATE);
-  duplicate_with_keys_kernel<<<(n_cap + 511) / 512, 256, 0, st>>>(P, n_cap, G.emit(), order, G.offsets(),
+  duplicate_with_keys_kernel<<<(n_cap + EMIT_SLOTS_PER_WG - 1) / EMIT_SLOTS_PER_WG, 256, 0, st>>>(P, n_cap, G.emit(), order, G.offsets(),
                                                                     (uint32_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev,
-                                                                    drop_dead ? 1 : 0, ng_dev);
+                                                                    drop_dead ? 1 : 0, ng_dev, first_owner);
   }
   LAUNCH_TRY("duplicate_with_keys_kernel");
   // (3)

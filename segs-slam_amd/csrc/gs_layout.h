@@ -96,6 +96,7 @@ inline ImageLayout image_layout(int W, int H) {
 constexpr int SORT_ITEMS_PER_THREAD = 8;
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_TILE = SORT_ITEMS_PER_THREAD * SORT_THREADS;  // 2048 items per workgroup
+constexpr int EMIT_SLOTS_PER_WG = 512;                            // instance slots per workgroup of duplicate_with_keys_kernel
 constexpr int SORT_COUNT_CHUNK_TILES = 4;                         // tiles per workgroup of radix_count_kernel (binning.hip)
 constexpr int SORT_MAX_DIGITS = 512;                             // count-matrix rows: 8-bit passes use 256 of them, 9-bit passes all
 
@@ -124,7 +125,7 @@ inline BinningLayout binning_layout(int R) {
   return b;
 }
 struct GaussSortLayout {   // appended after the instance-level BinningLayout inside the binning buffer
-  size_t base, block_sums, total;
+  size_t base, block_sums, first_owner, total;   // first_owner: per 512-slot emitter workgroup, the depth-ordered Gaussian owning its first slot
   BinningLayout inner;
 };
 inline GaussSortLayout gauss_sort_layout(int R, int P) {
@@ -132,7 +133,8 @@ inline GaussSortLayout gauss_sort_layout(int R, int P) {
   g.inner = binning_layout(P);
   g.base = align_up(binning_layout(R).total);
   g.block_sums = g.base + align_up(g.inner.total);
-  g.total = g.block_sums + align_up((size_t)((P + 255) / 256 + 4) * 4) + ALIGN;
+  g.first_owner = g.block_sums + align_up((size_t)((P + 255) / 256 + 4) * 4);
+  g.total = g.first_owner + align_up((size_t)(R / EMIT_SLOTS_PER_WG + 4) * 4) + ALIGN;
   return g;
 }
 

@@ -53,11 +53,13 @@ __global__ void sh_backward_kernel(int P, const float* __restrict__ means3D, con
 __global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks, const uint32_t* __restrict__ depth_range,
                                        uint32_t* __restrict__ total);
 __global__ void ordered_offsets_kernel(int P, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ incl,
-                                       uint32_t* __restrict__ total_out, const uint32_t* __restrict__ ng_dev);
+                                       uint32_t* __restrict__ total_out, const uint32_t* __restrict__ ng_dev,
+                                       uint32_t* __restrict__ first_owner, uint32_t owner_entries);
 __global__ void duplicate_with_keys_kernel(int P, int R, const float* __restrict__ emit,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
-                                           const uint32_t* __restrict__ n_dev, int mark_dead, const uint32_t* __restrict__ ng_dev);
+                                           const uint32_t* __restrict__ n_dev, int mark_dead, const uint32_t* __restrict__ ng_dev,
+                                           const uint32_t* __restrict__ first_owner);
 constexpr uint32_t PREPROCESS_TIGHT_RECT = 0x80000000u;   // internal flag bit of preprocess_fwd_kernel (resident forward)
 constexpr uint32_t DEAD_KEY = 0xFFFFFFFFu;   // tile-id key of an instance that reaches no quadrant of its tile
 template <typename K, int BITS>   // K = uint32_t (the pipeline's own sorts) or uint64_t (segs_sort_pairs); BITS per digit: 8 or 9
