@@ -27,6 +27,8 @@
 
 namespace segs {
 
+constexpr int PREFIX_ROWS = PREFIX_ROWS_PER_WG;  // gs_layout.h
+
 // ---------------------------------------------------------------------------------------------
 // K5: exclusive scan of the per-workgroup tiles_touched sums written by preprocess_fwd_kernel.
 // One 1024-thread workgroup; in-place; total (= num_rendered R) to *total.
@@ -124,11 +126,13 @@ __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const uint3
                                                               uint32_t* __restrict__ total_out,
                                                               const uint32_t* __restrict__ ng_dev /* slots that hold a binned Gaussian, or null = P */,
                                                               uint32_t* __restrict__ first_owner, uint32_t owner_entries) {
-  // workgroups wholly behind the binned Gaussians have nothing to scan (the emitter never looks there); the last one still
-  // reports the total
-  if (ng_dev && (uint32_t)blockIdx.x * 256u >= *ng_dev && blockIdx.x != gridDim.x - 1) return;
-  // Every workgroup sums the (unscanned) sums of the workgroups before it on its own -- P/256 values, a few loads per
-  // thread -- instead of a separate single-workgroup scan kernel between the two passes (one launch less).
+  // A workgroup owns PREFIX_ROWS rows of 256 consecutive slots (the same cut as ordered_block_sums_kernel).  Workgroups wholly
+  // behind the binned Gaussians have nothing to scan (the emitter never looks there); the last one still reports the total.
+  const uint32_t slot0 = (uint32_t)blockIdx.x * 256u * PREFIX_ROWS;
+  if (ng_dev && slot0 >= *ng_dev && blockIdx.x != gridDim.x - 1) return;
+  // Every workgroup sums the (unscanned) sums of the workgroups before it on its own -- P/2048 values, a few loads per
+  // thread -- instead of a separate single-workgroup scan kernel between the two passes (one launch less).  (With one sum per
+  // 256 slots these reads were quadratic in earnest: 270 MB of L2 traffic at 3 M Gaussians.)
   __shared__ uint32_t wave_tot[4], red[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   uint32_t before = 0;
@@ -136,27 +140,41 @@ __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const uint3
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off, 64);
   if (lane == 0) red[wv] = before;
-  const int slot = blockIdx.x * 256 + tid;
-  uint32_t x = slot < P ? incl[slot] : 0u;
-  const uint32_t t0 = x;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t y = __shfl_up(x, off, 64);
-    if (lane >= off) x += y;
-  }
-  if (lane == 63) wave_tot[wv] = x;
   __syncthreads();
-  uint32_t base = red[0] + red[1] + red[2] + red[3];
-  for (int w = 0; w < wv; w++) base += wave_tot[w];
-  if (slot < P) incl[slot] = base + x;
-  if (total_out && blockIdx.x == gridDim.x - 1 && tid == 255) total_out[0] = base + x;   // R = inclusive total
-  // The emitter's workgroup k starts at instance slot k * EMIT_SLOTS: the Gaussian whose range [excl, incl) holds that slot
-  // says so here, which saves the emitter two 64-ary searches (eight dependent loads) per workgroup.
-  if (slot < P && first_owner && t0 != 0u) {
-    const uint32_t v = base + x, excl = v - t0;
-    for (uint32_t k = (excl + EMIT_SLOTS_PER_WG - 1) / EMIT_SLOTS_PER_WG; k * EMIT_SLOTS_PER_WG < v && k < owner_entries; k++)
-      first_owner[k] = (uint32_t)slot;
+  uint32_t carry = red[0] + red[1] + red[2] + red[3];
+  uint32_t vals[PREFIX_ROWS];
+#pragma unroll
+  for (int r = 0; r < PREFIX_ROWS; r++) {   // all rows in flight before the first scan
+    const uint32_t slot = slot0 + (uint32_t)r * 256u + tid;
+    vals[r] = slot < (uint32_t)P ? incl[slot] : 0u;
   }
+#pragma unroll
+  for (int r = 0; r < PREFIX_ROWS; r++) {
+    const uint32_t slot = slot0 + (uint32_t)r * 256u + tid;
+    uint32_t x = vals[r];
+    const uint32_t t0 = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) wave_tot[wv] = x;
+    __syncthreads();
+    uint32_t base = carry;
+    for (int w = 0; w < wv; w++) base += wave_tot[w];
+    const uint32_t v = base + x;
+    if (slot < (uint32_t)P) incl[slot] = v;
+    // The emitter's workgroup k starts at instance slot k * EMIT_SLOTS: the Gaussian whose range [excl, incl) holds that slot
+    // says so here, which saves the emitter two 64-ary searches (eight dependent loads) per workgroup.
+    if (slot < (uint32_t)P && first_owner && t0 != 0u) {
+      const uint32_t excl = v - t0;
+      for (uint32_t k = (excl + EMIT_SLOTS_PER_WG - 1) / EMIT_SLOTS_PER_WG; k * EMIT_SLOTS_PER_WG < v && k < owner_entries; k++)
+        first_owner[k] = slot;
+    }
+    carry += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  }
+  if (total_out && blockIdx.x == gridDim.x - 1 && tid == 0) total_out[0] = carry;   // R = inclusive total
 }
 
 // The emitter is parallel over OUTPUT slots, not over Gaussians: workgroup b owns instances [b*512, (b+1)*512) of the
@@ -595,10 +613,15 @@ __global__ void __launch_bounds__(256) ordered_block_sums_kernel(int P, const ui
                                                                  uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched,
                                                                  const uint32_t* __restrict__ ng_dev /* entries of `order` that are valid, or null = P */) {
   __shared__ uint32_t wave_sums[4];
-  const int slot = blockIdx.x * 256 + threadIdx.x;
   const int ng = ng_dev ? (int)min(*ng_dev, (uint32_t)P) : P;
-  uint32_t s = slot < ng ? (order ? touched[order[slot]] : touched[slot]) : 0u;
-  if (slot < P) sorted_touched[slot] = s;
+  uint32_t s = 0;
+#pragma unroll
+  for (int r = 0; r < PREFIX_ROWS; r++) {   // PREFIX_ROWS rows of 256 slots per workgroup (ordered_offsets_kernel's cut)
+    const int slot = (blockIdx.x * PREFIX_ROWS + r) * 256 + threadIdx.x;
+    const uint32_t v = slot < ng ? (order ? touched[order[slot]] : touched[slot]) : 0u;
+    if (slot < P) sorted_touched[slot] = v;
+    s += v;
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = s;

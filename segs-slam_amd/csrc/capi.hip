@@ -225,14 +225,15 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   // (2)
   uint32_t* sums2 = (uint32_t*)(bin + GS.block_sums);
   uint32_t* first_owner = (uint32_t*)(bin + GS.first_owner);
+  const int prefix_wgs = (P + 256 * PREFIX_ROWS_PER_WG - 1) / (256 * PREFIX_ROWS_PER_WG);
   { PROF(K_SCAN);
-  ordered_block_sums_kernel<<<G.L.nblocks, 256, 0, st>>>(P, G.offsets(), nullptr, sums2, G.offsets(), ng_dev);
+  ordered_block_sums_kernel<<<prefix_wgs, 256, 0, st>>>(P, G.offsets(), nullptr, sums2, G.offsets(), ng_dev);
   }
   LAUNCH_TRY("ordered_block_sums_kernel");
   const int tpasses = (bit + 7) / 8;
   const int side = tpasses & 1;
   { PROF(K_SCAN);
-  ordered_offsets_kernel<<<G.L.nblocks, 256, 0, st>>>(P, sums2, G.offsets(), total_out, ng_dev, first_owner,
+  ordered_offsets_kernel<<<prefix_wgs, 256, 0, st>>>(P, sums2, G.offsets(), total_out, ng_dev, first_owner,
                                                       (uint32_t)(n_cap / EMIT_SLOTS_PER_WG + 2));
   }
   LAUNCH_TRY("ordered_offsets_kernel");
