@@ -32,14 +32,15 @@ LIVE_EVENT_KERNELS = ("render_bwd_kernel", "render_fwd_kernel", "preprocess_bwd_
 
 def algorithmic_bytes(P, P_vis, R, W, H, passes_depth, passes_tile):
     """algorithmic bytes per kernel of one fwd+bwd raster over R instances.  The sort line is this
-    design's two-level sort (P depth keys, then R tile keys; per pass: count reads the key, scatter reads and writes the
-    key+value pair), which moves fewer bytes than the reference's (8+24*passes)*R single 64-bit sort."""
+    design's two-level sort (P depth keys, then R tile keys, both 32-bit: per pass the count reads the 4-byte key, the
+    scatter reads and writes the 8-byte key+value pair = 20 B per key and pass), which moves far fewer bytes than the
+    reference's (8+24*passes)*R single 64-bit sort."""
     T = ((W + 15) // 16) * ((H + 15) // 16)
     return {
         "preprocess_fwd_kernel": 104 * P_vis + 8 * (P - P_vis),
         "scan_block_sums_kernel": 8 * P,
         "duplicate_with_keys_kernel": 20 * P + 12 * R,
-        "radix_sort(all passes)": 32 * (passes_depth * P + passes_tile * R),
+        "radix_sort(all passes)": 20 * (passes_depth * P + passes_tile * R),
         "identify_tile_ranges_kernel": 8 * R + 8 * T,
         "render_fwd_kernel": 40 * R + 20 * W * H,
         "render_bwd_kernel": 40 * R + 20 * W * H + 36 * R,
