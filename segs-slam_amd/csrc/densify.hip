@@ -127,10 +127,34 @@ __global__ void __launch_bounds__(256) scan_block_sums(int n, const uint32_t* __
   __syncthreads();
   if (threadIdx.x == 0) sums[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
 }
-__global__ void __launch_bounds__(1) scan_sums_serial(int nblocks, uint32_t* __restrict__ sums, int* __restrict__ total) {
-  uint32_t run = 0;
-  for (int b = 0; b < nblocks; b++) { const uint32_t v = sums[b]; sums[b] = run; run += v; }
-  *total = (int)run;
+// exclusive scan of the per-tile sums by ONE workgroup: 1024 entries per round, wave scans + a carry (n candidates / 1024
+// tiles: 2 900 entries for 3 M candidate slots; a single thread walked them one dependent load at a time)
+__global__ void __launch_bounds__(1024) scan_sums_kernel(int nblocks, uint32_t* __restrict__ sums, int* __restrict__ total) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = i < nblocks ? sums[i] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[wv] = x;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wv; w++) wbase += wave_tot[w];
+    const uint32_t carry = carry_s;
+    if (i < nblocks) sums[i] = carry + wbase + x - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + x;
+    __syncthreads();
+  }
+  if (tid == 0) *total = (int)carry_s;
 }
 __global__ void __launch_bounds__(256) scan_apply(int n, const uint32_t* __restrict__ in, const uint32_t* __restrict__ sums,
                                                   uint32_t* __restrict__ out) {
@@ -267,7 +291,7 @@ int segs_anchor_growing_level(int A, int A_init, int n_offsets, int feat_dim, co
   survive_flags_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, T.ckeys, A, T.akeys, T.flags);
   const int nblk = (n + SCAN_TILE - 1) / SCAN_TILE;
   scan_block_sums<<<nblk, 256, 0, st>>>(n, T.flags, T.sums);
-  scan_sums_serial<<<1, 1, 0, st>>>(nblk, T.sums, n_new);
+  scan_sums_kernel<<<1, 1024, 0, st>>>(nblk, T.sums, n_new);
   scan_apply<<<nblk, 256, 0, st>>>(n, T.flags, T.sums, T.excl);
   compact_heads_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, T.flags, T.excl, T.head_pos);
   const int cap = n < max_new ? n : max_new;

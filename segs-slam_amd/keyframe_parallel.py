@@ -79,15 +79,26 @@ class BucketExchange:
 
     # ---- flag
     def reduce_flag_async(self, local_flag: Optional[torch.Tensor]):
-        """Start the all-reduce of this step's overflow word (a 1-element int32 device tensor, or None for 0)."""
+        """Start the all-reduce of this step's overflow word (a 1-element int32 device tensor, or None for 0).  With one rank
+        the word itself is the guard: no copy, no launch."""
+        if self.world == 1:
+            self._local = local_flag
+            return
         if local_flag is None:
             self.flag.zero_()
         else:
             self.flag.copy_(local_flag.reshape(1))
-        self._flag_work = dist.all_reduce(self.flag, group=self.pg, async_op=True) if self.world > 1 else None
+        self._flag_work = dist.all_reduce(self.flag, group=self.pg, async_op=True)
 
     def wait_flag(self) -> torch.Tensor:
         """Make the current stream wait for the flag; returns the device word (non-zero: some rank's pass is invalid)."""
+        if self.world == 1:
+            if getattr(self, "_local", None) is not None:
+                return self._local
+            if not getattr(self, "_zeroed", False):     # (the buffer is never written with one rank)
+                self.flag.zero_()
+                self._zeroed = True
+            return self.flag
         if self._flag_work is not None:
             self._flag_work.wait()
             self._flag_work = None
