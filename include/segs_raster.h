@@ -123,6 +123,9 @@ int segs_debug_unpack_geometry(const char* geom_buffer, int P, const int* radii,
                                uint32_t* point_offsets /*P*/, float* rgb /*P,3*/, void* stream);
 int segs_debug_unpack_binning(const char* binning_buffer, const char* geom_buffer, int P, int R, int width, int height,
                               uint64_t* keys_sorted /*R*/, uint32_t* point_list /*R*/, void* stream);
+/* The sorted instance values as the tile kernels read them: Gaussian index | (quadrants of the 16x16 tile this instance can
+ * reach) << 28 (no reference counterpart; used by tools/tile_stats.py to measure what the tile kernels iterate over). */
+int segs_debug_instance_values(const char* binning_buffer, int R, uint32_t* values /*R*/, void* stream);
 int segs_debug_unpack_image(const char* image_buffer, int width, int height, uint32_t* ranges /*tiles,2*/,
                             float* final_T /*H*W*/, uint32_t* n_contrib /*H*W*/, void* stream);
 

@@ -58,6 +58,7 @@ SYMBOLS = {
     "segs_project2_image": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i,
                                   _vp, _vp, _vp, _vp]),
     "segs_debug_unpack_geometry": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "segs_debug_instance_values": (_i, [_vp, _i, _vp, _vp]),
     "segs_debug_unpack_binning": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "segs_debug_unpack_image": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "segs_debug_preprocess_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp,

@@ -509,7 +509,15 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const int lp = r * SORT_THREADS + tid;
     if (lp < nout) {
       const K k = s_keys[lp];
+#ifdef ABLATE_SCATTER_LINEAR   // measurement only (tools/ubench_sort_passes.hip): full-line stores, wrong order
+      const size_t gp = tile_base + (size_t)lp + (size_t)(gdelta[digit_of<BITS>(k, shift, km)] & 0);
+#else
       const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of<BITS>(k, shift, km)]);
+#endif
+#ifdef ABLATE_SCATTER_NO_STORE
+      if (k == (K)0x12345677 && gp == 77) keys_out[gp] = k;
+      continue;
+#endif
       keys_out[gp] = k;
       vals_out[gp] = s_vals[lp];
       if (AUX) aux_out[gp] = s_aux[lp];

@@ -490,6 +490,14 @@ int segs_debug_unpack_binning(const char* binning_buffer, const char* geom_buffe
   return SEGS_OK;
 }
 
+int segs_debug_instance_values(const char* binning_buffer, int R, uint32_t* values, void* stream) {
+  if (R <= 0) return SEGS_OK;
+  if (!binning_buffer || !values) return fail(SEGS_ERR_INVALID_ARGUMENT, "null pointer");
+  const BinningLayout BL = binning_layout(R);
+  HIP_TRY(hipMemcpyAsync(values, align_ptr(binning_buffer) + BL.vals[0], (size_t)R * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return SEGS_OK;
+}
+
 int segs_debug_unpack_image(const char* image_buffer, int width, int height, uint32_t* ranges, float* final_T,
                             uint32_t* n_contrib, void* stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -93,7 +93,10 @@ inline ImageLayout image_layout(int W, int H) {
   return l;
 }
 
-constexpr int SORT_ITEMS_PER_THREAD = 8;
+#ifndef SEGS_SORT_ITEMS_PER_THREAD
+#define SEGS_SORT_ITEMS_PER_THREAD 8
+#endif
+constexpr int SORT_ITEMS_PER_THREAD = SEGS_SORT_ITEMS_PER_THREAD;
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_TILE = SORT_ITEMS_PER_THREAD * SORT_THREADS;  // 2048 items per workgroup
 constexpr int PREFIX_ROWS_PER_WG = 8;                             // 256-slot rows per workgroup of the depth-ordered prefix kernels

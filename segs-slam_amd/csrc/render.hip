@@ -354,12 +354,19 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
       r0 = p[0]; r1 = p[1]; rb = reinterpret_cast<const float*>(p)[8];
     }
   }
-  for (int32_t cbase = cfirst; cbase >= 0; cbase -= 64) {
-    const int n = __builtin_amdgcn_readfirstlane(cc.n);
+  // Batches of BW_SLOTS entries are cut from the STREAM of compacted entries, not from each 64-entry chunk: what a chunk
+  // leaves over (fewer than BW_SLOTS records) stays staged in L.rec and the next chunk tops it up, so both roles always
+  // run on full batches (at 3 M Gaussians a chunk holds ~18 entries of this quadrant: per-chunk batches were 58 % full).
+  // One more pass of the loop after the last chunk (tail) flushes the final partial batch.
+  float (*mom)[12] = reinterpret_cast<float (*)[12]>(&L.at[0][0]);
+  int fill = 0;   // records staged in L.rec, wave-uniform
+  for (int32_t cbase = cfirst;; cbase -= 64) {
+    const bool tail = cbase < 0;
+    const int n = tail ? 0 : __builtin_amdgcn_readfirstlane(cc.n);
     // current chunk's records stay in registers (one per lane, compacted order); the next chunk's go in flight
     const float4 c0 = r0, c1 = r1;
     const float4 c2 = make_float4(rb, __uint_as_float((uint32_t)cbase + cc.pos), __uint_as_float(cc.val & ID_MASK), 0.f);
-    {
+    if (cbase >= 64) {
       uint32_t v_nn = 0u;
       if (cbase >= 128) v_nn = point_list[range.x + (uint32_t)(cbase - 128) + lane];
       cc = compact_chunk<true>(v_nxt, qbit, lane);
@@ -369,19 +376,24 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
       }
       v_nxt = v_nn;
     }
-    float (*mom)[12] = reinterpret_cast<float (*)[12]>(&L.at[0][0]);
-    for (int b0 = 0; b0 < n; b0 += BW_SLOTS) {
-      const int nb = __builtin_amdgcn_readfirstlane(min(BW_SLOTS, n - b0));
-      if (lane >= b0 && lane < b0 + nb) {
-        L.rec[lane - b0][0] = c0; L.rec[lane - b0][1] = c1; L.rec[lane - b0][2] = c2;
+    int taken = 0;
+    do {
+      const int take = min(BW_SLOTS - fill, n - taken);
+      if (lane >= taken && lane < taken + take) {
+        const int s = fill + lane - taken;
+        L.rec[s][0] = c0; L.rec[s][1] = c1; L.rec[s][2] = c2;
       }
+      fill += take; taken += take;
+      if (fill < BW_SLOTS && !(tail && fill > 0)) continue;   // batch not full yet: the next chunk tops it up
+      const int nb = fill;
+      fill = 0;
       wave_lds_fence();
       // ---------------- (1) pixel role
       if (use_bg) pixel_role<true>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, accd);
       else pixel_role<false>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, accd);
       wave_lds_fence();
 #ifdef ABLATE_NO_GAUSS_ROLE
-      continue;
+      continue;   // (the do-while's condition is evaluated)
 #endif
       // ---------------- (2) Gaussian role: lane = (part, gs): slot gs, pixels part*16 .. part*16+15
       // Moments are taken about the quadrant pixel NEAREST to the Gaussian's centre (cx, cy in 0..7), not about the
@@ -452,7 +464,8 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(
         }
       }
       wave_lds_fence();
-    }
+    } while (taken < n);
+    if (tail) break;
   }
 }
 
