@@ -457,20 +457,64 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
   if (threadIdx.x == 0 && blk_kept) atomicAdd(n_kept, blk_kept);
 }
 
-// End of one MLP in the backward pass: relu mask on dH = W2^T dOUT (accumulated tile by tile), H and dHpre to the
-// scratch row, dX (inputs 0..31) on the matrix cores and the view/dist tail on the VALU.
+// ---- weight gradients inside the backward kernel ---------------------------------------------------------------
+// dW[j][i] = sum_anchors dpre[a][j] act[a][i] contracts over the anchors, which the MLP chain keeps on the LANES; the matrix
+// cores contract over k.  So every operand of a weight-gradient product goes once through a per-wave LDS tile
+// T[anchor][unit] (row stride TS floats: conflict-free 16-byte writes from the chain's register layout, conflict-free
+// dword reads in the transposed one) and comes back as lane = unit, k = anchor: 16 v_mfma_f32_32x32x2_f32 per 32x32 tile
+// of dW and slab of 32 anchors, accumulated in registers over all the slabs of the wave (8 tiles = 128 accumulator
+// registers: the kernel runs one wave per SIMD with the 512-register budget).  The previous design wrote every
+// activation and pre-activation gradient to a 2-KB scratch row per anchor for a separate kernel: 0.6 GB written and 0.55 GB
+// read back per step at 300 k anchors, more than everything else the backward touches.
+constexpr int TS = 36;                       // floats per anchor row of a transposition tile
+constexpr int T_TILE = 32 * TS;
+constexpr int WAVE_LDS = 3 * T_TILE + 32 * 4;   // X | H | D | tail(view xyz, dist), floats per wave
+constexpr int BWD_GRID = 256;                // one workgroup per CU; also the number of partial tiles per job
+static_assert(BWD_GRID == WG_WAVES, "the fused backward's partial tiles reuse the per-wave slots of the reduce kernel");
+constexpr int N_SMALL = 20;                  // per-lane scalar accumulators: 5 + 3 bias sums, 3 x 4 tail columns
+
+__device__ __forceinline__ void put_tile(float* __restrict__ buf, int col, int h, const f32x16& v) {
+#pragma unroll
+  for (int g = 0; g < 4; g++)    // registers 4g..4g+3 are units 8g + 4h .. + 3
+    *reinterpret_cast<float4*>(buf + col * TS + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+// acc[i][j] += sum_a A[a][i] B[a][j] over the slab's 32 anchors; asum += this lane's column of A (bias gradient of unit i,
+// half of the anchors per lane half)
+__device__ __forceinline__ void wgrad_chain(const float* __restrict__ bufA, const float* __restrict__ bufB, int lane, f32x16& acc,
+                                            float& asum) {
+  const float* pa = bufA + (lane >> 5) * TS + (lane & 31);
+  const float* pb = bufB + (lane >> 5) * TS + (lane & 31);
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const float av = pa[2 * s * TS], bv = pb[2 * s * TS];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    asum += av;
+  }
+}
+// the same for a first layer: B = the 32 features; the four tail inputs (view xyz, dist) are too few for a tile of their
+// own and are accumulated on the VALU from the A values that are in registers anyway
+__device__ __forceinline__ void wgrad_chain_tail(const float* __restrict__ bufA, const float* __restrict__ bufB,
+                                                 const float* __restrict__ bufT, int lane, f32x16& acc, float& asum, float* tl) {
+  const int half = lane >> 5;
+  const float* pa = bufA + half * TS + (lane & 31);
+  const float* pb = bufB + half * TS + (lane & 31);
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const float av = pa[2 * s * TS], bv = pb[2 * s * TS];
+    const float4 t = *reinterpret_cast<const float4*>(bufT + (2 * s + half) * 4);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    asum += av;
+    tl[0] += av * t.x; tl[1] += av * t.y; tl[2] += av * t.z; tl[3] += av * t.w;
+  }
+}
+
+// End of one MLP in the backward pass: relu mask on dH = W2^T dOUT (accumulated tile by tile), dX (inputs 0..31) on the
+// matrix cores and the view/dist tail on the VALU; dHpre goes to the wave's D tile for the first layer's weight gradient.
 __device__ __forceinline__ void finish_mlp(const float* __restrict__ img, const Small& S, int m, int lane, int h, const f32x16& hpre,
-                                           f32x16& dh, f32x16& dx, float* dtail, float* __restrict__ row, bool valid) {
+                                           f32x16& dh, f32x16& dx, float* dtail, float* __restrict__ bufD) {
 #pragma unroll
   for (int r = 0; r < 16; r++) dh[r] = hpre[r] > 0.f ? dh[r] : 0.f;
-  if (valid) {
-#pragma unroll
-    for (int g = 0; g < 4; g++) {    // registers 4g..4g+3 are hidden units 8g + 4h .. + 3
-      *reinterpret_cast<float4*>(row + R_H + FD * m + 8 * g + 4 * h) =
-          make_float4(fmaxf(hpre[4 * g], 0.f), fmaxf(hpre[4 * g + 1], 0.f), fmaxf(hpre[4 * g + 2], 0.f), fmaxf(hpre[4 * g + 3], 0.f));
-      *reinterpret_cast<float4*>(row + R_DH + FD * m + 8 * g + 4 * h) = make_float4(dh[4 * g], dh[4 * g + 1], dh[4 * g + 2], dh[4 * g + 3]);
-    }
-  }
+  put_tile(bufD, lane & 31, h, dh);
   const float* im = img + (I_DX + m * 16) * 64 + lane;
 #pragma unroll
   for (int s = 0; s < 16; s++) dx = __builtin_amdgcn_mfma_f32_32x32x2f32(im[s * 64], dh[s], dx, 0, 0, 0);
@@ -481,14 +525,16 @@ __device__ __forceinline__ void finish_mlp(const float* __restrict__ img, const 
   }
 }
 
-__global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
+__device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }
+
+__global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
     Layout L, const uint32_t* __restrict__ count, const uint32_t* __restrict__ vis, const float* __restrict__ anchor,
     const float* __restrict__ offset, const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
     const float* __restrict__ g_img, const Small* __restrict__ g_small, const float* __restrict__ campos,
     const float* __restrict__ g_means, const float* __restrict__ g_colors, const float* __restrict__ g_opacity,
     const float* __restrict__ g_scales, const float* __restrict__ g_rot, float* __restrict__ d_anchor,
     float* __restrict__ d_offset, float* __restrict__ d_feat, float* __restrict__ d_scaling_log, float* __restrict__ rows,
-    float reg_weight, float* __restrict__ reg_sum) {
+    float* __restrict__ partial, float reg_weight, float* __restrict__ reg_sum) {
   extern __shared__ __align__(16) float lds_dyn[];
   float* img = lds_dyn;
   Small& S = *reinterpret_cast<Small*>(lds_dyn + N_IMG_BWD * 64);
@@ -497,6 +543,20 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
   stage_tables(img, S, N_IMG_BWD, g_img, g_small);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
+  float* const bufX = lds_dyn + N_IMG_BWD * 64 + sizeof(Small) / 4 + wv * WAVE_LDS;
+  float* const bufH = bufX + T_TILE;
+  float* const bufD = bufH + T_TILE;
+  float* const bufT = bufD + T_TILE;
+  // weight-gradient accumulators of this wave: second layers per output tile, first layers per MLP (feature columns)
+  f32x16 aW2_0, aW2_1, aW2_2, aW2_3, aW2_4, aW1_0, aW1_1, aW1_2;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    aW2_0[r] = 0.f; aW2_1[r] = 0.f; aW2_2[r] = 0.f; aW2_3[r] = 0.f; aW2_4[r] = 0.f; aW1_0[r] = 0.f; aW1_1[r] = 0.f; aW1_2[r] = 0.f;
+  }
+  float sm[N_SMALL];    // [0..4] bias sums of the output tiles, [5..7] of the hidden layers, [8 + 4m + c] tail column c of MLP m
+#pragma unroll
+  for (int q = 0; q < N_SMALL; q++) sm[q] = 0.f;
+
   for (uint32_t g0 = (blockIdx.x * 4u + wv) * 32u; g0 < n; g0 += gridDim.x * 128u) {
     const uint32_t t = g0 + col;
     const bool valid = t < n;
@@ -504,7 +564,12 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
     float* row = rows + (size_t)(valid ? t : 0) * ROW;
     AnchorLane st;
     anchor_lane(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
-    if (valid) stn<L1_STEPS>(row + R_X + L1_STEPS * h, st.xo);
+    if (valid && L.bank) stn<L1_STEPS>(row + R_X + L1_STEPS * h, st.xo);   // the feature bank's Linear(4 -> 32) reads view, dist
+    // X tile: unit 16 h + s holds input 2 s + h (this half's 16 features in one contiguous run); tail as one float4 per anchor
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+      *reinterpret_cast<float4*>(bufX + col * TS + 16 * h + 4 * g) = make_float4(st.xo[4 * g], st.xo[4 * g + 1], st.xo[4 * g + 2], st.xo[4 * g + 3]);
+    if (h == 0) *reinterpret_cast<float4*>(bufT + col * 4) = make_float4(st.view[0], st.view[1], st.view[2], st.dist);
     const size_t c0 = (size_t)a * NO + 5 * h;
     f32x16 dx;
 #pragma unroll
@@ -524,9 +589,14 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
         hp = layer1(img, S, m, lane, h, st.xo);
 #pragma unroll
         for (int r = 0; r < 16; r++) dh[r] = 0.f;
+        f32x16 hr;
+#pragma unroll
+        for (int r = 0; r < 16; r++) hr[r] = fmaxf(hp[r], 0.f);
+        put_tile(bufH, col, h, hr);
       }
       f32x16 o = layer2(img, S, tile, lane, h, hp);
-      // ---- element-wise: outputs -> dL/d(output pre-activation), in place
+      // ---- element-wise: outputs -> dL/d(output pre-activation), in place (zero for the padding lanes of the last slab:
+      // they carry a copy of the last anchor and must not reach the weight gradients)
       if (tile == 0) {
         float g[5], d[5];
         ldn<5>(g_opacity + c0, g);
@@ -536,9 +606,8 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
           d[r] = 0.f;
           if (op > 0.f) { keep |= 1u << r; d[r] = g[r] * (1.f - op * op); }
         }
-        if (valid) stn<5>(row + R_DO + 8 * h, d);
 #pragma unroll
-        for (int r = 0; r < 16; r++) o[r] = r < 5 ? d[r] : 0.f;
+        for (int r = 0; r < 16; r++) o[r] = (r < 5 && valid) ? d[r < 5 ? r : 0] : 0.f;
       } else if (tile == 1) {
         float g[15], d[15];
         ldn<15>(g_colors + c0 * 3, g);
@@ -547,9 +616,8 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
           const float colv = sigmoidf(o[r]);
           d[r] = ((keep >> (r / 3)) & 1u) ? g[r] * colv * (1.f - colv) : 0.f;
         }
-        if (valid) stn<15>(row + R_DK + 16 * h, d);
 #pragma unroll
-        for (int r = 0; r < 16; r++) o[r] = r < 15 ? d[r] : 0.f;
+        for (int r = 0; r < 16; r++) o[r] = (r < 15 && valid) ? d[r < 15 ? r : 0] : 0.f;
       } else {
 #pragma unroll
         for (int cl = 0; cl < 2; cl++) {
@@ -590,28 +658,45 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
               dsr[3] = gr.x * 1e12f; dsr[4] = gr.y * 1e12f; dsr[5] = gr.z * 1e12f; dsr[6] = gr.w * 1e12f;
             }
           }
-          if (valid && cc < 5) {
-            if (on) {   // masked-out candidates add nothing
-              float cur[3];
-              ldn<3>(d_offset + (c0 + cc) * 3, cur);
+          if (valid && on) {   // masked-out candidates add nothing
+            float cur[3];
+            ldn<3>(d_offset + (c0 + cc) * 3, cur);
 #pragma unroll
-              for (int c = 0; c < 3; c++) cur[c] += doff[c];
-              stn<3>(d_offset + (c0 + cc) * 3, cur);
-            }
-            stn<7>(row + R_DC + 36 * h + 7 * cc, dsr);
+            for (int c = 0; c < 3; c++) cur[c] += doff[c];
+            stn<3>(d_offset + (c0 + cc) * 3, cur);
           }
 #pragma unroll
-          for (int q = 0; q < 7; q++) o[7 * cl + q] = dsr[q];
+          for (int q = 0; q < 7; q++) o[7 * cl + q] = valid ? dsr[q] : 0.f;
         }
         o[14] = 0.f; o[15] = 0.f;
       }
+      // ---- second-layer weight gradient of this tile: dOUT tile x H of the MLP
+      put_tile(bufD, col, h, o);
+      lds_fence();
+      switch (tile) {    // wave-uniform; keeps every accumulator in statically named registers
+        case 0: wgrad_chain(bufD, bufH, lane, aW2_0, sm[0]); break;
+        case 1: wgrad_chain(bufD, bufH, lane, aW2_1, sm[1]); break;
+        case 2: wgrad_chain(bufD, bufH, lane, aW2_2, sm[2]); break;
+        case 3: wgrad_chain(bufD, bufH, lane, aW2_3, sm[3]); break;
+        default: wgrad_chain(bufD, bufH, lane, aW2_4, sm[4]); break;
+      }
+      lds_fence();
       // ---- dH += W2^T dOUT for this tile
       {
         const float* im = img + (I_DH + tile * 16) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < 16; s++) dh = __builtin_amdgcn_mfma_f32_32x32x2f32(im[s * 64], o[s], dh, 0, 0, 0);
       }
-      if (tile != 2 && tile != 3) finish_mlp(img, S, m, lane, h, hp, dh, dx, dtail, row, valid);
+      if (tile != 2 && tile != 3) {
+        finish_mlp(img, S, m, lane, h, hp, dh, dx, dtail, bufD);
+        lds_fence();
+        switch (m) {   // first-layer weight gradient: dHpre x (features | tail)
+          case 0: wgrad_chain_tail(bufD, bufX, bufT, lane, aW1_0, sm[5], &sm[8]); break;
+          case 1: wgrad_chain_tail(bufD, bufX, bufT, lane, aW1_1, sm[6], &sm[12]); break;
+          default: wgrad_chain_tail(bufD, bufX, bufT, lane, aW1_2, sm[7], &sm[16]); break;
+        }
+        lds_fence();
+      }
     }
     if (reg_sum != nullptr && reg_w != 0.f) {   // sum of prod(scaling) over the kept candidates, for the loss value
       reg_acc = valid ? reg_acc : 0.f;
@@ -702,6 +787,55 @@ __global__ void __launch_bounds__(256, 2) neural_bwd_kernel(
       d_anchor[(size_t)a * 3 + 2] += danc[2] + (dview[2] - vz * dot) * st.inv_dist + dview[3] * vz;
     }
   }
+
+  // ---- the workgroup's weight-gradient partials: the four waves' accumulators summed in a fixed order through LDS (the
+  // operand images are no longer needed), written in wgrad_reduce_kernel's partial-tile layout, slot = workgroup
+  __syncthreads();
+  float* const stage = lds_dyn;                       // [4 waves][max(1024, N_SMALL * 64)] floats
+  constexpr int STAGE = N_SMALL * 64 > 1024 ? N_SMALL * 64 : 1024;
+  const int tid = threadIdx.x;
+  auto slot = [&](int job) { return partial + ((size_t)job * WG_WAVES + blockIdx.x) * WG_TILE; };
+#pragma unroll 1
+  for (int k = 0; k < 8; k++) {
+    f32x16 v;
+    switch (k) {
+      case 0: v = aW2_0; break; case 1: v = aW2_1; break; case 2: v = aW2_2; break; case 3: v = aW2_3; break;
+      case 4: v = aW2_4; break; case 5: v = aW1_0; break; case 6: v = aW1_1; break; default: v = aW1_2; break;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) stage[wv * STAGE + r * 64 + lane] = v[r];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+      const float sum = (stage[e] + stage[STAGE + e]) + (stage[2 * STAGE + e] + stage[3 * STAGE + e]);
+      const int r = e >> 6, l = e & 63, i = rho(r, l >> 5), j = l & 31;   // D[i][j]
+      if (k < 5) {            // second layer, tile k: i = tile row -> output unit, j = hidden unit (the Linear's input)
+        const int o = out_row(k, (i >> 2) & 1, (i & 3) + 4 * (i >> 3));
+        if (o >= 0) slot(3 + tile_mlp(k))[(((o >> 5)) * 32 + j) * 32 + (o & 31)] = sum;
+      } else {                // first layer of MLP k - 5: i = hidden unit, j = feature position 16 (input & 1) + (input >> 1)
+        const int input = 2 * (j & 15) + (j >> 4);
+        slot(k - 5)[(size_t)input * 32 + i] = sum;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < N_SMALL; q++) stage[wv * STAGE + q * 64 + lane] = sm[q];
+  __syncthreads();
+  for (int e = tid; e < N_SMALL * 32; e += 256) {
+    const int q = e >> 5, u = e & 31;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) sum += stage[w * STAGE + q * 64 + u] + stage[w * STAGE + q * 64 + 32 + u];   // both lane halves
+    if (q < 5) {              // bias of output tile q: u = tile row
+      const int o = out_row(q, (u >> 2) & 1, (u & 3) + 4 * (u >> 3));
+      if (o >= 0) slot(3 + tile_mlp(q))[((1 * 3 + (o >> 5)) * 32 + 31) * 32 + (o & 31)] = sum;
+    } else if (q < 8) {       // bias of the hidden layer of MLP q - 5: u = hidden unit
+      slot(q - 5)[((1 * 3 + 0) * 32 + 31) * 32 + u] = sum;
+    } else {                  // tail input 32 + c of MLP (q - 8) / 4
+      const int mm = (q - 8) >> 2, c = (q - 8) & 3;
+      slot(mm)[((1 * 3 + 0) * 32 + c) * 32 + u] = sum;
+    }
+  }
 }
 
 // ---- weight gradients ---------------------------------------------------------------------------------------------
@@ -714,6 +848,8 @@ struct WJob {
   int w_off, ldw;     // dW[j][i] -> gsum[w_off + j*ldw + i]
   int bias_off;       // db[j]   -> gsum[bias_off + j]
   int active;
+  int via_rows;       // 1: partial tiles come from wgrad_mfma_kernel (one per wave, WG_WAVES of them) over the scratch rows;
+                      // 0: from neural_bwd_kernel itself (one per workgroup that had anchors to process)
 };
 struct WJobs { WJob j[WG_JOBS]; };
 
@@ -723,7 +859,7 @@ struct WJobs { WJob j[WG_JOBS]; };
 __global__ void __launch_bounds__(64) wgrad_mfma_kernel(WJobs jobs, const uint32_t* __restrict__ count,
                                                         const float* __restrict__ rows, float* __restrict__ partial) {
   const WJob job = jobs.j[blockIdx.y];
-  if (!job.active) return;
+  if (!job.active || !job.via_rows) return;
   const int lane = threadIdx.x;
   const int c = lane & 31, half = lane >> 5;
   const uint32_t n = *count;
@@ -792,8 +928,8 @@ __global__ void __launch_bounds__(64) wgrad_mfma_kernel(WJobs jobs, const uint32
   }
 }
 
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WJobs jobs, const float* __restrict__ partial, float* __restrict__ gsum,
-                                                           float* __restrict__ dparams) {
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WJobs jobs, const uint32_t* __restrict__ count, const float* __restrict__ partial,
+                                                           float* __restrict__ gsum, float* __restrict__ dparams) {
   // 16 elements x 16 slices of the partial waves per workgroup: every thread has its 16 loads in flight at once (the sum over
   // 256 per-wave partials was a latency-bound chain of load batches: 20 us; the data is only ~10 MB)
   constexpr int SLICES = 16, PER = WG_WAVES / SLICES;
@@ -817,9 +953,11 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WJobs jobs, const flo
     live = o >= 0;
     dst = i < job.M ? job.w_off + o * job.ldw + i : job.bias_off + o;
     const float* p = partial + ((size_t)blockIdx.y * WG_WAVES + q * PER) * WG_TILE + slot;
+    // partial tiles that exist: every wave's for the row-based jobs, one per workgroup of the backward kernel that had a slab
+    const int nparts = job.via_rows ? WG_WAVES : (int)min((uint32_t)BWD_GRID, (count[0] + 127u) / 128u);
     float acc[PER];
 #pragma unroll
-    for (int u = 0; u < PER; u++) acc[u] = p[(size_t)u * WG_TILE];
+    for (int u = 0; u < PER; u++) acc[u] = (q * PER + u < nparts) ? p[(size_t)u * WG_TILE] : 0.f;
 #pragma unroll
     for (int st = PER / 2; st > 0; st >>= 1)
 #pragma unroll
@@ -882,15 +1020,13 @@ __global__ void reg_finish_kernel(const uint32_t* count, float* reg_sum, float w
 
 WJobs make_jobs(const Layout& L) {
   WJobs J;
-  const int nstored[3] = {16, 72, 32};          // opacity, cov, colour: stored (padded) output columns
-  const int per_half[3] = {8, 36, 16}, real_half[3] = {5, 35, 15};
-  const int dout_off[3] = {R_DO, R_DC, R_DK};
-  for (int m = 0; m < 3; m++) {
-    J.j[m] = WJob{R_X, FD + 3 + L.dist[m], 0, R_DH + FD * m, FD, 0, 0, L.w1[m], L.in[m], L.b1[m], 1};
-    J.j[3 + m] = WJob{R_H + FD * m, FD, -1, dout_off[m], nstored[m], per_half[m], real_half[m], L.w2[m], FD, L.b2[m], 1};
+  const int nout[3] = {NO, 7 * NO, 3 * NO};
+  for (int m = 0; m < 3; m++) {   // accumulated inside neural_bwd_kernel: only the shapes and destinations matter here
+    J.j[m] = WJob{0, FD + 3 + L.dist[m], 0, 0, FD, 0, 0, L.w1[m], L.in[m], L.b1[m], 1, 0};
+    J.j[3 + m] = WJob{0, FD, -1, 0, nout[m], 0, 0, L.w2[m], FD, L.b2[m], 1, 0};
   }
-  J.j[6] = WJob{R_X, 4, FD, R_DH + FD * 3, FD, 0, 0, L.fw1, 4, L.fb1, L.bank};
-  J.j[7] = WJob{R_H + FD * 3, FD, -1, R_DF, 3, 0, 0, L.fw2, FD, L.fb2, L.bank};
+  J.j[6] = WJob{R_X, 4, FD, R_DH + FD * 3, FD, 0, 0, L.fw1, 4, L.fb1, L.bank, 1};
+  J.j[7] = WJob{R_H + FD * 3, FD, -1, R_DF, 3, 0, 0, L.fw2, FD, L.fb2, L.bank, 1};
   return J;
 }
 
@@ -955,20 +1091,21 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
     return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   Temp T;
   temp_carve(A, L.total, temp, &T);
-  constexpr size_t bwd_lds = N_IMG_BWD * 64 * sizeof(float) + sizeof(Small);   // > 64 KB: needs the opt-in below
+  constexpr size_t bwd_lds = (N_IMG_BWD * 64 + 4 * WAVE_LDS) * sizeof(float) + sizeof(Small);   // > 64 KB: needs the opt-in below
+  static_assert(bwd_lds <= 160 * 1024, "one workgroup per CU");
   static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
   if (attr_rc != hipSuccess) return segs::set_hip_error(attr_rc, __func__);
   // the regulariser sum was cleared by the forward (pack_tables_kernel) and is cleared again by reg_finish_kernel; it is
   // only accumulated when somebody reads it
   float* reg_sum = scaling_reg_out ? T.gsum + L.total + 8 : nullptr;
-  neural_bwd_kernel<<<NEURAL_GRID, 256, bwd_lds, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
+  neural_bwd_kernel<<<BWD_GRID, 256, bwd_lds, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
                                         camera_center, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor,
-                                        dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, scaling_reg_weight, reg_sum);
+                                        dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, T.partial, scaling_reg_weight, reg_sum);
   if (scaling_reg_out && L.app == 0) reg_finish_kernel<<<1, 1, 0, st>>>(T.count, reg_sum, scaling_reg_weight, scaling_reg_out);
   const WJobs J = make_jobs(L);
-  wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), 64, 0, st>>>(J, T.count, T.rows, T.partial);
-  wgrad_reduce_kernel<<<dim3((37 * 72 + 15) / 16, WG_JOBS), 256, 0, st>>>(J, T.partial, T.gsum, dL_dmlp_params);
+  if (L.bank) wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), 64, 0, st>>>(J, T.count, T.rows, T.partial);   // the feature bank's two small Linears
+  wgrad_reduce_kernel<<<dim3((37 * 72 + 15) / 16, WG_JOBS), 256, 0, st>>>(J, T.count, T.partial, T.gsum, dL_dmlp_params);
   if (L.app > 0) appearance_finish_kernel<<<1, 1024, 0, st>>>(L, mlp_params, pose7, T.gsum, dL_dmlp_params, T.count, reg_sum,
                                                               scaling_reg_weight, scaling_reg_out);
   hipError_t e = hipGetLastError();
