@@ -46,6 +46,7 @@ constexpr int WG_UNROLL = 8;   // row pairs whose operand loads are in flight to
 constexpr int WG_JOBS = 8;
 constexpr int WG_TILE = 2 * 3 * 1024;  // floats of partial sums per (job, wave): up to 2x3 tiles of 32x32
 constexpr int MAX_APP = 64;
+constexpr int MAX_ANCHORS = 8000000;   // 32-bit element offsets: A * ROW and A * 40 stay below 2^32
 
 struct Layout {           // float offsets into the flat parameter block
   int w1[3], b1[3], w2[3], b2[3];
@@ -275,7 +276,7 @@ struct AnchorLane {
 };
 
 __device__ __forceinline__ void load_feat(const float* __restrict__ anchor_feat, uint32_t a, float* f) {
-  const float4* p = reinterpret_cast<const float4*>(anchor_feat + (size_t)a * FD);
+  const float4* p = reinterpret_cast<const float4*>(anchor_feat + a * FD);
 #pragma unroll
   for (int q = 0; q < FD / 4; q++) {
     const float4 v = p[q];
@@ -297,20 +298,21 @@ __device__ __forceinline__ void bank_logits_partial(const Small& S, int h, const
   }
 }
 
+template <bool BANK>
 __device__ __forceinline__ void anchor_lane(const Small& S, const Layout& L, uint32_t a, int h, const float* __restrict__ anchor,
                                             const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
                                             const float* __restrict__ campos, AnchorLane& st) {
   float feat[FD];
   load_feat(anchor_feat, a, feat);
 #pragma unroll
-  for (int c = 0; c < 3; c++) st.anc[c] = anchor[(size_t)a * 3 + c];
+  for (int c = 0; c < 3; c++) st.anc[c] = anchor[a * 3 + c];
 #pragma unroll
-  for (int c = 0; c < 6; c++) st.gs[c] = expf(scaling_log[(size_t)a * 6 + c]);
+  for (int c = 0; c < 6; c++) st.gs[c] = expf(scaling_log[a * 6 + c]);
   const float ox = st.anc[0] - campos[0], oy = st.anc[1] - campos[1], oz = st.anc[2] - campos[2];
   st.dist = sqrtf(ox * ox + oy * oy + oz * oz);
   st.inv_dist = 1.0f / st.dist;
   st.view[0] = ox / st.dist; st.view[1] = oy / st.dist; st.view[2] = oz / st.dist;
-  if (L.bank) {
+  if (BANK) {
     const float cat4[4] = {st.view[0], st.view[1], st.view[2], st.dist};
     float lg[3];
     bank_logits_partial(S, h, cat4, lg);
@@ -406,7 +408,8 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
     const bool valid = t < n;
     const uint32_t a = vis[valid ? t : n - 1];
     AnchorLane st;
-    anchor_lane(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
+    if (L.bank) anchor_lane<true>(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
+    else anchor_lane<false>(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
     const size_t c0 = (size_t)a * NO + 5 * h;     // first candidate of this lane half
     f32x16 hp;
     uint32_t kept = 0;   // candidates of this lane with neural opacity > 0: P of the reference's compacted tensors
@@ -463,7 +466,8 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
 // T[anchor][unit] (row stride TS floats: conflict-free 16-byte writes from the chain's register layout, conflict-free
 // dword reads in the transposed one) and comes back as lane = unit, k = anchor: 16 v_mfma_f32_32x32x2_f32 per 32x32 tile
 // of dW and slab of 32 anchors, accumulated in registers over all the slabs of the wave (8 tiles = 128 accumulator
-// registers: the kernel runs one wave per SIMD with the 512-register budget).  The previous design wrote every
+// registers: the kernel runs one wave per SIMD with the 512-register budget).  The tile pointers are deliberately not
+// __restrict__: the compiler has to keep the order of a wave's LDS stores and the (other lanes') loads that follow.  The previous design wrote every
 // activation and pre-activation gradient to a 2-KB scratch row per anchor for a separate kernel: 0.6 GB written and 0.55 GB
 // read back per step at 300 k anchors, more than everything else the backward touches.
 constexpr int TS = 36;                       // floats per anchor row of a transposition tile
@@ -473,14 +477,14 @@ constexpr int BWD_GRID = 256;                // one workgroup per CU; also the n
 static_assert(BWD_GRID == WG_WAVES, "the fused backward's partial tiles reuse the per-wave slots of the reduce kernel");
 constexpr int N_SMALL = 20;                  // per-lane scalar accumulators: 5 + 3 bias sums, 3 x 4 tail columns
 
-__device__ __forceinline__ void put_tile(float* __restrict__ buf, int col, int h, const f32x16& v) {
+__device__ __forceinline__ void put_tile(float* buf, int col, int h, const f32x16& v) {
 #pragma unroll
   for (int g = 0; g < 4; g++)    // registers 4g..4g+3 are units 8g + 4h .. + 3
     *reinterpret_cast<float4*>(buf + col * TS + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
 // acc[i][j] += sum_a A[a][i] B[a][j] over the slab's 32 anchors; asum += this lane's column of A (bias gradient of unit i,
 // half of the anchors per lane half)
-__device__ __forceinline__ void wgrad_chain(const float* __restrict__ bufA, const float* __restrict__ bufB, int lane, f32x16& acc,
+__device__ __forceinline__ void wgrad_chain(const float* bufA, const float* bufB, int lane, f32x16& acc,
                                             float& asum) {
   const float* pa = bufA + (lane >> 5) * TS + (lane & 31);
   const float* pb = bufB + (lane >> 5) * TS + (lane & 31);
@@ -493,8 +497,8 @@ __device__ __forceinline__ void wgrad_chain(const float* __restrict__ bufA, cons
 }
 // the same for a first layer: B = the 32 features; the four tail inputs (view xyz, dist) are too few for a tile of their
 // own and are accumulated on the VALU from the A values that are in registers anyway
-__device__ __forceinline__ void wgrad_chain_tail(const float* __restrict__ bufA, const float* __restrict__ bufB,
-                                                 const float* __restrict__ bufT, int lane, f32x16& acc, float& asum, float* tl) {
+__device__ __forceinline__ void wgrad_chain_tail(const float* bufA, const float* bufB,
+                                                 const float* bufT, int lane, f32x16& acc, float& asum, float* tl) {
   const int half = lane >> 5;
   const float* pa = bufA + half * TS + (lane & 31);
   const float* pb = bufB + half * TS + (lane & 31);
@@ -511,7 +515,7 @@ __device__ __forceinline__ void wgrad_chain_tail(const float* __restrict__ bufA,
 // End of one MLP in the backward pass: relu mask on dH = W2^T dOUT (accumulated tile by tile), dX (inputs 0..31) on the
 // matrix cores and the view/dist tail on the VALU; dHpre goes to the wave's D tile for the first layer's weight gradient.
 __device__ __forceinline__ void finish_mlp(const float* __restrict__ img, const Small& S, int m, int lane, int h, const f32x16& hpre,
-                                           f32x16& dh, f32x16& dx, float* dtail, float* __restrict__ bufD) {
+                                           f32x16& dh, f32x16& dx, float* dtail, float* bufD) {
 #pragma unroll
   for (int r = 0; r < 16; r++) dh[r] = hpre[r] > 0.f ? dh[r] : 0.f;
   put_tile(bufD, lane & 31, h, dh);
@@ -525,8 +529,7 @@ __device__ __forceinline__ void finish_mlp(const float* __restrict__ img, const 
   }
 }
 
-__device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }
-
+template <bool BANK>
 __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
     Layout L, const uint32_t* __restrict__ count, const uint32_t* __restrict__ vis, const float* __restrict__ anchor,
     const float* __restrict__ offset, const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
@@ -561,16 +564,28 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
     const uint32_t t = g0 + col;
     const bool valid = t < n;
     const uint32_t a = vis[valid ? t : n - 1];
-    float* row = rows + (size_t)(valid ? t : 0) * ROW;
+    float* row = rows + (valid ? t : 0u) * ROW;
     AnchorLane st;
-    anchor_lane(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
-    if (valid && L.bank) stn<L1_STEPS>(row + R_X + L1_STEPS * h, st.xo);   // the feature bank's Linear(4 -> 32) reads view, dist
+    anchor_lane<BANK>(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
+    if (BANK && valid) stn<L1_STEPS>(row + R_X + L1_STEPS * h, st.xo);   // the feature bank's Linear(4 -> 32) reads view, dist
     // X tile: unit 16 h + s holds input 2 s + h (this half's 16 features in one contiguous run); tail as one float4 per anchor
 #pragma unroll
     for (int g = 0; g < 4; g++)
       *reinterpret_cast<float4*>(bufX + col * TS + 16 * h + 4 * g) = make_float4(st.xo[4 * g], st.xo[4 * g + 1], st.xo[4 * g + 2], st.xo[4 * g + 3]);
     if (h == 0) *reinterpret_cast<float4*>(bufT + col * 4) = make_float4(st.view[0], st.view[1], st.view[2], st.dist);
-    const size_t c0 = (size_t)a * NO + 5 * h;
+    const uint32_t c0 = a * NO + 5 * h;   // 32-bit element offsets (the entry points bound A): one SGPR base + one VGPR offset per access
+    // With one wave per SIMD every dependent round trip to memory is exposed, and the loop made about twenty per slab (one
+    // per field and candidate).  So the inputs of a tile are requested together and EARLY: opacity and colour gradients
+    // here, next to the anchor's own data; a covariance tile's at the top of its iteration, in front of the MFMA chains;
+    // the rows the slab's results are added to with the last tile.
+    // (The feature-bank variant has no registers to spare for this: it requests each tile's inputs where they are used.)
+    constexpr bool EARLY = !BANK;
+    float in_op[5], in_col[15];
+    if (EARLY) { ldn<5>(g_opacity + c0, in_op); ldn<15>(g_colors + c0 * 3, in_col); }
+    float in_sc[6], in_mu[6], in_off[6], in_rot[8], acc_off[6];   // the (up to) two candidates of the current covariance tile
+    float4* const dfo = reinterpret_cast<float4*>(d_feat + a * FD);
+    float4 acc_feat[4];
+    float acc_scl[6], acc_anc[3];
     f32x16 dx;
 #pragma unroll
     for (int r = 0; r < 16; r++) dx[r] = 0.f;
@@ -585,6 +600,35 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
 #pragma unroll 1
     for (int tile = 0; tile < N_TILES; tile++) {
       const int m = tile_mlp(tile);
+      auto request_cov_inputs = [&]() {
+#pragma unroll
+        for (int cl = 0; cl < 2; cl++) {
+          const int cc = 2 * (tile - 2) + cl;
+          if (cc < 5 && ((keep >> cc) & 1u)) {   // masked-out candidates are never read
+            ldn<3>(g_scales + (c0 + cc) * 3, in_sc + 3 * cl);
+            ldn<3>(g_means + (c0 + cc) * 3, in_mu + 3 * cl);
+            ldn<3>(offset + (c0 + cc) * 3, in_off + 3 * cl);
+            ldn<4>(g_rot + (c0 + cc) * 4, in_rot + 4 * cl);
+            ldn<3>(d_offset + (c0 + cc) * 3, acc_off + 3 * cl);
+          }
+        }
+      };
+      auto request_accumulated_rows = [&]() {
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc_feat[g] = dfo[2 * g + h];
+        ldn<6>(d_scaling_log + a * 6, acc_scl);
+        ldn<3>(d_anchor + a * 3, acc_anc);
+      };
+      if (EARLY && tile >= 2) {
+        request_cov_inputs();
+        if (tile == N_TILES - 1) request_accumulated_rows();
+      }
+      if (!EARLY) {   // nothing is carried from tile to tile: keeps the register allocator from holding these across the loop
+#pragma unroll
+        for (int q = 0; q < 6; q++) { in_sc[q] = 0.f; in_mu[q] = 0.f; in_off[q] = 0.f; acc_off[q] = 0.f; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) in_rot[q] = 0.f;
+      }
       if (tile <= 2) {
         hp = layer1(img, S, m, lane, h, st.xo);
 #pragma unroll
@@ -598,27 +642,28 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
       // ---- element-wise: outputs -> dL/d(output pre-activation), in place (zero for the padding lanes of the last slab:
       // they carry a copy of the last anchor and must not reach the weight gradients)
       if (tile == 0) {
-        float g[5], d[5];
-        ldn<5>(g_opacity + c0, g);
+        float d[5];
+        if (!EARLY) ldn<5>(g_opacity + c0, in_op);
 #pragma unroll
         for (int r = 0; r < 5; r++) {
           const float op = fast_tanh(o[r]);
           d[r] = 0.f;
-          if (op > 0.f) { keep |= 1u << r; d[r] = g[r] * (1.f - op * op); }
+          if (op > 0.f) { keep |= 1u << r; d[r] = in_op[r] * (1.f - op * op); }
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) o[r] = (r < 5 && valid) ? d[r < 5 ? r : 0] : 0.f;
       } else if (tile == 1) {
-        float g[15], d[15];
-        ldn<15>(g_colors + c0 * 3, g);
+        float d[15];
+        if (!EARLY) ldn<15>(g_colors + c0 * 3, in_col);
 #pragma unroll
         for (int r = 0; r < 15; r++) {
           const float colv = sigmoidf(o[r]);
-          d[r] = ((keep >> (r / 3)) & 1u) ? g[r] * colv * (1.f - colv) : 0.f;
+          d[r] = ((keep >> (r / 3)) & 1u) ? in_col[r] * colv * (1.f - colv) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) o[r] = (r < 15 && valid) ? d[r < 15 ? r : 0] : 0.f;
       } else {
+        if (!EARLY) request_cov_inputs();
 #pragma unroll
         for (int cl = 0; cl < 2; cl++) {
           const int cc = 2 * (tile - 2) + cl;
@@ -627,10 +672,9 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
           float doff[3] = {0.f, 0.f, 0.f};
           if (on) {
             const float sr3 = o[7 * cl + 3], sr4 = o[7 * cl + 4], sr5 = o[7 * cl + 5], sr6 = o[7 * cl + 6];
-            float gsc[3], gm[3], off[3];
-            ldn<3>(g_scales + (c0 + cc) * 3, gsc);
-            ldn<3>(g_means + (c0 + cc) * 3, gm);
-            ldn<3>(offset + (c0 + cc) * 3, off);
+            float gsc[3] = {in_sc[3 * cl], in_sc[3 * cl + 1], in_sc[3 * cl + 2]};
+            const float gm[3] = {in_mu[3 * cl], in_mu[3 * cl + 1], in_mu[3 * cl + 2]};
+            const float off[3] = {in_off[3 * cl], in_off[3 * cl + 1], in_off[3 * cl + 2]};
             if (reg_w != 0.f) {
               const float s0 = st.gs[3] * sigmoidf(o[7 * cl]), s1 = st.gs[4] * sigmoidf(o[7 * cl + 1]),
                           s2 = st.gs[5] * sigmoidf(o[7 * cl + 2]);
@@ -646,7 +690,7 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
               doff[c] = gm[c] * st.gs[c];
               dgs[c] += gm[c] * off[c];
             }
-            const float4 gr = reinterpret_cast<const float4*>(g_rot)[c0 + cc];
+            const float4 gr = make_float4(in_rot[4 * cl], in_rot[4 * cl + 1], in_rot[4 * cl + 2], in_rot[4 * cl + 3]);
             const float nr = sqrtf(sr3 * sr3 + sr4 * sr4 + sr5 * sr5 + sr6 * sr6);
             if (nr >= 1e-12f) {   // r = v / |v|:  dv = (g - r (r.g)) / |v|
               const float inv = 1.0f / nr;
@@ -659,10 +703,7 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
             }
           }
           if (valid && on) {   // masked-out candidates add nothing
-            float cur[3];
-            ldn<3>(d_offset + (c0 + cc) * 3, cur);
-#pragma unroll
-            for (int c = 0; c < 3; c++) cur[c] += doff[c];
+            const float cur[3] = {acc_off[3 * cl] + doff[0], acc_off[3 * cl + 1] + doff[1], acc_off[3 * cl + 2] + doff[2]};
             stn<3>(d_offset + (c0 + cc) * 3, cur);
           }
 #pragma unroll
@@ -672,7 +713,6 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
       }
       // ---- second-layer weight gradient of this tile: dOUT tile x H of the MLP
       put_tile(bufD, col, h, o);
-      lds_fence();
       switch (tile) {    // wave-uniform; keeps every accumulator in statically named registers
         case 0: wgrad_chain(bufD, bufH, lane, aW2_0, sm[0]); break;
         case 1: wgrad_chain(bufD, bufH, lane, aW2_1, sm[1]); break;
@@ -680,7 +720,6 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
         case 3: wgrad_chain(bufD, bufH, lane, aW2_3, sm[3]); break;
         default: wgrad_chain(bufD, bufH, lane, aW2_4, sm[4]); break;
       }
-      lds_fence();
       // ---- dH += W2^T dOUT for this tile
       {
         const float* im = img + (I_DH + tile * 16) * 64 + lane;
@@ -689,14 +728,12 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
       }
       if (tile != 2 && tile != 3) {
         finish_mlp(img, S, m, lane, h, hp, dh, dx, dtail, bufD);
-        lds_fence();
-        switch (m) {   // first-layer weight gradient: dHpre x (features | tail)
+          switch (m) {   // first-layer weight gradient: dHpre x (features | tail)
           case 0: wgrad_chain_tail(bufD, bufX, bufT, lane, aW1_0, sm[5], &sm[8]); break;
           case 1: wgrad_chain_tail(bufD, bufX, bufT, lane, aW1_1, sm[6], &sm[12]); break;
           default: wgrad_chain_tail(bufD, bufX, bufT, lane, aW1_2, sm[7], &sm[16]); break;
         }
-        lds_fence();
-      }
+        }
     }
     if (reg_sum != nullptr && reg_w != 0.f) {   // sum of prod(scaling) over the kept candidates, for the loss value
       reg_acc = valid ? reg_acc : 0.f;
@@ -712,8 +749,11 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
 #pragma unroll
     for (int c = 0; c < 4; c++) dtail[c] += other_half(dtail[c]);
     if (valid && h == 0) {
+      float v[6];
+      if (!EARLY) ldn<6>(d_scaling_log + a * 6, acc_scl);
 #pragma unroll
-      for (int c = 0; c < 6; c++) d_scaling_log[(size_t)a * 6 + c] += dgs[c] * st.gs[c];   // through exp()
+      for (int c = 0; c < 6; c++) v[c] = acc_scl[c] + dgs[c] * st.gs[c];   // through exp()
+      stn<6>(d_scaling_log + a * 6, v);
     }
     // dL/dfeat' for all 32 inputs: mine = rows rho(r,h), the other half's = rows rho(r,1-h)
     float dxf[FD];
@@ -724,9 +764,8 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
       dxf[rho(r, 1)] = h ? mine : oth;
     }
     float dview[4] = {dtail[0], dtail[1], dtail[2], dtail[3]};   // view xyz, dist (weights are zero where unused)
-    float4* dfo = reinterpret_cast<float4*>(d_feat + (size_t)a * FD);
     float df[FD];
-    if (L.bank) {
+    if (BANK) {
       float feat[FD];
       load_feat(anchor_feat, a, feat);
       float dbw[3] = {0.f, 0.f, 0.f};
@@ -772,7 +811,7 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
     if (valid) {   // each half adds its own 16 features: float4 groups 8g + 4h
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        float4 v = dfo[2 * g + h];
+        float4 v = EARLY ? acc_feat[g] : dfo[2 * g + h];
         v.x += h ? df[8 * g + 4] : df[8 * g]; v.y += h ? df[8 * g + 5] : df[8 * g + 1];
         v.z += h ? df[8 * g + 6] : df[8 * g + 2]; v.w += h ? df[8 * g + 7] : df[8 * g + 3];
         dfo[2 * g + h] = v;
@@ -782,9 +821,11 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
     if (valid && h == 0) {
       const float vx = st.view[0], vy = st.view[1], vz = st.view[2];
       const float dot = vx * dview[0] + vy * dview[1] + vz * dview[2];
-      d_anchor[(size_t)a * 3 + 0] += danc[0] + (dview[0] - vx * dot) * st.inv_dist + dview[3] * vx;
-      d_anchor[(size_t)a * 3 + 1] += danc[1] + (dview[1] - vy * dot) * st.inv_dist + dview[3] * vy;
-      d_anchor[(size_t)a * 3 + 2] += danc[2] + (dview[2] - vz * dot) * st.inv_dist + dview[3] * vz;
+      if (!EARLY) ldn<3>(d_anchor + a * 3, acc_anc);
+      const float v[3] = {acc_anc[0] + danc[0] + (dview[0] - vx * dot) * st.inv_dist + dview[3] * vx,
+                          acc_anc[1] + danc[1] + (dview[1] - vy * dot) * st.inv_dist + dview[3] * vy,
+                          acc_anc[2] + danc[2] + (dview[2] - vz * dot) * st.inv_dist + dview[3] * vz};
+      stn<3>(d_anchor + a * 3, v);
     }
   }
 
@@ -1084,6 +1125,7 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   int rc = make_layout(dims, &L, nullptr, nullptr, nullptr);
   if (rc != SEGS_OK) return rc;
   if (A < 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
+  if (A > MAX_ANCHORS) return segs::set_error(SEGS_ERR_UNSUPPORTED, "more than 8 M anchors (the kernels index with 32-bit element offsets)");
   if (A == 0) return SEGS_OK;
   if (!anchor || !offset || !anchor_feat || !scaling_log || !mlp_params || !camera_center || !dL_dmeans3D || !dL_dcolors ||
       !dL_dopacity || !dL_dscales || !dL_drotations || !dL_danchor || !dL_doffset || !dL_dfeat || !dL_dscaling_log ||
@@ -1093,15 +1135,20 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   temp_carve(A, L.total, temp, &T);
   constexpr size_t bwd_lds = (N_IMG_BWD * 64 + 4 * WAVE_LDS) * sizeof(float) + sizeof(Small);   // > 64 KB: needs the opt-in below
   static_assert(bwd_lds <= 160 * 1024, "one workgroup per CU");
-  static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
-  if (attr_rc != hipSuccess) return segs::set_hip_error(attr_rc, __func__);
+  static const hipError_t attr_rc0 = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel<false>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
+  static const hipError_t attr_rc1 = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel<true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
+  if (attr_rc0 != hipSuccess) return segs::set_hip_error(attr_rc0, __func__);
+  if (attr_rc1 != hipSuccess) return segs::set_hip_error(attr_rc1, __func__);
   // the regulariser sum was cleared by the forward (pack_tables_kernel) and is cleared again by reg_finish_kernel; it is
   // only accumulated when somebody reads it
   float* reg_sum = scaling_reg_out ? T.gsum + L.total + 8 : nullptr;
-  neural_bwd_kernel<<<BWD_GRID, 256, bwd_lds, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
-                                        camera_center, dL_dmeans3D, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor,
-                                        dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, T.partial, scaling_reg_weight, reg_sum);
+  // the feature bank's extra state (32 features kept for its mixing weights) costs registers the plain model does not need
+  (L.bank ? neural_bwd_kernel<true> : neural_bwd_kernel<false>)<<<BWD_GRID, 256, bwd_lds, st>>>(
+      L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small, camera_center, dL_dmeans3D,
+      dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor, dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, T.partial,
+      scaling_reg_weight, reg_sum);
   if (scaling_reg_out && L.app == 0) reg_finish_kernel<<<1, 1, 0, st>>>(T.count, reg_sum, scaling_reg_weight, scaling_reg_out);
   const WJobs J = make_jobs(L);
   if (L.bank) wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), 64, 0, st>>>(J, T.count, T.rows, T.partial);   // the feature bank's two small Linears
