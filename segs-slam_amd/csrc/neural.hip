@@ -298,16 +298,24 @@ __device__ __forceinline__ void bank_logits_partial(const Small& S, int h, const
   }
 }
 
+// What a lane reads about its anchor, as it comes from memory.  Kept apart from the arithmetic so that the forward kernel can
+// request the NEXT slab's anchors while it works on the current one.
+struct RawAnchor { float feat[FD]; float anc[3]; float sl[6]; };
+__device__ __forceinline__ void load_raw(uint32_t a, const float* __restrict__ anchor, const float* __restrict__ anchor_feat,
+                                         const float* __restrict__ scaling_log, RawAnchor& r) {
+  load_feat(anchor_feat, a, r.feat);
+  ldn<3>(anchor + a * 3, r.anc);
+  ldn<6>(scaling_log + a * 6, r.sl);
+}
+
 template <bool BANK>
-__device__ __forceinline__ void anchor_lane(const Small& S, const Layout& L, uint32_t a, int h, const float* __restrict__ anchor,
-                                            const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
-                                            const float* __restrict__ campos, AnchorLane& st) {
-  float feat[FD];
-  load_feat(anchor_feat, a, feat);
+__device__ __forceinline__ void anchor_lane_raw(const Small& S, int h, const RawAnchor& raw, const float* __restrict__ campos,
+                                                AnchorLane& st) {
+  const float* feat = raw.feat;
 #pragma unroll
-  for (int c = 0; c < 3; c++) st.anc[c] = anchor[a * 3 + c];
+  for (int c = 0; c < 3; c++) st.anc[c] = raw.anc[c];
 #pragma unroll
-  for (int c = 0; c < 6; c++) st.gs[c] = expf(scaling_log[a * 6 + c]);
+  for (int c = 0; c < 6; c++) st.gs[c] = expf(raw.sl[c]);
   const float ox = st.anc[0] - campos[0], oy = st.anc[1] - campos[1], oz = st.anc[2] - campos[2];
   st.dist = sqrtf(ox * ox + oy * oy + oz * oz);
   st.inv_dist = 1.0f / st.dist;
@@ -338,6 +346,15 @@ __device__ __forceinline__ void anchor_lane(const Small& S, const Layout& L, uin
   st.xo[16] = h ? st.view[1] : st.view[0];
   st.xo[17] = h ? st.dist : st.view[2];
 }
+template <bool BANK>
+__device__ __forceinline__ void anchor_lane(const Small& S, const Layout& L, uint32_t a, int h, const float* __restrict__ anchor,
+                                            const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
+                                            const float* __restrict__ campos, AnchorLane& st) {
+  (void)L;
+  RawAnchor raw;
+  load_raw(a, anchor, anchor_feat, scaling_log, raw);
+  anchor_lane_raw<BANK>(S, h, raw, campos, st);
+}
 
 // H_pre = W1_m X + b1_m  (rows rho(r,h) in the registers); m is a runtime value
 __device__ __forceinline__ f32x16 layer1(const float* __restrict__ img, const Small& S, int m, int lane, int h, const float* xo) {
@@ -360,7 +377,7 @@ __device__ __forceinline__ f32x16 layer2(const float* __restrict__ img, const Sm
   return d;
 }
 
-constexpr int NEURAL_GRID = 512;   // persistent workgroups (2 per CU), each loops over 128-anchor slabs
+constexpr int NEURAL_GRID = 512;   // persistent forward workgroups (2 per CU; 4 per CU was slower: 112 -> 141 us at 300 k anchors), each loops over 128-anchor slabs
 
 __global__ void __launch_bounds__(256) compact_visible_kernel(int A, const int* __restrict__ radii, uint32_t* __restrict__ count,
                                                               uint32_t* __restrict__ vis, float* __restrict__ opacity,
@@ -403,14 +420,33 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
   uint32_t kept_total = 0;
-  for (uint32_t g0 = (blockIdx.x * 4u + wv) * 32u; g0 < n; g0 += gridDim.x * 128u) {
+  // Software pipeline over the wave's slabs: the anchors (index, features, position, scaling, the five offsets of this lane
+  // half) of slab k + 1 are requested before slab k is computed, so no slab waits for its own loads (each used to pay about
+  // seven dependent round trips: index -> anchor data, then one per candidate for the offsets).
+  const uint32_t stride = gridDim.x * 128u;
+  uint32_t a_nx;
+  RawAnchor raw_nx;
+  float off_nx[15];
+  auto request = [&](uint32_t g) {
+    const uint32_t t = g + col;
+    a_nx = vis[t < n ? t : n - 1];
+    load_raw(a_nx, anchor, anchor_feat, scaling_log, raw_nx);
+    ldn<15>(offset + (a_nx * NO + 5 * h) * 3, off_nx);
+  };
+  request((blockIdx.x * 4u + wv) * 32u);
+  for (uint32_t g0 = (blockIdx.x * 4u + wv) * 32u; g0 < n; g0 += stride) {
     const uint32_t t = g0 + col;
     const bool valid = t < n;
-    const uint32_t a = vis[valid ? t : n - 1];
+    const uint32_t a = a_nx;
+    const RawAnchor raw = raw_nx;
+    float off_q[15];   // offsets of the candidates still to come, the next covariance tile's two in front
+#pragma unroll
+    for (int q = 0; q < 15; q++) off_q[q] = off_nx[q];
+    if (g0 + stride < n) request(g0 + stride);
     AnchorLane st;
-    if (L.bank) anchor_lane<true>(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
-    else anchor_lane<false>(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
-    const size_t c0 = (size_t)a * NO + 5 * h;     // first candidate of this lane half
+    if (L.bank) anchor_lane_raw<true>(S, h, raw, campos, st);
+    else anchor_lane_raw<false>(S, h, raw, campos, st);
+    const uint32_t c0 = a * NO + 5 * h;     // first candidate of this lane half (32-bit element offsets: the entry points bound A)
     f32x16 hp;
     uint32_t kept = 0;   // candidates of this lane with neural opacity > 0: P of the reference's compacted tensors
 #pragma unroll 1
@@ -435,12 +471,11 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
           const int cc = 2 * (tile - 2) + cl;
           if (cc < 5) {
             const float q0 = o[7 * cl + 3], q1 = o[7 * cl + 4], q2 = o[7 * cl + 5], q3 = o[7 * cl + 6];
-            float off[3], sc[3], mu[3];
-            ldn<3>(offset + (c0 + cc) * 3, off);
+            float sc[3], mu[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
               sc[c] = st.gs[3 + c] * sigmoidf(o[7 * cl + c]);   // :327-328
-              mu[c] = st.anc[c] + off[c] * st.gs[c];            // :331-332
+              mu[c] = st.anc[c] + off_q[3 * cl + c] * st.gs[c];  // :331-332
             }
             stn<3>(scales + (c0 + cc) * 3, sc);
             const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);  // F::normalize
@@ -448,6 +483,8 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
             stn<3>(means3D + (c0 + cc) * 3, mu);
           }
         }
+#pragma unroll
+        for (int q = 0; q < 9; q++) off_q[q] = off_q[q + 6];   // the tile loop is rolled: register arrays take no runtime index
       }
     }
     kept_total += valid ? kept : 0u;
@@ -1097,6 +1134,7 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
   int rc = make_layout(dims, &L, nullptr, nullptr, nullptr);
   if (rc != SEGS_OK) return rc;
   if (A < 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
+  if (A > MAX_ANCHORS) return segs::set_error(SEGS_ERR_UNSUPPORTED, "more than 8 M anchors (the kernels index with 32-bit element offsets)");
   if (A == 0) return SEGS_OK;
   if (!anchor || !offset || !anchor_feat || !scaling_log || !mlp_params || !camera_center || !means3D || !colors || !opacity ||
       !scales || !rotations || !neural_opacity || !temp || (L.app > 0 && !pose7))

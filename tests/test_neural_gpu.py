@@ -231,13 +231,14 @@ def test_model_io_round_trip(tmp_path):
 
 
 def test_second_slab_of_persistent_workgroups_is_consistent():
-    """A = 70 001 anchors exceed 512 workgroups x 128 anchors, so the persistent workgroups loop over a second slab.  Checked
+    """A = 140 001 anchors exceed the forward's 1024 workgroups x 128 anchors (and the backward's 256), so the persistent
+    workgroups loop over further slabs.  Checked
     by consistency (no float64 reference at this size): the same anchors processed as two smaller models give bit-identical
     per-anchor outputs and gradients (the arithmetic of an anchor does not depend on the wave that carries it) and MLP weight
     gradients that add up (different summation order: 1e-5 of the largest entry)."""
     from segs_slam_amd import neural_gaussians as ng
     dev = torch.device("cuda:0")
-    A, A1 = 70001, 35000
+    A, A1 = 140001, 70000
     rd = neural_ref.NeuralDims(**CASES[0])
     md = ng.ModelDims(**CASES[0])
     anchor, offset, feat, scaling_log, mlp = neural_ref.random_model(rd, A, 77)
