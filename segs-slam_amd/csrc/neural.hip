@@ -101,10 +101,11 @@ struct Temp {             // carve-up of the caller's scratch
   float* images;          // [N_IMG_BWD][64] MFMA A-operand images of the MLP weights (built by the forward call)
   void* small;            // Small tables
 };
-size_t temp_carve(int A, int total, char* base, Temp* t) {
+size_t temp_carve(int A, int total, int bank, char* base, Temp* t) {
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-  const size_t o_count = take(256), o_vis = take((size_t)A * 4), o_rows = take((size_t)A * ROW * 4),
+  // scratch rows: only the feature bank's two small Linears still take their weight gradients from them (2 KB per anchor)
+  const size_t o_count = take(256), o_vis = take((size_t)A * 4), o_rows = take(bank ? (size_t)A * ROW * 4 : 256),
                o_part = take((size_t)WG_JOBS * WG_WAVES * WG_TILE * 4), o_gsum = take((size_t)(total + 64) * 4),
                o_img = take((size_t)262 * 64 * 4), o_small = take(8192);
   if (t) {
@@ -1122,7 +1123,7 @@ int segs_neural_param_layout(const segs_neural_dims* dims, int64_t* offsets, int
 size_t segs_neural_temp_bytes(const segs_neural_dims* dims, int A) {
   Layout L;
   if (make_layout(dims, &L, nullptr, nullptr, nullptr) != SEGS_OK || A < 0) return 0;
-  return temp_carve(A, L.total, nullptr, nullptr);
+  return temp_carve(A, L.total, L.bank, nullptr, nullptr);
 }
 
 int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor, const float* offset, const float* anchor_feat,
@@ -1140,7 +1141,7 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
       !scales || !rotations || !neural_opacity || !temp || (L.app > 0 && !pose7))
     return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   Temp T;
-  temp_carve(A, L.total, temp, &T);
+  temp_carve(A, L.total, L.bank, temp, &T);
   static_assert(N_IMG_BWD == 262 && sizeof(Small) <= 8192, "temp_carve sizes");
   // T.count: [0] visible anchors, [1] kept candidates; cleared (with the regulariser sum) by pack_tables_kernel
   pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small, T.count, T.gsum + L.total + 8);
@@ -1170,7 +1171,7 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
       !dL_dmlp_params || !temp || (L.app > 0 && !pose7))
     return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   Temp T;
-  temp_carve(A, L.total, temp, &T);
+  temp_carve(A, L.total, L.bank, temp, &T);
   constexpr size_t bwd_lds = (N_IMG_BWD * 64 + 4 * WAVE_LDS) * sizeof(float) + sizeof(Small);   // > 64 KB: needs the opt-in below
   static_assert(bwd_lds <= 160 * 1024, "one workgroup per CU");
   static const hipError_t attr_rc0 = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel<false>),
