@@ -12,7 +12,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libsegs_raster.so")
+# SEGS_RASTER_LIB: load another build of the library (A/B measurements); the default is the in-tree build
+LIB_PATH = os.environ.get("SEGS_RASTER_LIB") or os.path.join(CSRC, "libsegs_raster.so")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
