@@ -551,6 +551,7 @@ __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const 
                                                                    uint2* __restrict__ ranges, const uint32_t* __restrict__ n_dev,
                                                                    uint32_t* __restrict__ status, uint32_t* __restrict__ status_mirror,
                                                                    const uint32_t* __restrict__ n_live /* entries left after dead keys were dropped, or null */) {
+  static_assert(RANGE_KEYS_PER_THREAD == 4, "one uint4 per thread");
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (n_dev) {
     const uint32_t n = *n_dev;
@@ -567,14 +568,30 @@ __global__ void __launch_bounds__(256) identify_tile_ranges_kernel(int L, const 
     L = (int)min(n, (uint32_t)L);
   }
   if (n_live) L = (int)min(*n_live, (uint32_t)L);
-  if (idx >= L) return;
-  const uint32_t cur = keys[idx];
-  if (idx == 0) ranges[cur].x = 0;
-  else {
-    const uint32_t prev = keys[idx - 1];
-    if (cur != prev) { ranges[prev].y = idx; ranges[cur].x = idx; }
+  // four consecutive keys per thread (one 16-byte load; the kernel is a pure stream over the sorted keys: one key per thread
+  // took 14 us for 6.8 M keys)
+  const int i0 = idx * RANGE_KEYS_PER_THREAD;
+  if (i0 >= L) return;
+  uint32_t k[RANGE_KEYS_PER_THREAD];
+  if (i0 + RANGE_KEYS_PER_THREAD <= L) {
+    const uint4 v = *reinterpret_cast<const uint4*>(keys + i0);
+    k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < RANGE_KEYS_PER_THREAD; q++) k[q] = i0 + q < L ? keys[i0 + q] : 0u;
   }
-  if (idx == L - 1) ranges[cur].y = L;
+  uint32_t prev = i0 > 0 ? keys[i0 - 1] : 0u;
+#pragma unroll
+  for (int q = 0; q < RANGE_KEYS_PER_THREAD; q++) {
+    const int i = i0 + q;
+    if (i < L) {
+      const uint32_t cur = k[q];
+      if (i == 0) ranges[cur].x = 0;
+      else if (cur != prev) { ranges[prev].y = i; ranges[cur].x = i; }
+      if (i == L - 1) ranges[cur].y = L;
+      prev = cur;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -247,7 +247,7 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   rc = sort_pairs<uint32_t>(bin, BL, n_cap, bit, 0u, 0, st, n_dev, drop_dead);
   if (rc) return rc;
   { PROF(K_RANGES);
-  identify_tile_ranges_kernel<<<(n_cap + 255) / 256, 256, 0, st>>>(n_cap, (const uint32_t*)(bin + BL.keys[0]), ranges, n_dev,
+  identify_tile_ranges_kernel<<<(n_cap + 256 * RANGE_KEYS_PER_THREAD - 1) / (256 * RANGE_KEYS_PER_THREAD), 256, 0, st>>>(n_cap, (const uint32_t*)(bin + BL.keys[0]), ranges, n_dev,
                                                                    n_dev ? total_out : nullptr, n_dev ? g_status_mirror : nullptr,
                                                                    drop_dead ? (const uint32_t*)(bin + BL.n_live) : nullptr);
   }

@@ -102,6 +102,7 @@ constexpr int SORT_TILE = SORT_ITEMS_PER_THREAD * SORT_THREADS;  // 2048 items p
 constexpr int PREFIX_ROWS_PER_WG = 8;                             // 256-slot rows per workgroup of the depth-ordered prefix kernels
 constexpr int EMIT_SLOTS_PER_WG = 512;                            // instance slots per workgroup of duplicate_with_keys_kernel
 constexpr int SORT_COUNT_CHUNK_TILES = 4;                         // tiles per workgroup of radix_count_kernel (binning.hip)
+constexpr int RANGE_KEYS_PER_THREAD = 4;                          // identify_tile_ranges_kernel
 constexpr int SORT_MAX_DIGITS = 512;                             // count-matrix rows: 8-bit passes use 256 of them, 9-bit passes all
 
 struct BinningLayout {
