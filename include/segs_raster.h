@@ -117,7 +117,9 @@ int segs_project2_image(int P, int D, int M, int width, int height, const float*
                         int* radii, void* stream);
 
 /* ---- Parity-test support: expand the private scratch into the reference's state arrays
- * (GeometryState / BinningState / ImageState, cuda_rasterizer/rasterizer_impl.h:30-66). Any output may be null. */
+ * (GeometryState / BinningState / ImageState, cuda_rasterizer/rasterizer_impl.h:30-66). Any output may be null.
+ * For the scratch of the reference-shaped entry points (segs_rasterize_forward); the resident entry points do not keep
+ * tiles_touched / the 64-bit keys' depth bits in the geometry scratch. */
 int segs_debug_unpack_geometry(const char* geom_buffer, int P, const int* radii, float* means2D /*P,2*/,
                                float* conic_opacity /*P,4*/, float* depths /*P*/, uint32_t* tiles_touched /*P*/,
                                uint32_t* point_offsets /*P*/, float* rgb /*P,3*/, void* stream);

@@ -284,7 +284,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       e4[1] = make_float4(g.conic.z, op, __uint_as_float(b.rect_min), __uint_as_float(b.rect_max));
     }
     radii[idx] = g.radius;
-    reinterpret_cast<uint4*>(bin)[idx] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
+    // BinInfo feeds make_depth_keys_kernel and the parity-test unpackers of the reference-shaped path; the resident path
+    // (depth keys written right here) reads it nowhere: 16 B x P saved per step
+    if (!depth_keys) reinterpret_cast<uint4*>(bin)[idx] = make_uint4(b.depth_bits, b.rect_min, b.rect_max, b.tiles_touched);
     touched_dense[idx] = b.tiles_touched;
     if (depth_keys) {   // resident mode: what make_depth_keys_kernel would write (32-bit depth keys, culled = 0xFFFFFFFF)
       // The resident depth sort looks at DEPTH_KEY_BITS bits above the near plane's bit pattern (three 9-bit passes).
