@@ -414,7 +414,25 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   for (int i = tid; i < 4 * NDIG; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
 
-  const size_t tile_base = (size_t)blockIdx.x * SORT_TILE;
+  // Which tile this workgroup sorts.  Workgroup ids are dealt round-robin to the 8 XCDs, and the runs that consecutive tiles
+  // write for one digit are ADJACENT in the output (4-8 keys each): with tile = workgroup id the eight L2s each hold an
+  // eighth of every output line and write it back as masked partial sectors.  Giving each XCD a contiguous range of tiles
+  // lets its L2 complete the lines before they leave (ubench_sort_passes: 29 -> 21 us per 9-bit pass over 2.1 M keys,
+  // 67 -> 46 us for the first tile-id pass over 7.9 M).  The grid is rounded up to a multiple of 8; surplus workgroups have
+  // no tile.
+  // The ranges are cut from the tiles that HOLD keys (n may come from the device and be well below the launch's capacity):
+  // cut from the capacity they would leave the last XCDs idle.
+#ifdef SORT_TILE_IDENTITY
+  const int tile_id = (int)blockIdx.x;
+#else
+  const int tiles_in_use = (int)(((size_t)n + SORT_TILE - 1) / SORT_TILE);
+  const int tiles_per_xcd = (tiles_in_use + 7) >> 3;
+  const int tile_id = (int)(blockIdx.x & 7u) * tiles_per_xcd + (int)(blockIdx.x >> 3);
+  if (tiles_in_use == 0 && n_live_out != nullptr && blockIdx.x == 0 && tid == 0) *n_live_out = 0u;   // nobody has tile 0 then
+  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
+#endif
+  if (tile_id >= nblocks) return;
+  const size_t tile_base = (size_t)tile_id * SORT_TILE;
   const size_t wave_base = tile_base + (size_t)wv * (SORT_TILE / 4);
   const int nvalid = (size_t)n > tile_base ? (int)min((size_t)SORT_TILE, (size_t)n - tile_base) : 0;
 
@@ -484,13 +502,13 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const int d = tid * DPT + j;
     local_start[d] = lstart;
     // keys with digit d: in smaller digits' runs (gstart), in earlier chunks, in earlier tiles of this chunk
-    gdelta[d] = (int32_t)(gstart + chunk_prefix[(size_t)d * nchunks + blockIdx.x / COUNT_CHUNK] +
-                          tile_prefix[(size_t)blockIdx.x * NDIG + d] - lstart);
+    gdelta[d] = (int32_t)(gstart + chunk_prefix[(size_t)d * nchunks + tile_id / COUNT_CHUNK] +
+                          tile_prefix[(size_t)tile_id * NDIG + d] - lstart);
     lstart += run[j]; gstart += tot[j];
   }
   // with dead keys dropped the tile holds fewer than nvalid entries, and the pass leaves sum(digit_totals) of them in all
   const int nout = drop_dead ? (int)(scan_tmp[0] + scan_tmp[1] + scan_tmp[2] + scan_tmp[3]) : nvalid;
-  if (n_live_out != nullptr && blockIdx.x == 0 && tid == 0) *n_live_out = tot_tmp[0] + tot_tmp[1] + tot_tmp[2] + tot_tmp[3];
+  if (n_live_out != nullptr && tile_id == 0 && tid == 0) *n_live_out = tot_tmp[0] + tot_tmp[1] + tot_tmp[2] + tot_tmp[3];
   __syncthreads();
 
 #pragma unroll

@@ -126,19 +126,20 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     LAUNCH_TRY("radix_scan_kernel");
     if (iota_vals && p == 0) vin = nullptr;
     const int nbits = std::min(BITS, end_bit - shift);   // the last pass may have fewer significant bits than a full digit
+    const int scatter_grid = (L.nblocks + 7) / 8 * 8;   // a multiple of the XCD count: see radix_scatter_kernel's tile mapping
     { PROF(K_RADIX_SCATTER);
     if constexpr (sizeof(K) == 4) {
       if (aux_in && p == passes - 1) {
-        radix_scatter_kernel<K, BITS, true><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
+        radix_scatter_kernel<K, BITS, true><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                         digit_totals, L.nblocks, L.nchunks, n_in, drop,
                                                                         drop ? n_live : nullptr, aux_in, aux_final, nbits);
       } else {
-        radix_scatter_kernel<K, BITS, false><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
+        radix_scatter_kernel<K, BITS, false><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                          digit_totals, L.nblocks, L.nchunks, n_in, drop,
                                                                          drop ? n_live : nullptr, nullptr, nullptr, nbits);
       }
     } else {
-      radix_scatter_kernel<K, BITS, false><<<L.nblocks, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
+      radix_scatter_kernel<K, BITS, false><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                        digit_totals, L.nblocks, L.nchunks, n_in, drop,
                                                                        drop ? n_live : nullptr, nullptr, nullptr, nbits);
     }
