@@ -311,7 +311,23 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
 #pragma unroll
   for (int j = 0; j < DPT; j++) running[j] = 0u;
   K kreg[SORT_ITEMS_PER_THREAD], knext[SORT_ITEMS_PER_THREAD];
-  const int b0 = blockIdx.x * COUNT_CHUNK;
+  // chunk of this workgroup: each XCD takes a contiguous range of the chunks in use, like the scatter's tiles -- the chunk
+  // totals are written one dword per digit row, and consecutive chunks' dwords share their lines
+  const int chunks_in_use = (int)(((size_t)n + (size_t)SORT_TILE * COUNT_CHUNK - 1) / ((size_t)SORT_TILE * COUNT_CHUNK));
+  const int chunks_per_xcd = (chunks_in_use + 7) >> 3;
+  const int chunk_id = (int)(blockIdx.x & 7u) * chunks_per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= chunks_per_xcd) {
+    // no keys for this workgroup: it zeroes the totals of one of the columns beyond the chunks in use (the row scan runs over
+    // all nchunks columns of the capacity)
+    const int col = 8 * chunks_per_xcd + ((int)(blockIdx.x >> 3) - chunks_per_xcd) * 8 + (int)(blockIdx.x & 7u);
+    if (col < nchunks) {
+      constexpr int ND = 1 << BITS;
+      for (int d = threadIdx.x; d < ND; d += SORT_THREADS) chunk_hist[(size_t)d * nchunks + col] = 0u;
+    }
+    return;
+  }
+  if (chunk_id >= nchunks) return;
+  const int b0 = chunk_id * COUNT_CHUNK;
   auto load_tile = [&](int b, K* dst) {
     const size_t wave_base = (size_t)b * SORT_TILE + (size_t)wv * (SORT_TILE / 4);
 #pragma unroll
@@ -348,7 +364,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
     for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) kreg[r] = knext[r];
   }
 #pragma unroll
-  for (int j = 0; j < DPT; j++) chunk_hist[(size_t)(tid * DPT + j) * nchunks + blockIdx.x] = running[j];
+  for (int j = 0; j < DPT; j++) chunk_hist[(size_t)(tid * DPT + j) * nchunks + chunk_id] = running[j];
 }
 
 // Row d of the count matrix -> exclusive scan in place; row total -> digit_totals[d].  Grid = one workgroup per digit.

@@ -117,7 +117,7 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     const int drop = drop_dead && p == 0;
     const uint32_t* n_in = (drop_dead && p > 0) ? n_live : n_dev;
     { PROF(K_RADIX_COUNT);
-    radix_count_kernel<K, BITS><<<L.nchunks, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, L.nchunks, n_in, drop);
+    radix_count_kernel<K, BITS><<<(L.nchunks + 7) / 8 * 8, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, L.nchunks, n_in, drop);
     }
     LAUNCH_TRY("radix_count_kernel");
     { PROF(K_RADIX_SCAN);
