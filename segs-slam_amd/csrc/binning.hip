@@ -82,40 +82,38 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(uint32_t* __restr
 // Each emitted VALUE also carries the 4-bit mask of 8x8 quadrants of the tile in which this Gaussian can pass
 // the alpha >= 1/255 test at all: exact minimum of the quadratic form over the quadrant's pixel rectangle
 // against 2 ln(255 o) (conservatively inflated).  See gs_layout.h.
-// The test for one pixel rectangle [x0,x1] x [y0,y1] (relative to the centre: lx0..ly1): true if the centre lies inside;
-// otherwise the minimum of A dx^2 + 2 B dx dy + C dy^2 over the rectangle sits on one of its four edges, and along an edge
-// (say dx fixed) it is the quadratic in dy clamped to the edge span at its vertex -B dx / C.  The rectangle is hit iff the
-// smallest of the four edge minima is <= k.
-// quadrant_mask does this for the four 8x8 quadrants of the tile at (fx, fy) at once.  The quadrants share their edge lines
-// (x = fx, fx+7, fx+8, fx+15, likewise y), so the clamped 1-D minimum along a line is set up once per line and evaluated
-// for the two spans it bounds: 16 edge minima at about 150 VALU operations instead of 4 x 60 for four separate tests (the
-// emitter is VALU-bound on this).  Evaluated as a dx^2 + dy (2 b dx + c dy); the threshold k is inflated by the caller, so
-// last-bit differences stay on the conservative side.
+// The test for one pixel rectangle (spans relative to the centre): the minimum of A dx^2 + 2 B dx dy + C dy^2 over the
+// rectangle against k; along a line (say dx fixed) the form is a quadratic in dy, clamped to the span at its vertex
+// -B dx / C.  quadrant_mask does this for the four 8x8 quadrants of the tile at (fx, fy) at once; evaluated as
+// a dx^2 + dy (2 b dx + c dy); the threshold k is inflated by the caller, so last-bit differences stay on the conservative side.
 __device__ __forceinline__ uint32_t quadrant_mask(float cx, float cy, float A, float B, float C, float k, float nb_c /* -B/C */,
                                                   float nb_a /* -B/A */, float fx, float fy) {
-  const float lx[4] = {fx - cx, fx + 7.f - cx, fx + 8.f - cx, fx + 15.f - cx};
-  const float ly[4] = {fy - cy, fy + 7.f - cy, fy + 8.f - cy, fy + 15.f - cy};
+  // q(dx, dy) = A dx^2 + 2 B dx dy + C dy^2 is convex with its minimum at the centre, so over a pixel rectangle that does not
+  // contain the centre the minimum sits on an edge FACING the centre (walking from any other boundary point towards the
+  // centre lowers q and leaves the rectangle through such an edge).  With xn / yn = the centre's coordinates clamped into
+  // the rectangle's spans, two clamped 1-D minima decide a quadrant: along x = xn (vertex at dy = -B/C xn) and along
+  // y = yn (vertex at dx = -B/A yn); a centre inside the rectangle gives xn = yn = 0 and q = 0.  (The first version took
+  // all four edges of each quadrant, 16 edge minima per tile at ~150 operations; this is ~85, and the emitter is VALU-bound.)
+  const float x_lo[2] = {fx - cx, fx + 8.f - cx}, x_hi[2] = {fx + 7.f - cx, fx + 15.f - cx};
+  const float y_lo[2] = {fy - cy, fy + 8.f - cy}, y_hi[2] = {fy + 7.f - cy, fy + 15.f - cy};
   const float B2 = 2.f * B;
-  float v[4][2], h[4][2];
+  float xn[2], yn[2], axx[2], bx2[2], tv[2], cyy[2], by2[2], th[2];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float dx = lx[i], t = nb_c * dx, adx2 = A * dx * dx, bdx2 = B2 * dx;   // line x = lx[i]
-    const float dy = ly[i], u = nb_a * dy, cdy2 = C * dy * dy, bdy2 = B2 * dy;   // line y = ly[i]
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const float yy = fminf(ly[2 * r + 1], fmaxf(ly[2 * r], t));
-      v[i][r] = adx2 + yy * (bdx2 + C * yy);
-      const float xx = fminf(lx[2 * r + 1], fmaxf(lx[2 * r], u));
-      h[i][r] = cdy2 + xx * (bdy2 + A * xx);
-    }
+  for (int i = 0; i < 2; i++) {
+    xn[i] = fminf(x_hi[i], fmaxf(x_lo[i], 0.f));
+    yn[i] = fminf(y_hi[i], fmaxf(y_lo[i], 0.f));
+    axx[i] = A * xn[i] * xn[i]; bx2[i] = B2 * xn[i]; tv[i] = nb_c * xn[i];
+    cyy[i] = C * yn[i] * yn[i]; by2[i] = B2 * yn[i]; th[i] = nb_a * yn[i];
   }
   uint32_t mask = 0u;
 #pragma unroll
   for (int qd = 0; qd < 4; qd++) {
     const int qx = qd & 1, qy = qd >> 1;
-    const bool inside = lx[2 * qx] <= 0.f && lx[2 * qx + 1] >= 0.f && ly[2 * qy] <= 0.f && ly[2 * qy + 1] >= 0.f;
-    const float best = fminf(fminf(v[2 * qx][qy], v[2 * qx + 1][qy]), fminf(h[2 * qy][qx], h[2 * qy + 1][qx]));
-    if (inside || best <= k) mask |= 1u << qd;
+    const float yy = fminf(y_hi[qy], fmaxf(y_lo[qy], tv[qx]));
+    const float v = axx[qx] + yy * (bx2[qx] + C * yy);
+    const float xx = fminf(x_hi[qx], fmaxf(x_lo[qx], th[qy]));
+    const float h = cyy[qy] + xx * (by2[qy] + A * xx);
+    if (fminf(v, h) <= k) mask |= 1u << qd;
   }
   return mask;
 }

@@ -40,8 +40,10 @@ def check_binning_invariants(P, W, H, radii, means2D, depths, tiles_touched, off
     f32 = np.float32
     rminx = np.clip(((means2D[:, 0] - r) / f32(16)).astype(np.int32), 0, gx)
     rminy = np.clip(((means2D[:, 1] - r) / f32(16)).astype(np.int32), 0, gy)
-    rmaxx = np.clip(((means2D[:, 0] + r + f32(15)) / f32(16)).astype(np.int32), 0, gx)
-    rmaxy = np.clip(((means2D[:, 1] + r + f32(15)) / f32(16)).astype(np.int32), 0, gy)
+    # auxiliary.h:47-57 evaluates p.x + max_radius + BLOCK_X - 1 left to right in float: (+16) then (-1), two roundings; "+ 15"
+    # differs from that in the last bit when the sum crosses a binade (found by tools/fuzz_raster.py, seed 31017)
+    rmaxx = np.clip(((means2D[:, 0] + r + f32(16) - f32(1)) / f32(16)).astype(np.int32), 0, gx)
+    rmaxy = np.clip(((means2D[:, 1] + r + f32(16) - f32(1)) / f32(16)).astype(np.int32), 0, gy)
     vis = radii > 0
     assert np.array_equal(((rmaxx - rminx) * (rmaxy - rminy))[vis].astype(np.uint32), tiles_touched[vis])
     tx, ty = tile % gx, tile // gx
