@@ -391,9 +391,9 @@ static int rasterize_backward_impl(int P, int D, int M, int R, const float* back
   }
   if (R > 0) {
     { PROF(K_RENDER_BWD);
-    render_bwd_kernel<<<gx * gy, 256, 0, st>>>((const uint2*)(img + IL.ranges), (const uint32_t*)(bin + BL.vals[0]), width,
+    render_bwd_kernel<<<(gx * gy + 7) / 8 * 32, 64, 0, st>>>((const uint2*)(img + IL.ranges), (const uint32_t*)(bin + BL.vals[0]), width,
                                                     height, G.rec(), background, (const float*)(img + IL.final_T),
-                                                    (const uint32_t*)(img + IL.n_contrib), dL_dpix, G.gacc());
+                                                    (const uint32_t*)(img + IL.n_contrib), dL_dpix, G.gacc(), gx * gy);
     }
     LAUNCH_TRY("render_bwd_kernel");
   }

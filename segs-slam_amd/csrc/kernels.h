@@ -85,7 +85,7 @@ __global__ void render_fwd_kernel(const uint2* __restrict__ ranges, const uint32
 __global__ void render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
                                   const float* __restrict__ rec, const float* __restrict__ bg,
                                   const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                                  const float* __restrict__ dL_dpix, float* __restrict__ gacc);
+                                  const float* __restrict__ dL_dpix, float* __restrict__ gacc, uint32_t num_tiles);
 
 // ---- debug / test support (binning.hip)
 __global__ void unpack_geometry_kernel(int P, const float* __restrict__ rec, const BinInfo* __restrict__ bin,

@@ -249,7 +249,7 @@ __device__ __forceinline__ void fmac_row_bcast(float& acc, float v, float a) {
 }
 constexpr int BW_SLOTS = 16;
 constexpr int BW_STRIDE = 65;  // padded row of the transposed tiles: conflict-free in both roles
-struct BwdLds {                  // 9088 B per wave -> 4 workgroups (16 waves) per CU
+struct BwdLds {                  // 9088 B per wave -> 16 single-wave workgroups per CU
   float4 rec[BW_SLOTS][3];      // staged records of the current batch: [0] x y a2 b2  [1] c2 o r g  [2] b pos id -
   float wt[BW_SLOTS][BW_STRIDE];
   float at[BW_SLOTS][BW_STRIDE];  // its first 16x12 floats are reused as the moment exchange area `mom`
@@ -298,17 +298,24 @@ __device__ __forceinline__ void pixel_role(BwdLds& L, int nb, int lane, float px
   }
 }
 
-__global__ void __launch_bounds__(256) render_bwd_kernel(
+__global__ void __launch_bounds__(64) render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
     const float* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ gacc) {
-  __shared__ BwdLds lds_all[4];
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ gacc, uint32_t num_tiles) {
+  // One wave (one 8x8 quadrant) per workgroup: the four quadrants of a tile share nothing but their inputs, and as one
+  // 256-thread workgroup the three shorter ones held their LDS and wave slots until the longest list ended (the longest
+  // quadrant of a tile is 1.15-1.17 x the mean, tools/tile_stats.py).  Workgroup b = ((tl * 4 + q) << 3) | xcd: the four
+  // quadrants of a tile stay on one XCD, tiles are dealt to the XCDs as before (xcd_tile).
+  __shared__ BwdLds lds_one;
   const uint32_t tiles_x = (W + TILE_X - 1) / TILE_X;
-  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+  const uint32_t v = ((local >> 2) << 3) | xcd;   // the tile-level workgroup id of the 256-thread formulation
+  if (v >= num_tiles) return;
+  const uint32_t tile = xcd_tile(v, num_tiles);
   const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
   const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  BwdLds& L = lds_all[wv];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(local & 3u));
+  BwdLds& L = lds_one;
   const uint32_t qx0 = tile_x * TILE_X + (wv & 1) * 8, qy0 = tile_y * TILE_Y + (wv >> 1) * 8;
   const uint32_t px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const bool inside = px < (uint32_t)W && py < (uint32_t)H;
