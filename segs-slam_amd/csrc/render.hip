@@ -6,8 +6,10 @@
 // Neither kernel is HBM-bound: per (Gaussian, 8x8 quadrant) the forward issues ~22 vector instructions, the backward ~39,
 // against 64 B of record; the forward is VALU-issue bound, the backward VALU- and LDS-bound at once.
 // MI355X mapping:
-//  * workgroup = one 16x16 tile (the binning unit, fixed by the reference's key format) = 4 wave64; each wave owns an
-//    8x8 pixel quadrant and walks the tile's list on its own: no workgroup barrier anywhere.
+//  * a 16x16 tile (the binning unit, fixed by the reference's key format) is rendered by 4 wave64; each wave owns an 8x8
+//    pixel quadrant and walks the tile's list on its own: no workgroup barrier anywhere.  The forward launches them as one
+//    256-thread workgroup, the backward as four single-wave workgroups on the same XCD (its lists end at different depths
+//    per quadrant, and a finished wave should give its LDS and registers back at once).
 //  * the list is read 64 entries at a time with one coalesced vector load; each entry carries a 4-bit "quadrants this
 //    instance can reach" mask (gs_layout.h); the entries of this wave's quadrant are compacted to the low lanes with
 //    ds_permute, their 64-byte records gathered one per lane (two chunks in flight ahead of the one being evaluated).
