@@ -37,9 +37,6 @@ constexpr int ROW = 512;   // scratch floats per visible anchor
 constexpr int R_X = 0;     // x[36] in lane order: position 18 h + s holds input 2 s + h
 constexpr int R_H = 64;    // + 32*m : hidden activations, m = 0 opacity, 1 cov, 2 colour, 3 feature bank
 constexpr int R_DH = 192;  // + 32*m : dL/d(hidden pre-activation)
-constexpr int R_DO = 320;  // dL/d(opacity MLP output pre-tanh): position 8 h + r  <-> output 5 h + r, r < 5      [16]
-constexpr int R_DK = 336;  // dL/d(colour MLP output pre-sigmoid): position 16 h + r <-> output 15 h + r, r < 15  [32]
-constexpr int R_DC = 368;  // dL/d(cov MLP output): position 36 h + r <-> output 35 h + r, r < 35                  [72]
 constexpr int R_DF = 440;  // dL/d(feature-bank logits) [3]
 constexpr int WG_WAVES = 256;  // waves per weight-gradient job
 constexpr int WG_UNROLL = 8;   // row pairs whose operand loads are in flight together
