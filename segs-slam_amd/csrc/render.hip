@@ -154,10 +154,14 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(
   for (uint32_t base = range.x; base < range.y && alive; base += 64) {
     // stage chunk c's records for broadcast reads
     const int n = __builtin_amdgcn_readfirstlane(cc.n);
-    if (lane < n) {
-      s_rec[wv][lane][0] = r0;
-      s_rec[wv][lane][1] = r1;
-      s_rec[wv][lane][2] = make_float4(rb, __uint_as_float(base - range.x + cc.pos + 1u), 0.f, 0.f);
+    // The entries are evaluated four at a time (records at immediate LDS offsets, the loop counter scalar); the last group is
+    // padded with null records: opacity 0 gives alpha 0, which is not a contribution and changes nothing.
+    const int n4 = (n + 3) & ~3;
+    if (lane < n4) {
+      const bool real = lane < n;
+      s_rec[wv][lane][0] = real ? r0 : make_float4(0.f, 0.f, 0.f, 0.f);
+      s_rec[wv][lane][1] = real ? r1 : make_float4(0.f, 0.f, 0.f, 0.f);
+      s_rec[wv][lane][2] = make_float4(real ? rb : 0.f, __uint_as_float(base - range.x + cc.pos + 1u), 0.f, 0.f);
     }
     wave_lds_fence();
     // put chunk c+1's records and chunk c+2's list entries in flight
@@ -171,11 +175,10 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(
       }
       v_nxt = v_nn;
     }
-#ifndef FWD_UNROLL
-#define FWD_UNROLL 1
-#endif
-#pragma unroll FWD_UNROLL
-    for (int k = 0; k < n; k++) {
+    for (int k0 = 0; k0 < n4 && alive; k0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + u;
       const float4 q0 = s_rec[wv][k][0], q1 = s_rec[wv][k][1];
       const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[wv][k][2]);
       const float dx = q0.x - pxf, dy = q0.y - pyf;
@@ -198,6 +201,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(
       C0 += q1.z * w; C1 += q1.w * w; C2 += q2.x * w;
       last = ok ? __float_as_uint(q2.y) : last;
       if (!alive) break;
+    }
     }
   }
   if (inside) {
