@@ -269,7 +269,7 @@ __device__ __forceinline__ void pixel_role(BwdLds& L, int nb, int lane, float px
                                            float dp0, float dp1, float dp2, float T_final, float bg_dot_dpixel, float& T,
                                            float& accd) {
 #ifndef PIX_UNROLL
-#define PIX_UNROLL 2
+#define PIX_UNROLL 4
 #endif
 #pragma unroll PIX_UNROLL
   for (int sl = 0; sl < nb; sl++) {
