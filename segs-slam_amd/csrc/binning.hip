@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
                                                                     uint32_t dmin, int dbits,
                                                                     uint32_t* __restrict__ tile_prefix, uint32_t* __restrict__ chunk_hist,
                                                                     int nblocks, int nchunks,
-                                                                    const uint32_t* __restrict__ n_dev, int drop_dead) {
+                                                                    const uint32_t* __restrict__ n_dev, int drop_dead, int chunk_tiles) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   constexpr int NDIG = 1 << BITS;
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
   K kreg[SORT_ITEMS_PER_THREAD], knext[SORT_ITEMS_PER_THREAD];
   // chunk of this workgroup: each XCD takes a contiguous range of the chunks in use, like the scatter's tiles -- the chunk
   // totals are written one dword per digit row, and consecutive chunks' dwords share their lines
-  const int chunks_in_use = (int)(((size_t)n + (size_t)SORT_TILE * COUNT_CHUNK - 1) / ((size_t)SORT_TILE * COUNT_CHUNK));
+  const int chunks_in_use = (int)(((size_t)n + (size_t)SORT_TILE * chunk_tiles - 1) / ((size_t)SORT_TILE * chunk_tiles));
   const int chunks_per_xcd = (chunks_in_use + 7) >> 3;
   const int chunk_id = (int)(blockIdx.x & 7u) * chunks_per_xcd + (int)(blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= chunks_per_xcd) {
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
     return;
   }
   if (chunk_id >= nchunks) return;
-  const int b0 = chunk_id * COUNT_CHUNK;
+  const int b0 = chunk_id * chunk_tiles;
   auto load_tile = [&](int b, K* dst) {
     const size_t wave_base = (size_t)b * SORT_TILE + (size_t)wv * (SORT_TILE / 4);
 #pragma unroll
@@ -335,11 +335,11 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
     }
   };
   load_tile(b0, kreg);
-  for (int t = 0; t < COUNT_CHUNK; t++) {
+  for (int t = 0; t < chunk_tiles; t++) {
     const int b = b0 + t;
     if (b >= nblocks) break;
     for (int i = tid; i < 4 * NDIG; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
-    if (t + 1 < COUNT_CHUNK) load_tile(b + 1, knext);      // next tile's keys in flight while this one is counted
+    if (t + 1 < chunk_tiles) load_tile(b + 1, knext);      // next tile's keys in flight while this one is counted
     __syncthreads();
     // Counting needs no ranks: one LDS atomic per key into the wave's private histogram.  Lanes with equal digits
     // serialise inside the LDS (worst case, one digit for the whole wave, about the cost of the 8-ballot peer match the
@@ -411,7 +411,8 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     uint32_t* __restrict__ vals_out, int n, int shift, uint32_t dmin, int dbits, const uint32_t* __restrict__ tile_prefix,
     const uint32_t* __restrict__ chunk_prefix /* chunk_hist after radix_scan_kernel */, const uint32_t* __restrict__ digit_totals,
     int nblocks, int nchunks, const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out,
-    const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits /* significant bits of this pass's digit */) {
+    const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits /* significant bits of this pass's digit */,
+    int chunk_tiles /* tiles per chunk of the count kernel that produced the tables */) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   constexpr int NDIG = 1 << BITS;
@@ -516,7 +517,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const int d = tid * DPT + j;
     local_start[d] = lstart;
     // keys with digit d: in smaller digits' runs (gstart), in earlier chunks, in earlier tiles of this chunk
-    gdelta[d] = (int32_t)(gstart + chunk_prefix[(size_t)d * nchunks + tile_id / COUNT_CHUNK] +
+    gdelta[d] = (int32_t)(gstart + chunk_prefix[(size_t)d * nchunks + tile_id / chunk_tiles] +
                           tile_prefix[(size_t)tile_id * NDIG + d] - lstart);
     lstart += run[j]; gstart += tot[j];
   }
@@ -559,10 +560,10 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 
 #define SEGS_INSTANTIATE_RADIX(K, BITS)                                                                                          \
   template __global__ void radix_count_kernel<K, BITS>(const K*, int, int, uint32_t, int, uint32_t*, uint32_t*, int, int,       \
-                                                       const uint32_t*, int);                                                  \
+                                                       const uint32_t*, int, int);                                                  \
   template __global__ void radix_scatter_kernel<K, BITS, false>(const K*, const uint32_t*, K*, uint32_t*, int, int, uint32_t, int, \
                                                                 const uint32_t*, const uint32_t*, const uint32_t*, int, int,        \
-                                                                const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int);
+                                                                const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int);
 SEGS_INSTANTIATE_RADIX(uint64_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 9)
@@ -570,7 +571,7 @@ SEGS_INSTANTIATE_RADIX(uint32_t, 9)
 #define SEGS_INSTANTIATE_AUX(BITS)                                                                                                     \
   template __global__ void radix_scatter_kernel<uint32_t, BITS, true>(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, int, int, \
                                                                       uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, \
-                                                                      int, int, const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int);
+                                                                      int, int, const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int);
 SEGS_INSTANTIATE_AUX(8)
 SEGS_INSTANTIATE_AUX(9)
 #undef SEGS_INSTANTIATE_AUX

@@ -108,6 +108,13 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
   uint32_t* tile_prefix = (uint32_t*)(bin + L.tile_prefix);
   uint32_t* chunk_hist = (uint32_t*)(bin + L.chunk_hist);
   uint32_t* digit_totals = (uint32_t*)(bin + L.digit_totals);
+  // Tiles per chunk of the count kernel (a workgroup walks its chunk's tiles one after the other; only the chunk totals go
+  // through the row scan).  Few tiles: one tile per workgroup -- the launch is latency-bound and a 4-tile walk quadruples
+  // that latency for nothing (50 k Gaussians at 640x480: 0.206 -> 0.187 ms per step with one tile per chunk).  Many tiles:
+  // longer chunks keep the row scan short (3 M Gaussians at 1080p: 1.102 / 1.108 / 1.126 ms with 4 / 2 / 1).
+  static const int chunk_override = [] { const char* e = getenv("SEGS_COUNT_CHUNK"); return e ? atoi(e) : 0; }();
+  const int chunk_tiles = chunk_override > 0 ? chunk_override : (L.nblocks <= 256 ? 1 : (L.nblocks <= 2048 ? 2 : SORT_COUNT_CHUNK_TILES));
+  const int nchunks = (L.nblocks + chunk_tiles - 1) / chunk_tiles;
   for (int p = 0; p < passes; p++) {
     const K* kin = (const K*)(bin + L.keys[side]);
     const uint32_t* vin = (const uint32_t*)(bin + L.vals[side]);
@@ -117,11 +124,11 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     const int drop = drop_dead && p == 0;
     const uint32_t* n_in = (drop_dead && p > 0) ? n_live : n_dev;
     { PROF(K_RADIX_COUNT);
-    radix_count_kernel<K, BITS><<<(L.nchunks + 7) / 8 * 8, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, L.nchunks, n_in, drop);
+    radix_count_kernel<K, BITS><<<(nchunks + 7) / 8 * 8, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, nchunks, n_in, drop, chunk_tiles);
     }
     LAUNCH_TRY("radix_count_kernel");
     { PROF(K_RADIX_SCAN);
-    radix_scan_kernel<<<1 << BITS, 256, 0, st>>>(chunk_hist, L.nchunks, digit_totals);
+    radix_scan_kernel<<<1 << BITS, 256, 0, st>>>(chunk_hist, nchunks, digit_totals);
     }
     LAUNCH_TRY("radix_scan_kernel");
     if (iota_vals && p == 0) vin = nullptr;
@@ -131,17 +138,17 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     if constexpr (sizeof(K) == 4) {
       if (aux_in && p == passes - 1) {
         radix_scatter_kernel<K, BITS, true><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
-                                                                        digit_totals, L.nblocks, L.nchunks, n_in, drop,
-                                                                        drop ? n_live : nullptr, aux_in, aux_final, nbits);
+                                                                        digit_totals, L.nblocks, nchunks, n_in, drop,
+                                                                        drop ? n_live : nullptr, aux_in, aux_final, nbits, chunk_tiles);
       } else {
         radix_scatter_kernel<K, BITS, false><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
-                                                                         digit_totals, L.nblocks, L.nchunks, n_in, drop,
-                                                                         drop ? n_live : nullptr, nullptr, nullptr, nbits);
+                                                                         digit_totals, L.nblocks, nchunks, n_in, drop,
+                                                                         drop ? n_live : nullptr, nullptr, nullptr, nbits, chunk_tiles);
       }
     } else {
       radix_scatter_kernel<K, BITS, false><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
-                                                                       digit_totals, L.nblocks, L.nchunks, n_in, drop,
-                                                                       drop ? n_live : nullptr, nullptr, nullptr, nbits);
+                                                                       digit_totals, L.nblocks, nchunks, n_in, drop,
+                                                                       drop ? n_live : nullptr, nullptr, nullptr, nbits, chunk_tiles);
     }
     }
     LAUNCH_TRY("radix_scatter_kernel");

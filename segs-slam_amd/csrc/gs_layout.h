@@ -121,7 +121,7 @@ inline BinningLayout binning_layout(int R) {
   for (int i = 0; i < 2; i++) { b.vals[i] = o; o = align_up(o + (size_t)R * 4); }
   // per-tile digit offsets inside their chunk, tile-major [nblocks][digits]; per-chunk digit counts, digit-major
   // [digits][nchunks] (scanned in place by radix_scan_kernel)
-  b.nchunks = (b.nblocks + SORT_COUNT_CHUNK_TILES - 1) / SORT_COUNT_CHUNK_TILES;
+  b.nchunks = b.nblocks;   // columns ALLOCATED for the chunk totals: one per tile, the smallest chunk sort_pairs may choose
   b.tile_prefix = o;  o = align_up(o + (size_t)SORT_MAX_DIGITS * (b.nblocks > 0 ? b.nblocks : 1) * 4);
   b.chunk_hist = o;   o = align_up(o + (size_t)SORT_MAX_DIGITS * (b.nchunks > 0 ? b.nchunks : 1) * 4);
   b.digit_totals = o; o = align_up(o + SORT_MAX_DIGITS * 4);

@@ -27,6 +27,8 @@ void run(const char* name, const std::vector<uint32_t>& keys, int end_bit, uint3
   hipEvent_t ev[64]; for (auto& evt : ev) CK(hipEventCreate(&evt));
   std::vector<double> tc(passes, 0), ts(passes, 0), tx(passes, 0);
   const int reps = 20;
+  const int chunk_tiles = getenv("SEGS_COUNT_CHUNK") ? atoi(getenv("SEGS_COUNT_CHUNK")) : SORT_COUNT_CHUNK_TILES;
+  const int nchunks = (L.nblocks + chunk_tiles - 1) / chunk_tiles;
   uint32_t* tile_prefix = (uint32_t*)(bin + L.tile_prefix); uint32_t* chunk_hist = (uint32_t*)(bin + L.chunk_hist);
   uint32_t* digit_totals = (uint32_t*)(bin + L.digit_totals);
   for (int rep = 0; rep < reps + 2; rep++) {
@@ -38,12 +40,12 @@ void run(const char* name, const std::vector<uint32_t>& keys, int end_bit, uint3
       uint32_t* kout = (uint32_t*)(bin + L.keys[side ^ 1]); uint32_t* vout = (uint32_t*)(bin + L.vals[side ^ 1]);
       const int shift = BITS * p, nbits = std::min(BITS, end_bit - shift);
       CK(hipEventRecord(ev[e++]));
-      radix_count_kernel<uint32_t, BITS><<<(L.nchunks + 7) / 8 * 8, SORT_THREADS>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, L.nchunks, nullptr, 0);
+      radix_count_kernel<uint32_t, BITS><<<(nchunks + 7) / 8 * 8, SORT_THREADS>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, nchunks, nullptr, 0, chunk_tiles);
       CK(hipEventRecord(ev[e++]));
-      radix_scan_kernel<<<1 << BITS, 256>>>(chunk_hist, L.nchunks, digit_totals);
+      radix_scan_kernel<<<1 << BITS, 256>>>(chunk_hist, nchunks, digit_totals);
       CK(hipEventRecord(ev[e++]));
       radix_scatter_kernel<uint32_t, BITS, false><<<(L.nblocks + 7) / 8 * 8, SORT_THREADS>>>(kin, (iota && p == 0) ? nullptr : vin, kout, vout, n, shift, dmin, dbits, tile_prefix,
-                                                                          chunk_hist, digit_totals, L.nblocks, L.nchunks, nullptr, 0, nullptr, nullptr, nullptr, nbits);
+                                                                          chunk_hist, digit_totals, L.nblocks, nchunks, nullptr, 0, nullptr, nullptr, nullptr, nbits, chunk_tiles);
       CK(hipEventRecord(ev[e++]));
       side ^= 1;
     }
