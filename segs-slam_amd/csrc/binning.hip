@@ -283,15 +283,14 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {  // number of set bits o
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Digit counts of one pass, in two levels.  A workgroup walks a CHUNK of COUNT_CHUNK consecutive 2048-key tiles and keeps a
+// Digit counts of one pass, in two levels.  A workgroup walks a CHUNK of chunk_tiles (1, 2 or 4: sort_pairs) consecutive 2048-key tiles and keeps a
 // running per-digit count: for every tile it writes the count of each digit in the chunk's EARLIER tiles,
 //     tile_prefix[b * NDIG + d]            (tile-major: one coalesced 1-2 KB row per tile, read back coalesced by the scatter)
 // and at the end the chunk's totals, chunk_hist[d * nchunks + c] (digit-major rows for radix_scan_kernel).  Only that small
-// matrix -- COUNT_CHUNK times fewer columns than one column per tile -- goes through the row scan.  (One column per tile,
+// matrix -- chunk_tiles times fewer columns than one column per tile -- goes through the row scan.  (One column per tile,
 // digit-major, cost 14 x write amplification -- one dword per 64-B line -- and a 10 us scan launch per pass at 3 M Gaussians.)
 // BITS = 8 everywhere except the depth sort, whose 26-27 significant key bits take three 9-bit passes instead of four
 // 8-bit ones (the passes over P keys are bound by their launch count, not by bytes).
-constexpr int COUNT_CHUNK = SORT_COUNT_CHUNK_TILES;   // gs_layout.h
 template <typename K, int BITS>
 __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __restrict__ keys, int n, int shift,
                                                                     uint32_t dmin, int dbits,
@@ -567,6 +566,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 SEGS_INSTANTIATE_RADIX(uint64_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 9)
+SEGS_INSTANTIATE_RADIX(uint32_t, 11)
 #undef SEGS_INSTANTIATE_RADIX
 #define SEGS_INSTANTIATE_AUX(BITS)                                                                                                     \
   template __global__ void radix_scatter_kernel<uint32_t, BITS, true>(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, int, int, \

@@ -238,7 +238,11 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   ordered_block_sums_kernel<<<prefix_wgs, 256, 0, st>>>(P, G.offsets(), nullptr, sums2, G.offsets(), ng_dev);
   }
   LAUNCH_TRY("ordered_block_sums_kernel");
-  const int tpasses = (bit + 7) / 8;
+  // tile-id sort: two 8-bit passes in general; ONE 11-bit pass when the image has at most 2048 tiles and the instances fit
+  // SORT_WIDE_MAX_TILES sort tiles (640x480: three launches and a pass over the instances less)
+  static const bool no_wide = getenv("SEGS_NO_WIDE_DIGIT") != nullptr;   // measurement switch
+  const bool wide_digit = !no_wide && bit <= 11 && BL.nblocks <= SORT_WIDE_MAX_TILES;
+  const int tpasses = wide_digit ? 1 : (bit + 7) / 8;
   const int side = tpasses & 1;
   { PROF(K_SCAN);
   ordered_offsets_kernel<<<prefix_wgs, 256, 0, st>>>(P, sums2, G.offsets(), total_out, ng_dev, first_owner,
@@ -252,7 +256,8 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   }
   LAUNCH_TRY("duplicate_with_keys_kernel");
   // (3)
-  rc = sort_pairs<uint32_t>(bin, BL, n_cap, bit, 0u, 0, st, n_dev, drop_dead);
+  rc = wide_digit ? sort_pairs<uint32_t, 11>(bin, BL, n_cap, bit, 0u, 0, st, n_dev, drop_dead)
+                  : sort_pairs<uint32_t>(bin, BL, n_cap, bit, 0u, 0, st, n_dev, drop_dead);
   if (rc) return rc;
   { PROF(K_RANGES);
   identify_tile_ranges_kernel<<<(n_cap + 256 * RANGE_KEYS_PER_THREAD - 1) / (256 * RANGE_KEYS_PER_THREAD), 256, 0, st>>>(n_cap, (const uint32_t*)(bin + BL.keys[0]), ranges, n_dev,

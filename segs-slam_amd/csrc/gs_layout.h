@@ -8,6 +8,7 @@
 // (SMEM) loads into SGPRs; compact 16-byte bin records for the instance emitter; 64-byte gradient
 // accumulation rows so that one packed float-atomic wave instruction touches a single line.
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 
@@ -103,6 +104,8 @@ constexpr int PREFIX_ROWS_PER_WG = 8;                             // 256-slot ro
 constexpr int EMIT_SLOTS_PER_WG = 512;                            // instance slots per workgroup of duplicate_with_keys_kernel
 constexpr int SORT_COUNT_CHUNK_TILES = 4;                         // tiles per workgroup of radix_count_kernel (binning.hip)
 constexpr int RANGE_KEYS_PER_THREAD = 4;                          // identify_tile_ranges_kernel
+constexpr int SORT_WIDE_DIGITS = 2048;                           // 11-bit digits: tile-id sort of images of at most 2048 tiles, small instance counts
+constexpr int SORT_WIDE_MAX_TILES = 1024;                        // ... up to this many 2048-key sort tiles (2 M instances)
 constexpr int SORT_MAX_DIGITS = 512;                             // count-matrix rows: 8-bit passes use 256 of them, 9-bit passes all
 
 struct BinningLayout {
@@ -122,9 +125,13 @@ inline BinningLayout binning_layout(int R) {
   // per-tile digit offsets inside their chunk, tile-major [nblocks][digits]; per-chunk digit counts, digit-major
   // [digits][nchunks] (scanned in place by radix_scan_kernel)
   b.nchunks = b.nblocks;   // columns ALLOCATED for the chunk totals: one per tile, the smallest chunk sort_pairs may choose
-  b.tile_prefix = o;  o = align_up(o + (size_t)SORT_MAX_DIGITS * (b.nblocks > 0 ? b.nblocks : 1) * 4);
-  b.chunk_hist = o;   o = align_up(o + (size_t)SORT_MAX_DIGITS * (b.nchunks > 0 ? b.nchunks : 1) * 4);
-  b.digit_totals = o; o = align_up(o + SORT_MAX_DIGITS * 4);
+  // count matrices: SORT_MAX_DIGITS rows in general; a sort of at most SORT_WIDE_MAX_TILES tiles may run with SORT_WIDE_DIGITS
+  // (one 11-bit pass over the tile ids of a small image instead of two 8-bit ones)
+  const size_t cols = (size_t)(b.nblocks > 0 ? b.nblocks : 1);
+  const size_t matrix = std::max((size_t)SORT_MAX_DIGITS * cols, (size_t)SORT_WIDE_DIGITS * std::min(cols, (size_t)SORT_WIDE_MAX_TILES));
+  b.tile_prefix = o;  o = align_up(o + matrix * 4);
+  b.chunk_hist = o;   o = align_up(o + matrix * 4);
+  b.digit_totals = o; o = align_up(o + SORT_WIDE_DIGITS * 4);
   b.n_live = o;       o = align_up(o + 4);   // entries left after the first pass dropped the dead keys (sort_pairs)
   b.total = o + ALIGN;
   return b;
