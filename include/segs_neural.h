@@ -46,8 +46,9 @@ typedef struct segs_neural_dims {
  * Any of offsets/counts/ntensors/total may be NULL. */
 int segs_neural_param_layout(const segs_neural_dims* dims, int64_t* offsets, int64_t* counts, int* ntensors, int64_t* total);
 
-/* Bytes of device scratch shared by forward and backward for A anchors (visible list, per-anchor activations kept
- * for the weight-gradient reduction, per-wave partial sums). */
+/* Bytes of device scratch shared by forward and backward for A anchors (visible list, operand images of the MLP weights,
+ * per-workgroup partial sums of the weight gradients; per-anchor scratch rows only for the feature bank's two Linears).
+ * A <= 8 000 000 (the kernels index with 32-bit element offsets; SEGS_ERR_UNSUPPORTED beyond). */
 size_t segs_neural_temp_bytes(const segs_neural_dims* dims, int A);
 
 /* Forward.  anchor (A,3), offset (A,n_offsets,3), anchor_feat (A,32), scaling_log (A,6) [the stored _scaling; exp is
