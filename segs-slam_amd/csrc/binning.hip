@@ -296,13 +296,15 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
                                                                     uint32_t dmin, int dbits,
                                                                     uint32_t* __restrict__ tile_prefix, uint32_t* __restrict__ chunk_hist,
                                                                     int nblocks, int nchunks,
-                                                                    const uint32_t* __restrict__ n_dev, int drop_dead, int chunk_tiles) {
+                                                                    const uint32_t* __restrict__ n_dev, int drop_dead, int chunk_tiles,
+                                                                    int nbits /* significant bits of this pass's digit: key bits at or above the sort's end_bit are ignored */) {
   const KeyMap km{dmin, dbits};
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   constexpr int NDIG = 1 << BITS;
   constexpr int DPT = NDIG / SORT_THREADS;
   __shared__ uint32_t cnt[4][NDIG];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t dmask = (1u << nbits) - 1u;
   uint32_t* my = cnt[wv];
   uint32_t running[DPT];
 #pragma unroll
@@ -347,7 +349,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_count_kernel(const K* __re
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
       const size_t i = wave_base + (size_t)r * 64 + lane;
-      if (i < (size_t)n && !(drop_dead && kreg[r] == (K)DEAD_KEY_OF(K))) atomicAdd(&my[digit_of<BITS>(kreg[r], shift, km)], 1u);
+      if (i < (size_t)n && !(drop_dead && kreg[r] == (K)DEAD_KEY_OF(K))) atomicAdd(&my[digit_of<BITS>(kreg[r], shift, km) & dmask], 1u);
     }
     __syncthreads();
 #pragma unroll
@@ -413,6 +415,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits /* significant bits of this pass's digit */,
     int chunk_tiles /* tiles per chunk of the count kernel that produced the tables */) {
   const KeyMap km{dmin, dbits};
+  const uint32_t dmask = (1u << nbits) - 1u;   // key bits at or above the sort's end_bit are not part of the order
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   constexpr int NDIG = 1 << BITS;
   constexpr int DPT = NDIG / SORT_THREADS;   // consecutive digits per thread in the prefix step (1 or 2)
@@ -467,7 +470,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
     const size_t i = wave_base + (size_t)r * 64 + lane;
     const bool valid = i < (size_t)n && !(drop_dead && key[r] == (K)DEAD_KEY_OF(K));   // dead keys take no rank: dropped here
-    const uint32_t d = valid ? digit_of<BITS>(key[r], shift, km) : 0u;
+    const uint32_t d = valid ? (digit_of<BITS>(key[r], shift, km) & dmask) : 0u;
     const uint64_t vmask = __ballot(valid);
     const uint64_t peers = match_digit<BITS>(d, vmask, nbits);
     const uint32_t below = mbcnt(peers);
@@ -542,9 +545,9 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     if (lp < nout) {
       const K k = s_keys[lp];
 #ifdef ABLATE_SCATTER_LINEAR   // measurement only (tools/ubench_sort_passes.hip): full-line stores, wrong order
-      const size_t gp = tile_base + (size_t)lp + (size_t)(gdelta[digit_of<BITS>(k, shift, km)] & 0);
+      const size_t gp = tile_base + (size_t)lp + (size_t)(gdelta[digit_of<BITS>(k, shift, km) & dmask] & 0);
 #else
-      const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of<BITS>(k, shift, km)]);
+      const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of<BITS>(k, shift, km) & dmask]);
 #endif
 #ifdef ABLATE_SCATTER_NO_STORE
       if (k == (K)0x12345677 && gp == 77) keys_out[gp] = k;
@@ -559,7 +562,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
 
 #define SEGS_INSTANTIATE_RADIX(K, BITS)                                                                                          \
   template __global__ void radix_count_kernel<K, BITS>(const K*, int, int, uint32_t, int, uint32_t*, uint32_t*, int, int,       \
-                                                       const uint32_t*, int, int);                                                  \
+                                                       const uint32_t*, int, int, int);                                                  \
   template __global__ void radix_scatter_kernel<K, BITS, false>(const K*, const uint32_t*, K*, uint32_t*, int, int, uint32_t, int, \
                                                                 const uint32_t*, const uint32_t*, const uint32_t*, int, int,        \
                                                                 const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int);

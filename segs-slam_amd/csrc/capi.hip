@@ -123,8 +123,9 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     const int shift = BITS * p;
     const int drop = drop_dead && p == 0;
     const uint32_t* n_in = (drop_dead && p > 0) ? n_live : n_dev;
+    const int nbits = std::min(BITS, end_bit - shift);   // the last pass may have fewer significant bits than a full digit
     { PROF(K_RADIX_COUNT);
-    radix_count_kernel<K, BITS><<<(nchunks + 7) / 8 * 8, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, nchunks, n_in, drop, chunk_tiles);
+    radix_count_kernel<K, BITS><<<(nchunks + 7) / 8 * 8, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, nchunks, n_in, drop, chunk_tiles, nbits);
     }
     LAUNCH_TRY("radix_count_kernel");
     { PROF(K_RADIX_SCAN);
@@ -132,7 +133,6 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     }
     LAUNCH_TRY("radix_scan_kernel");
     if (iota_vals && p == 0) vin = nullptr;
-    const int nbits = std::min(BITS, end_bit - shift);   // the last pass may have fewer significant bits than a full digit
     const int scatter_grid = (L.nblocks + 7) / 8 * 8;   // a multiple of the XCD count: see radix_scatter_kernel's tile mapping
     { PROF(K_RADIX_SCATTER);
     if constexpr (sizeof(K) == 4) {

@@ -65,7 +65,7 @@ constexpr uint32_t DEAD_KEY = 0xFFFFFFFFu;   // tile-id key of an instance that 
 template <typename K, int BITS>   // K = uint32_t (the pipeline's own sorts) or uint64_t (segs_sort_pairs); BITS per digit: 8 or 9
 __global__ void radix_count_kernel(const K* __restrict__ keys, int n, int shift, uint32_t dmin, int dbits,
                                    uint32_t* __restrict__ tile_prefix, uint32_t* __restrict__ chunk_hist, int nblocks, int nchunks,
-                                   const uint32_t* __restrict__ n_dev, int drop_dead, int chunk_tiles);
+                                   const uint32_t* __restrict__ n_dev, int drop_dead, int chunk_tiles, int nbits);
 __global__ void radix_scan_kernel(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_totals);
 template <typename K, int BITS, bool AUX>
 __global__ void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,

@@ -214,7 +214,10 @@ def test_preprocess_backward_alone_matches_float64_evaluation():
             assert np.all(err <= 1e-5 * np.abs(want) + 4e-6 * np.abs(want).max()), (who, k, float(err.max()), float(np.abs(want).max()))
 
 
-@pytest.mark.parametrize("n,end_bit", [(1, 44), (63, 40), (4096, 44), (4097, 45), (100_000, 44), (1_000_003, 48), (5000, 7)])
+# sizes on both sides of the count kernel's chunk policy (1 / 2 / 4 tiles per chunk at <= 256 / <= 2048 / more sort tiles) and
+# grids that are not multiples of the 8 XCDs the scatter and count kernels deal their tiles to
+@pytest.mark.parametrize("n,end_bit", [(1, 44), (63, 40), (4096, 44), (4097, 45), (100_000, 44), (1_000_003, 48), (5000, 7),
+                                       (524_288, 44), (524_289, 33), (4_194_305, 36)])
 def test_sort_pairs(n, end_bit):
     """Stable LSD radix sort on key bits [0,end_bit) == numpy stable argsort of the masked keys."""
     import ctypes as C

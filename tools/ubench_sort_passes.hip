@@ -40,7 +40,7 @@ void run(const char* name, const std::vector<uint32_t>& keys, int end_bit, uint3
       uint32_t* kout = (uint32_t*)(bin + L.keys[side ^ 1]); uint32_t* vout = (uint32_t*)(bin + L.vals[side ^ 1]);
       const int shift = BITS * p, nbits = std::min(BITS, end_bit - shift);
       CK(hipEventRecord(ev[e++]));
-      radix_count_kernel<uint32_t, BITS><<<(nchunks + 7) / 8 * 8, SORT_THREADS>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, nchunks, nullptr, 0, chunk_tiles);
+      radix_count_kernel<uint32_t, BITS><<<(nchunks + 7) / 8 * 8, SORT_THREADS>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, nchunks, nullptr, 0, chunk_tiles, nbits);
       CK(hipEventRecord(ev[e++]));
       radix_scan_kernel<<<1 << BITS, 256>>>(chunk_hist, nchunks, digit_totals);
       CK(hipEventRecord(ev[e++]));
