@@ -413,7 +413,8 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const uint32_t* __restrict__ chunk_prefix /* chunk_hist after radix_scan_kernel */, const uint32_t* __restrict__ digit_totals,
     int nblocks, int nchunks, const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out,
     const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits /* significant bits of this pass's digit */,
-    int chunk_tiles /* tiles per chunk of the count kernel that produced the tables */) {
+    int chunk_tiles /* tiles per chunk of the count kernel that produced the tables */,
+    int pack_shift /* > 0 with vals_in == nullptr and !AUX: the value of entry i is i | min(aux_in[i], tmax) << pack_shift */) {
   const KeyMap km{dmin, dbits};
   const uint32_t dmask = (1u << nbits) - 1u;   // key bits at or above the sort's end_bit are not part of the order
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
@@ -465,6 +466,9 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     key[r] = valid ? keys_in[i] : (K)0;
     val[r] = vals_in ? (valid ? vals_in[i] : 0u) : (uint32_t)i;
     if (AUX) aux[r] = valid ? aux_in[val[r]] : 0u;
+    // first pass of an index sort with a small payload riding in the value's spare high bits: read here, where entry i IS
+    // Gaussian i, it is a coalesced load; fetched after the sort it is a random 4-byte gather per entry
+    if (!AUX && pack_shift > 0 && valid) val[r] |= min(aux_in[i], (0xFFFFFFFFu >> pack_shift)) << pack_shift;
   }
 #pragma unroll
   for (int r = 0; r < SORT_ITEMS_PER_THREAD; r++) {
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
                                                        const uint32_t*, int, int, int);                                                  \
   template __global__ void radix_scatter_kernel<K, BITS, false>(const K*, const uint32_t*, K*, uint32_t*, int, int, uint32_t, int, \
                                                                 const uint32_t*, const uint32_t*, const uint32_t*, int, int,        \
-                                                                const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int);
+                                                                const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int, int);
 SEGS_INSTANTIATE_RADIX(uint64_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 9)
@@ -574,7 +578,7 @@ SEGS_INSTANTIATE_RADIX(uint32_t, 11)
 #define SEGS_INSTANTIATE_AUX(BITS)                                                                                                     \
   template __global__ void radix_scatter_kernel<uint32_t, BITS, true>(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, int, int, \
                                                                       uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, \
-                                                                      int, int, const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int);
+                                                                      int, int, const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int, int);
 SEGS_INSTANTIATE_AUX(8)
 SEGS_INSTANTIATE_AUX(9)
 #undef SEGS_INSTANTIATE_AUX
@@ -670,16 +674,30 @@ __global__ void __launch_bounds__(256) make_depth_keys_kernel(int P, const BinIn
 // Per-workgroup sums of tiles_touched taken in depth order (feeds ordered_offsets_kernel for the emitter).  `touched` is
 // either already in depth order (`order` == nullptr: it rode along with the depth sort as the scatter's aux payload) or is
 // gathered into depth order here ONCE and left in `sorted_touched` for ordered_offsets_kernel.
+// pack_shift > 0: `order_rw` holds index | min(tiles_touched, tmax) << pack_shift (the payload rode through the depth sort in the
+// values' spare bits, see radix_scatter_kernel); it is taken apart here -- the plain index goes back into order_rw for the
+// emitter, a saturated count (rare: a Gaussian touching more tiles than the spare bits hold) is fetched from `touched`.
 __global__ void __launch_bounds__(256) ordered_block_sums_kernel(int P, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ order,
                                                                  uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched,
-                                                                 const uint32_t* __restrict__ ng_dev /* entries of `order` that are valid, or null = P */) {
+                                                                 const uint32_t* __restrict__ ng_dev /* entries of `order` that are valid, or null = P */,
+                                                                 uint32_t* __restrict__ order_rw, int pack_shift) {
   __shared__ uint32_t wave_sums[4];
   const int ng = ng_dev ? (int)min(*ng_dev, (uint32_t)P) : P;
   uint32_t s = 0;
 #pragma unroll
   for (int r = 0; r < PREFIX_ROWS; r++) {   // PREFIX_ROWS rows of 256 slots per workgroup (ordered_offsets_kernel's cut)
     const int slot = (blockIdx.x * PREFIX_ROWS + r) * 256 + threadIdx.x;
-    const uint32_t v = slot < ng ? (order ? touched[order[slot]] : touched[slot]) : 0u;
+    uint32_t v = 0u;
+    if (slot < ng) {
+      if (pack_shift > 0) {
+        const uint32_t packed = order_rw[slot], idx = packed & ((1u << pack_shift) - 1u);
+        v = packed >> pack_shift;
+        if (v == (0xFFFFFFFFu >> pack_shift)) v = touched[idx];
+        order_rw[slot] = idx;
+      } else {
+        v = order ? touched[order[slot]] : touched[slot];
+      }
+    }
     if (slot < P) sorted_touched[slot] = v;
     s += v;
   }

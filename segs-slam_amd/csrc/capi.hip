@@ -100,7 +100,8 @@ uint32_t getHigherMsb(uint32_t n) {
 template <typename K, int BITS = 8>
 int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t dmin, int dbits, hipStream_t st,
                const uint32_t* n_dev = nullptr, bool drop_dead = false, bool iota_vals = false, const uint32_t* aux_in = nullptr,
-               uint32_t* aux_final = nullptr) {
+               uint32_t* aux_final = nullptr, int pack_shift = 0 /* > 0 (with iota_vals, aux_in, no aux_final): the FIRST pass packs
+               min(aux_in[i], tmax) into the value's bits from pack_shift up; the caller takes the sorted values apart */) {
   if (n <= 0) return SEGS_OK;
   uint32_t* n_live = (uint32_t*)(bin + L.n_live);
   const int passes = (end_bit + BITS - 1) / BITS;
@@ -136,19 +137,20 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     const int scatter_grid = (L.nblocks + 7) / 8 * 8;   // a multiple of the XCD count: see radix_scatter_kernel's tile mapping
     { PROF(K_RADIX_SCATTER);
     if constexpr (sizeof(K) == 4) {
-      if (aux_in && p == passes - 1) {
+      if (aux_in && aux_final && p == passes - 1) {
         radix_scatter_kernel<K, BITS, true><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                         digit_totals, L.nblocks, nchunks, n_in, drop,
-                                                                        drop ? n_live : nullptr, aux_in, aux_final, nbits, chunk_tiles);
+                                                                        drop ? n_live : nullptr, aux_in, aux_final, nbits, chunk_tiles, 0);
       } else {
         radix_scatter_kernel<K, BITS, false><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                          digit_totals, L.nblocks, nchunks, n_in, drop,
-                                                                         drop ? n_live : nullptr, nullptr, nullptr, nbits, chunk_tiles);
+                                                                         drop ? n_live : nullptr, (pack_shift > 0 && p == 0) ? aux_in : nullptr, nullptr,
+                                                                         nbits, chunk_tiles, (p == 0) ? pack_shift : 0);
       }
     } else {
       radix_scatter_kernel<K, BITS, false><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                        digit_totals, L.nblocks, nchunks, n_in, drop,
-                                                                       drop ? n_live : nullptr, nullptr, nullptr, nbits, chunk_tiles);
+                                                                       drop ? n_live : nullptr, nullptr, nullptr, nbits, chunk_tiles, 0);
     }
     }
     LAUNCH_TRY("radix_scatter_kernel");
@@ -223,19 +225,26 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   LAUNCH_TRY("make_depth_keys_kernel");
   // resident mode (K1 wrote the keys): culled Gaussians carry the all-ones key and are dropped by the first depth pass
   const bool drop_culled = depth_keys_ready;
-  // the values are the Gaussian indices 0..P-1 (never materialised); the last pass leaves tiles_touched in depth order in
-  // G.offsets(), where ordered_offsets_kernel turns it into the inclusive offsets in place
-  int rc = nine_bit_depth ? sort_pairs<uint32_t, 9>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), G.offsets())
-                          : sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), G.offsets());
+  // The values are the Gaussian indices 0..P-1 (never materialised); tiles_touched must follow them into depth order for the
+  // emitter's offsets.  It rides in the values' spare high bits, picked up by the FIRST pass (where entry i is Gaussian i: a
+  // coalesced read) and taken apart by ordered_block_sums_kernel; a count that does not fit the spare bits saturates and is
+  // fetched there.  (As a gather by the sorted values in the last pass it cost 44 instead of 21 us at 3 M Gaussians.)  With
+  // fewer than six spare bits (P > 2^26) the last pass gathers it after all.
+  int idx_bits = 1;
+  while (idx_bits < 32 && ((uint64_t)1 << idx_bits) < (uint64_t)P) idx_bits++;
+  const int pack_shift = (32 - idx_bits >= 6) ? idx_bits : 0;
+  uint32_t* aux_final = pack_shift ? nullptr : G.offsets();
+  int rc = nine_bit_depth ? sort_pairs<uint32_t, 9>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), aux_final, pack_shift)
+                          : sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), aux_final, pack_shift);
   if (rc) return rc;
-  const uint32_t* order = (const uint32_t*)(gbin + GL.vals[0]);
+  uint32_t* order = (uint32_t*)(gbin + GL.vals[0]);
   const uint32_t* ng_dev = drop_culled ? (const uint32_t*)(gbin + GL.n_live) : nullptr;
   // (2)
   uint32_t* sums2 = (uint32_t*)(bin + GS.block_sums);
   uint32_t* first_owner = (uint32_t*)(bin + GS.first_owner);
   const int prefix_wgs = (P + 256 * PREFIX_ROWS_PER_WG - 1) / (256 * PREFIX_ROWS_PER_WG);
   { PROF(K_SCAN);
-  ordered_block_sums_kernel<<<prefix_wgs, 256, 0, st>>>(P, G.offsets(), nullptr, sums2, G.offsets(), ng_dev);
+  ordered_block_sums_kernel<<<prefix_wgs, 256, 0, st>>>(P, pack_shift ? G.touched() : G.offsets(), nullptr, sums2, G.offsets(), ng_dev, order, pack_shift);
   }
   LAUNCH_TRY("ordered_block_sums_kernel");
   // tile-id sort: two 8-bit passes in general; ONE 11-bit pass when the image has at most 2048 tiles and the instances fit

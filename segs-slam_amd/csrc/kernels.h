@@ -73,7 +73,7 @@ __global__ void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32
                                      uint32_t dmin, int dbits, const uint32_t* __restrict__ tile_prefix, const uint32_t* __restrict__ chunk_prefix,
                                      const uint32_t* __restrict__ digit_totals, int nblocks, int nchunks,
                                      const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out,
-                                     const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits, int chunk_tiles);
+                                     const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits, int chunk_tiles, int pack_shift);
 __global__ void identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges,
                                             const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ status,
                                             uint32_t* __restrict__ status_mirror, const uint32_t* __restrict__ n_live);
@@ -99,7 +99,7 @@ __global__ void make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, u
                                        uint32_t* __restrict__ vals, uint2* __restrict__ ranges, int num_tiles);
 __global__ void ordered_block_sums_kernel(int P, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ order,
                                           uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched,
-                                          const uint32_t* __restrict__ ng_dev);
+                                          const uint32_t* __restrict__ ng_dev, uint32_t* __restrict__ order_rw, int pack_shift);
 __global__ void point_offsets_kernel(int P, const BinInfo* __restrict__ bin, uint32_t* __restrict__ offsets);
 __global__ void strip_mask_kernel(int n, const uint32_t* __restrict__ vals, uint32_t* __restrict__ out);
 
