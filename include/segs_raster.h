@@ -48,6 +48,13 @@ const char* segs_last_error(void);
  * and gradients are unchanged; the per-tile lists get shorter.  With this flag the full lists are kept, as the
  * reference-shaped segs_rasterize_forward always does (its R, point_list and ranges are the reference's, bit for bit). */
 #define SEGS_RASTER_KEEP_DEAD_INSTANCES 2u
+/* SEGS_RASTER_GATHER_TILES_TOUCHED: take the per-Gaussian tile counts into depth order with a gather in the last depth-sort pass
+ * instead of carrying them in the spare bits of the sort values (what the build does by itself above 2^26 Gaussians, where
+ * fewer than six spare bits are left).  Same results; exists so that the tests keep that path alive. */
+#define SEGS_RASTER_GATHER_TILES_TOUCHED 4u
+/* SEGS_RASTER_TEST_NARROW_PACK (test support): carry the tile counts in only the top two bits of the sort values, so that
+ * nearly every count saturates the packed field and takes the fetch-on-saturation path. */
+#define SEGS_RASTER_TEST_NARROW_PACK 8u
 uint32_t segs_raster_set_flags(uint32_t flags);
 
 /* Resident mode only, per host thread; returns the previous pointer.  When set, segs_rasterize_forward_resident also

@@ -232,7 +232,8 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   // fewer than six spare bits (P > 2^26) the last pass gathers it after all.
   int idx_bits = 1;
   while (idx_bits < 32 && ((uint64_t)1 << idx_bits) < (uint64_t)P) idx_bits++;
-  const int pack_shift = (32 - idx_bits >= 6) ? idx_bits : 0;
+  int pack_shift = (32 - idx_bits >= 6 && !(g_flags & SEGS_RASTER_GATHER_TILES_TOUCHED)) ? idx_bits : 0;
+  if (pack_shift && (g_flags & SEGS_RASTER_TEST_NARROW_PACK)) pack_shift = 30;
   uint32_t* aux_final = pack_shift ? nullptr : G.offsets();
   int rc = nine_bit_depth ? sort_pairs<uint32_t, 9>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), aux_final, pack_shift)
                           : sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), aux_final, pack_shift);

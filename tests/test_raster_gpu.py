@@ -441,3 +441,25 @@ def test_device_gradients_match_independent_float64_autograd():
         nz = want != 0
         pure = float((err[nz] <= 1e-4 * np.abs(want[nz])).mean())
         assert pure >= 0.95, (k, pure)
+
+
+def test_tiles_touched_by_gather_path_gives_the_same_binning():
+    """The build carries tiles_touched into depth order in the spare bits of the depth sort's values; above 2^26 Gaussians (fewer
+    than six spare bits) the last sort pass gathers it instead.  SEGS_RASTER_GATHER_TILES_TOUCHED forces that path: binning and
+    image must not change.  Includes Gaussians whose tile count saturates the packed field (a 640x480 image has 1200 tiles, a
+    4000-Gaussian scene leaves 20 spare bits, so saturation is forced here by scale: every visible Gaussian covers the image)."""
+    from segs_slam_amd import _capi
+    sc = scenes.make_scene(4000, 208, 144, 150.0, 150.0, seed=515, bg=(0.1, 0.1, 0.1))
+    sc.scales *= 3.0
+    outs = []
+    for flags in (0, 4, 8):   # packed (default), gathered by the last pass, packed into two bits (counts above 2 saturate and are fetched)
+        old = _capi.lib().segs_raster_set_flags(flags)
+        try:
+            args, fwd = gpu_forward(sc)
+            outs.append(gpu_state(sc, fwd))
+        finally:
+            _capi.lib().segs_raster_set_flags(old)
+    assert (outs[0]["tiles_touched"] > 2).mean() > 0.2
+    for other in outs[1:]:
+        for k in ("keys", "point_list", "ranges", "n_contrib", "out_color", "tiles_touched"):
+            assert np.array_equal(outs[0][k], other[k]), k
