@@ -163,19 +163,29 @@ def main():
         model = ng.synthetic_model(args.anchors, dims, cam, dev, seed=0)   # replicas must be identical; the keyframe differs per rank
         tstep = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
         tstep.sharded_optimizer = not args.dense_allreduce
+        tstep.single_rank_collectives = args.force_dist
         eng = tstep.engine
         kfs = [ng.Keyframe(view, proj, campos, torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)]
         gts = [torch.rand(3, cam.height, cam.width, device=dev)]
         tstep.keyframe_for = lambda step, n: 0
     elif args.mode == "trainer":
         from segs_slam_amd.gaussian_trainer import TrainerStep, keyframe_tensors
-        tstep = TrainerStep.on_gpu(sc, dev, sharded_optimizer=not args.dense_allreduce)
+        tstep = TrainerStep.on_gpu(sc, dev, sharded_optimizer=not args.dense_allreduce, single_rank_collectives=args.force_dist)
         eng = tstep.engine
         kfs = [keyframe_tensors(cam, dev)]
         gts = [torch.rand(3, cam.height, cam.width, device=dev)]
         tstep.keyframe_for = lambda step, n: 0
     else:
         eng = RasterEngine(sc.P, cam.width, cam.height, dev, resident=not args.sync_forward)
+    raster_ex = raster_params = None
+    if tstep is None and use_dist:
+        # the exchange of a keyframe-parallel step over the flat Gaussian bucket, through the same BucketExchange the trainer
+        # steps use: reduce-scatter of the gradients + all-gather of a parameter-sized bucket (what follows the sharded Adam),
+        # or one dense all-reduce -- the same bytes per link either way
+        from segs_slam_amd.keyframe_parallel import BucketExchange
+        raster_ex = BucketExchange(eng.grads_flat.numel(), dev, None, sharded=not args.dense_allreduce,
+                                   single_rank_collectives=args.force_dist)
+        raster_params = torch.zeros_like(eng.grads_flat) if raster_ex.sharded else None
 
     def step():
         if tstep is not None:
@@ -183,8 +193,10 @@ def main():
             return
         eng.forward(bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy)
         eng.backward(dL)
-        if use_dist:
-            dist.all_reduce(eng.grads_flat)  # sum of per-keyframe parameter gradients over xGMI (RCCL)
+        if raster_ex is not None:     # sum of per-keyframe parameter gradients over xGMI (RCCL)
+            raster_ex.reduce_gradients(eng.grads_flat)
+            if raster_params is not None:
+                raster_ex.gather(raster_params)
 
     def fence():
         if use_dist:
@@ -272,7 +284,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {eng.P_active} Gaussians, {cam.width}x{cam.height}, 1 keyframe per GPU, "
-                                   "fwd+bwd raster" + (", RCCL all-reduce of parameter grads" if world > 1 and tstep is None else "")
+                                   "fwd+bwd raster" + ((", RCCL all-reduce of parameter grads" if args.dense_allreduce else
+                                                        ", RCCL reduce-scatter of parameter grads + all-gather of the parameter bucket")
+                                                       if world > 1 and tstep is None else "")
                                    + (" + L1/SSIM loss + fused Adam" if args.mode == "trainer" else "")
                                    + (f"; anchor-level mapper step: {args.anchors} anchors x 10 offsets -> neural Gaussians "
                                       f"(appearance_dim {args.appearance_dim}, feature bank {'off' if args.no_feat_bank else 'on'}; MLPs fwd+bwd), "

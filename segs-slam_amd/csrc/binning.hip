@@ -677,8 +677,10 @@ __global__ void __launch_bounds__(256) make_depth_keys_kernel(int P, const BinIn
 // pack_shift > 0: `order_rw` holds index | min(tiles_touched, tmax) << pack_shift (the payload rode through the depth sort in the
 // values' spare bits, see radix_scatter_kernel); it is taken apart here -- the plain index goes back into order_rw for the
 // emitter, a saturated count (rare: a Gaussian touching more tiles than the spare bits hold) is fetched from `touched`.
-__global__ void __launch_bounds__(256) ordered_block_sums_kernel(int P, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ order,
-                                                                 uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched,
+// (`touched` and `sorted_touched` are the SAME array on the gather-in-the-last-pass path, read and rewritten slot by slot: no
+// __restrict__ on those two.)
+__global__ void __launch_bounds__(256) ordered_block_sums_kernel(int P, const uint32_t* touched, const uint32_t* __restrict__ order,
+                                                                 uint32_t* __restrict__ block_sums, uint32_t* sorted_touched,
                                                                  const uint32_t* __restrict__ ng_dev /* entries of `order` that are valid, or null = P */,
                                                                  uint32_t* __restrict__ order_rw, int pack_shift) {
   __shared__ uint32_t wave_sums[4];

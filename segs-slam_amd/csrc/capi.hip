@@ -113,7 +113,8 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
   // through the row scan).  Few tiles: one tile per workgroup -- the launch is latency-bound and a 4-tile walk quadruples
   // that latency for nothing (50 k Gaussians at 640x480: 0.206 -> 0.187 ms per step with one tile per chunk).  Many tiles:
   // longer chunks keep the row scan short (3 M Gaussians at 1080p: 1.102 / 1.108 / 1.126 ms with 4 / 2 / 1).
-  static const int chunk_override = [] { const char* e = getenv("SEGS_COUNT_CHUNK"); return e ? atoi(e) : 0; }();
+  // measurement switch; anything but 1, 2 or 4 tiles per chunk is ignored (the tables are sized for chunks of >= 1 tile)
+  static const int chunk_override = [] { const char* e = getenv("SEGS_COUNT_CHUNK"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
   const int chunk_tiles = chunk_override > 0 ? chunk_override : (L.nblocks <= 256 ? 1 : (L.nblocks <= 2048 ? 2 : SORT_COUNT_CHUNK_TILES));
   const int nchunks = (L.nblocks + chunk_tiles - 1) / chunk_tiles;
   for (int p = 0; p < passes; p++) {

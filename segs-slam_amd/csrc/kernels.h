@@ -97,8 +97,8 @@ __global__ void rebuild_keys_kernel(int R, const uint32_t* __restrict__ tile_key
                                     const BinInfo* __restrict__ bin, uint64_t* __restrict__ keys64);
 __global__ void make_depth_keys_kernel(int P, const BinInfo* __restrict__ bin, uint32_t dcull, uint32_t* __restrict__ keys,
                                        uint32_t* __restrict__ vals, uint2* __restrict__ ranges, int num_tiles);
-__global__ void ordered_block_sums_kernel(int P, const uint32_t* __restrict__ touched, const uint32_t* __restrict__ order,
-                                          uint32_t* __restrict__ block_sums, uint32_t* __restrict__ sorted_touched,
+__global__ void ordered_block_sums_kernel(int P, const uint32_t* touched, const uint32_t* __restrict__ order,
+                                          uint32_t* __restrict__ block_sums, uint32_t* sorted_touched,
                                           const uint32_t* __restrict__ ng_dev, uint32_t* __restrict__ order_rw, int pack_shift);
 __global__ void point_offsets_kernel(int P, const BinInfo* __restrict__ bin, uint32_t* __restrict__ offsets);
 __global__ void strip_mask_kernel(int n, const uint32_t* __restrict__ vals, uint32_t* __restrict__ out);

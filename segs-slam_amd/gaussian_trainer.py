@@ -70,6 +70,12 @@ class DeviceStepCount:
         """Steps taken so far (synchronises; for tests and checkpoints)."""
         return int(self.words[self.calls & 1].item())
 
+    def dropped(self) -> int:
+        """Launches the device dropped (guard word set: an iteration whose pass overflowed the resident capacity on some
+        rank): launches issued minus steps taken (synchronises).  The reference never drops an iteration; the loss returned
+        for a dropped one comes from a truncated image and the iteration counter / LR schedule still advanced."""
+        return self.calls - self.value()
+
 
 def field_segments(lrs: Dict[str, float], P: int):
     """(offset, count, lr) of the five per-Gaussian fields inside the flat bucket (raster_engine.FIELDS order)."""
@@ -171,7 +177,8 @@ class TrainerStep:
     render the keyframe, call dL_fn(image) -> (loss, dL_dimage) and leave parameter gradients in `grads_flat`."""
 
     def __init__(self, params_flat: torch.Tensor, P: int, render_backward: Callable, optimizer, opt: OptimizationParams,
-                 grads_flat: torch.Tensor, process_group=None, sharded_optimizer: bool = True):
+                 grads_flat: torch.Tensor, process_group=None, sharded_optimizer: bool = True,
+                 single_rank_collectives: bool = False):
         import inspect
         from .keyframe_parallel import BucketExchange
         assert params_flat.numel() == FLOATS_PER_GAUSSIAN * P and grads_flat.numel() == params_flat.numel()
@@ -179,7 +186,8 @@ class TrainerStep:
         self.params = split_flat(params_flat, P)
         self.render_backward, self.optimizer, self.opt = render_backward, optimizer, opt
         self.pg = process_group
-        self.exchange = BucketExchange(params_flat.numel(), params_flat.device, process_group, sharded=sharded_optimizer)
+        self.exchange = BucketExchange(params_flat.numel(), params_flat.device, process_group, sharded=sharded_optimizer,
+                                       single_rank_collectives=single_rank_collectives)
         self.world, self.rank = self.exchange.world, self.exchange.rank
         self.iteration = 0
         # a backend that knows an overflow word (the HIP engine) takes a hook it calls right after its forward
@@ -228,7 +236,8 @@ class TrainerStep:
 
     # ---- product wiring -------------------------------------------------------------------------------
     @staticmethod
-    def on_gpu(scene, device, opt: Optional[OptimizationParams] = None, process_group=None, sharded_optimizer: bool = True):
+    def on_gpu(scene, device, opt: Optional[OptimizationParams] = None, process_group=None, sharded_optimizer: bool = True,
+               single_rank_collectives: bool = False):
         """HIP raster engine + fused HIP Adam over a segs_slam_amd.scenes.Scene's Gaussians."""
         import numpy as np
         from .raster_engine import RasterEngine
@@ -256,7 +265,7 @@ class TrainerStep:
             return loss
 
         step = TrainerStep(params_flat, P, render_backward, FusedAdam(params_flat.numel(), device, opt), opt, eng.grads_flat,
-                           process_group, sharded_optimizer=sharded_optimizer)
+                           process_group, sharded_optimizer=sharded_optimizer, single_rank_collectives=single_rank_collectives)
         step.engine = eng
         step.fused_loss = FusedL1SSIM(cam.height, cam.width, device, opt.lambda_dssim)
         return step

@@ -38,19 +38,23 @@ class BucketExchange:
 
     ALIGN = 4      # shard boundaries fall on 16-byte boundaries (float4 accesses of the fused Adam)
 
-    def __init__(self, n: int, device, process_group=None, sharded: bool = True):
+    def __init__(self, n: int, device, process_group=None, sharded: bool = True, single_rank_collectives: bool = False):
         self.pg = process_group
         self.world, self.rank = _group_info(process_group)
         self.n = int(n)
         self.device = torch.device(device)
-        self.sharded = bool(sharded) and self.world > 1
+        # single_rank_collectives: issue every collective even with ONE rank in an initialised group (bench.py --force-dist,
+        # tests/test_rccl_single_rank_gpu.py): the reduce_scatter_tensor / all_gather_into_tensor calls of the N > 1 path then
+        # run under the real RCCL backend on a one-GPU box, where they must leave the dense path's parameters
+        self.active = self.world > 1 or (bool(single_rank_collectives) and dist.is_available() and dist.is_initialized())
+        self.sharded = bool(sharded) and self.active
         per = -(-self.n // self.world)
         self.shard_len = -(-per // self.ALIGN) * self.ALIGN
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._flag_work = None
         # gloo (only used to rehearse the N > 1 path, on the CPU or with every rank on one GPU) has no tensor-shaped
         # reduce-scatter / all-gather for device tensors: same result from an all-reduce + slice and a list all-gather
-        self._emulate = (self.world > 1 and self.device.type == "cuda" and dist.get_backend(process_group) != "nccl")
+        self._emulate = (self.active and self.device.type == "cuda" and dist.get_backend(process_group) != "nccl")
         if self.sharded:
             f = dict(dtype=torch.float32, device=self.device)
             # staging in equal-sized shards: the collectives need world * shard_len elements, the bucket has n
@@ -81,7 +85,7 @@ class BucketExchange:
     def reduce_flag_async(self, local_flag: Optional[torch.Tensor]):
         """Start the all-reduce of this step's overflow word (a 1-element int32 device tensor, or None for 0).  With one rank
         the word itself is the guard: no copy, no launch."""
-        if self.world == 1:
+        if not self.active:
             self._local = local_flag
             return
         if local_flag is None:
@@ -92,7 +96,7 @@ class BucketExchange:
 
     def wait_flag(self) -> torch.Tensor:
         """Make the current stream wait for the flag; returns the device word (non-zero: some rank's pass is invalid)."""
-        if self.world == 1:
+        if not self.active:
             if getattr(self, "_local", None) is not None:
                 return self._local
             if not getattr(self, "_zeroed", False):     # (the buffer is never written with one rank)
@@ -105,17 +109,25 @@ class BucketExchange:
         return self.flag
 
     # ---- gradients
-    def reduce_gradients(self, grads: torch.Tensor):
-        """dense: grads <- sum over ranks (in place).  sharded: grads[lo:hi] <- sum over ranks; the rest of the bucket still
-        holds this rank's own contribution and must be cleared by the caller before the next backward accumulates."""
+    def reduce_gradients(self, grads: torch.Tensor, dense: bool = False):
+        """dense (or an unsharded exchange): grads <- sum over ranks (in place).  sharded: grads[lo:hi] <- sum over ranks; the
+        rest of the bucket still holds this rank's own contribution and must be cleared by the caller before the next
+        backward accumulates.  `dense=True` is for the steps whose shard partition changes between this call and the
+        optimizer (a densification that re-sizes the bucket): every element must then hold the sum, whoever updates it."""
         assert grads.numel() == self.n
-        if self.world == 1:
+        if not self.active:
             return
-        if not self.sharded:
+        if dense or not self.sharded:
             dist.all_reduce(grads, group=self.pg)
             return
         if self._emulate:
-            dist.all_reduce(grads, group=self.pg)       # (leaves the whole bucket reduced; the caller clears it anyway)
+            # same RESULT as the reduce-scatter below, outside the shard included: there the bucket keeps this rank's own
+            # contribution (an emulation that left the full sum everywhere would hide a step reading outside its shard)
+            lo, hi = self.shard_range()
+            own = grads.clone()
+            dist.all_reduce(grads, group=self.pg)
+            own[lo:hi] = grads[lo:hi]
+            grads.copy_(own)
             return
         src = grads
         if self._send is not None:

@@ -343,6 +343,7 @@ class ScaffoldTrainerStep:
         # N > 1: reduce-scatter -> Adam on this rank's shard -> all-gather (keyframe_parallel.BucketExchange); False = dense
         # all-reduce and a full Adam on every rank
         self.sharded_optimizer = True
+        self.single_rank_collectives = False   # keyframe_parallel.BucketExchange: run the collectives with one rank too
         self.densifier = None            # densify.AnchorDensifier, see enable_densification()
         self.densify_generator = None
         self.keyframe_selector = None    # keyframe_window.SlidingWindowKeyframes: the mapper's walk instead of round-robin
@@ -525,7 +526,9 @@ class ScaffoldTrainerStep:
             else:
                 raise RuntimeError("resident rasterizer kept overflowing its re-sized scratch")
         guard = C.c_void_p(flag.data_ptr())
-        ex.reduce_gradients(self.model.grads)
+        # A densification may re-size the bucket (reserve() moves the MLP block), so the shard partition the optimizer clips
+        # to below is not the one a reduce-scatter would have summed for: every element gets the full sum on those steps.
+        ex.reduce_gradients(self.model.grads, dense=adjust_now)
         adjusted = False
         if in_stat_window:
             d.training_statis(self.neural, self.visible_radii, self.engine.radii, self.engine.dL_dmean2D, guard,
@@ -558,12 +561,18 @@ class ScaffoldTrainerStep:
             self.model.grads.zero_()      # outside this rank's shard the bucket still holds its own contribution
         return loss
 
+    def dropped_steps(self) -> int:
+        """Iterations the device dropped so far (overflowed resident capacity on some rank; synchronises).  Their returned
+        loss is invalid and their keyframe use was still counted; the reference never drops an iteration."""
+        return self._mlp_count.dropped()
+
     def _exchange(self):
         """The step's BucketExchange over the model's flat bucket (rebuilt when densification re-sized the bucket)."""
         from .keyframe_parallel import BucketExchange
         ex = getattr(self, "_ex", None)
         if ex is None or ex.n != self.model.params.numel():
-            ex = self._ex = BucketExchange(self.model.params.numel(), self.model.device, self.pg, sharded=self.sharded_optimizer)
+            ex = self._ex = BucketExchange(self.model.params.numel(), self.model.device, self.pg, sharded=self.sharded_optimizer,
+                                           single_rank_collectives=self.single_rank_collectives)
         return ex
 
 

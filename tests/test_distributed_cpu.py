@@ -153,3 +153,54 @@ def test_ssim_matches_reference_formula_on_cpu():
     ref = (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 ** 2 + mu2 ** 2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
     got = float(loss_utils.ssim(torch.from_numpy(a), torch.from_numpy(b)))
     assert abs(got - ref) < 2e-5
+
+
+def _resize_worker(rank, world, port, out_dir):
+    """A densification re-sizes the bucket between the gradient exchange and the optimizer: the block that sits at the END
+    of the bucket (the MLPs) moves, so the shard that updates an element afterwards is not the shard whose reduce-scatter
+    summed it.  `reduce_gradients(dense=True)` must therefore leave the full sum EVERYWHERE; the plain sharded call must
+    leave it in the rank's own shard only (outside it the rank's own contribution stays -- the caller clears it)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segs_slam_amd.keyframe_parallel import BucketExchange
+    n_rows, mlp = 10, 1501                        # 71 floats per anchor row, then the MLP block: it spans both shards
+    n_old = 71 * n_rows + mlp
+    own = torch.arange(n_old, dtype=torch.float32) * (rank + 1)          # rank r contributes (r + 1) * i
+    total = torch.arange(n_old, dtype=torch.float32) * 3.0
+    ex = BucketExchange(n_old, "cpu", None, sharded=True)
+    assert ex.sharded and not ex._emulate
+    lo, hi = ex.shard_range()
+    g = own.clone()
+    ex.reduce_gradients(g)
+    assert torch.equal(g[lo:hi], total[lo:hi])
+    outside = torch.ones(n_old, dtype=torch.bool)
+    outside[lo:hi] = False
+    assert torch.equal(g[outside], own[outside]), "outside its shard a rank keeps its own contribution"
+    g = own.clone()
+    ex.reduce_gradients(g, dense=True)
+    assert torch.equal(g, total)
+    # the bucket grows by 50 anchor rows: the MLP block shifts by 71 * 50 floats and the shard cut with it
+    n_new = 71 * (n_rows + 50) + mlp
+    moved = torch.zeros(n_new)
+    moved[n_new - mlp:] = g[n_old - mlp:]
+    ex2 = BucketExchange(n_new, "cpu", None, sharded=True)
+    lo2, hi2 = ex2.shard_range()
+    a, b = max(lo2, n_new - mlp), max(hi2, max(lo2, n_new - mlp))     # this rank's part of the moved MLP block (may be empty)
+    assert torch.equal(moved[a:b], total[n_old - mlp:][a - (n_new - mlp):b - (n_new - mlp)])
+    # ... and with the plain sharded reduce the same elements would have been wrong on some rank (what the fix is for)
+    g = own.clone()
+    ex.reduce_gradients(g)
+    moved_bad = torch.zeros(n_new)
+    moved_bad[n_new - mlp:] = g[n_old - mlp:]
+    bad = not torch.equal(moved_bad[a:b], total[n_old - mlp:][a - (n_new - mlp):b - (n_new - mlp)])
+    np.save(os.path.join(out_dir, f"bad_{rank}.npy"), np.array([bad, lo, hi, lo2, hi2]))
+    dist.destroy_process_group()
+
+
+def test_dense_reduce_survives_a_bucket_resize_between_exchange_and_optimizer(tmp_path):
+    port = 29500 + (os.getpid() % 2000) + 13
+    mp.spawn(_resize_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(tmp_path / f"bad_{k}.npy") for k in range(2)]
+    assert r[0][0] or r[1][0], "the scenario must exercise elements that change owner"
