@@ -55,6 +55,9 @@ const char* segs_last_error(void);
 /* SEGS_RASTER_TEST_NARROW_PACK (test support): carry the tile counts in only the top two bits of the sort values, so that
  * nearly every count saturates the packed field and takes the fetch-on-saturation path. */
 #define SEGS_RASTER_TEST_NARROW_PACK 8u
+/* SEGS_RASTER_UNFUSED_BINNING (A/B measurements and tests): fill the range table and the status words with their own kernel
+ * (identify_tile_ranges) after the tile-id sort instead of inside its last scatter pass.  Same results. */
+#define SEGS_RASTER_UNFUSED_BINNING 16u
 uint32_t segs_raster_set_flags(uint32_t flags);
 
 /* Resident mode only, per host thread; returns the previous pointer.  When set, segs_rasterize_forward_resident also

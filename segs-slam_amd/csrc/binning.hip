@@ -175,15 +175,97 @@ __global__ void __launch_bounds__(256) ordered_offsets_kernel(int P, const uint3
   if (total_out && blockIdx.x == gridDim.x - 1 && tid == 0) total_out[0] = carry;   // R = inclusive total
 }
 
-// The emitter is parallel over OUTPUT slots, not over Gaussians: workgroup b owns instances [b*512, (b+1)*512) of the
-// unsorted list, takes the Gaussians (in depth order) that own them from the first_owner table the prefix kernel left
-// (a 64-ary search in the inclusive offsets before: eight dependent loads per workgroup), stages those owners once in LDS
-// and lets every lane resolve its slot with an LDS binary search ("load-balanced search").
-// A Gaussian covering thousands of tiles is thereby spread over many workgroups instead of serialising one wave,
-// and all 12-byte pairs leave as coalesced stores.
-// 512 slots: 25 KB of LDS per workgroup -> 6 workgroups per CU.  1024 slots (49 KB, 3 per CU) left the LDS binary searches
-// without cover: 40 us against 34 us at 2.6 M instances; 256 slots pay the two global owner searches too often (40 us).
+// The emitter is parallel over OUTPUT slots, not over Gaussians: a sub-batch is 512 consecutive instance slots of the unsorted
+// (depth-ordered) list; the Gaussians (in depth order) that own them come from the first_owner table the prefix kernel left
+// (a 64-ary search in the inclusive offsets before: eight dependent loads per workgroup), are staged once in LDS, and every
+// thread resolves the owners of its TWO CONSECUTIVE slots and writes the two 8-byte pairs as one coalesced store each.
+// A Gaussian covering thousands of tiles is thereby spread over many workgroups instead of serialising one wave.
+//
+// What bounds it (round 3 measurements, 3 M Gaussians: 7.9 M slots, 2.1 M owners, 66 us): the 2.1 M gathers of emit records
+// in depth order.  tools/ubench_gather.hip: 2.1 M random gathers from a freshly written table take 43-47 us whether a record
+// is 16, 32, 64 or 128 bytes -- a gather pulls one whole 128-byte line, ~47 G lines/s chip-wide -- so 45 us is the floor
+// of ANY kernel that visits the records in depth order, and carrying them through the depth sort instead costs more.
+// Tried against the other 20 us and not kept: (i) the whole load chain of a sub-batch (first_owner -> order / offsets ->
+// record) software-pipelined across the 8-16 sub-batches of a chunk-walking workgroup that also leaves the first tile-id
+// pass's count tables (emit_count_kernel, removed again): 92 us against 66 + 15 for this kernel plus radix_count_kernel --
+// 965-1930 fat workgroups keep fewer gathers in flight than 15 400 small ones, whatever the chunk size (PMC: 2.4 waves per
+// SIMD resident on average against 5.2); (ii) fewer instructions: the owner of a slot used to be found by an LDS binary
+// search (8 dependent rounds) and the tile row by an IEEE division; now every owner drops its index at the position of its
+// first slot into a 512-entry LDS array and a running maximum over the slots (max of the thread's two entries, a wave64 scan,
+// four wave totals) gives every slot its owner, and the row comes from one v_rcp_f32 plus the two corrections that were
+// there anyway: 12 % fewer VALU instructions, 66.6 -> 65.6 us.  Kept because it is the simpler code.
+// 512 slots: 24 KB of LDS per workgroup -> 6 workgroups per CU.
 constexpr int EMIT_SLOTS = EMIT_SLOTS_PER_WG;   // gs_layout.h
+static_assert(EMIT_SLOTS == 2 * 256, "two consecutive slots per thread");
+struct EmitLds {
+  uint32_t excl[EMIT_SLOTS + 2];   // first slot of owner k (= inclusive offset of the Gaussian before it); n_own + 1 entries
+  uint32_t idx[EMIT_SLOTS + 1];    // Gaussian index of owner k
+  uint2 bin[EMIT_SLOTS + 1];       // rect min (x | y << 16), rect width in tiles
+  float4 geo0[EMIT_SLOTS + 1];     // x, y, A, B
+  float2 geo1[EMIT_SLOTS + 1];     // C, k = inflated 2 ln(255 o) (or -1: no pixel can reach alpha >= 1/255)
+  uint32_t mark[EMIT_SLOTS];       // 1 << 10 | owner, at the owner's first slot (0 = no owner starts here)
+  uint32_t wave_max[4];
+};
+constexpr uint32_t EMIT_OWNER_MASK = 1023u;
+
+__device__ __forceinline__ void emit_stage_owner(EmitLds& L, int k, uint32_t idx, const float4& e0, const float4& e1) {
+  // e0, e1: the 32-byte emit record  x y A B | C opacity rect_min rect_max
+  const uint32_t rmin = __float_as_uint(e1.z), rmax = __float_as_uint(e1.w);
+  L.idx[k] = idx;
+  L.bin[k] = make_uint2(rmin, (rmax & 0xFFFFu) - (rmin & 0xFFFFu));
+  const float op = e1.y;
+  L.geo0[k] = e0;
+  L.geo1[k] = make_float2(e1.x, (op * 255.0f > 1.0f) ? 2.0f * __logf(255.0f * op) * 1.0001f + 1e-3f : -1.0f);
+}
+// owner k's first slot is `start`; its mark goes to the slot's position inside the sub-batch [s0, s0 + 512) (owner 0 may
+// start before s0: position 0; an owner that starts behind the sub-batch -- the next sub-batch's first -- leaves no mark)
+__device__ __forceinline__ void emit_mark_owner(uint32_t* mark, int k, uint32_t start, uint32_t s0, uint32_t tag) {
+  const uint32_t pos = start > s0 ? start - s0 : 0u;
+  if (pos < (uint32_t)EMIT_SLOTS) mark[pos] = (tag << 10) | (uint32_t)k;
+}
+// Owners of slots 2 tid and 2 tid + 1 of the sub-batch from the marks (first half: up to the wave totals; a barrier between
+// the halves is the caller's, which has other LDS writes to publish with it).
+__device__ __forceinline__ void emit_scan_begin(EmitLds& L, const uint32_t* mark, int tid, uint32_t& m0, uint32_t& incl) {
+  const uint2 m = *reinterpret_cast<const uint2*>(mark + 2 * tid);
+  m0 = m.x;
+  uint32_t x = max(m.x, m.y);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off, 64);
+    if ((tid & 63) >= off) x = max(x, y);
+  }
+  incl = x;
+  if ((tid & 63) == 63) L.wave_max[tid >> 6] = x;
+}
+__device__ __forceinline__ void emit_scan_end(const EmitLds& L, int tid, uint32_t m0, uint32_t incl, int& g0, int& g1) {
+  const int wv = tid >> 6;
+  uint32_t before = __shfl_up(incl, 1, 64);
+  if ((tid & 63) == 0) before = 0u;
+  for (int w = 0; w < wv; w++) before = max(before, L.wave_max[w]);
+  g0 = (int)(max(before, m0) & EMIT_OWNER_MASK);
+  g1 = (int)(max(before, incl) & EMIT_OWNER_MASK);
+}
+// One (tile | quadrant mask, Gaussian) instance: slot j of owner g.
+__device__ __forceinline__ void emit_instance(const EmitLds& L, int g, uint32_t j, uint32_t gx, int mark_dead, uint32_t& key, uint32_t& val) {
+  const uint2 bb = L.bin[g];
+  const uint32_t t = j - L.excl[g];
+  const uint32_t minx = bb.x & 0xFFFFu, miny = bb.x >> 16, w = bb.y;
+  // row = t / w: the reciprocal is good to an ulp and t < 2^24, so the estimate is off by at most one -- the corrections
+  uint32_t q = (uint32_t)((float)t * __builtin_amdgcn_rcpf((float)w));
+  if (q * w > t) q--;
+  if ((q + 1) * w <= t) q++;
+  const uint32_t ty = miny + q, tx = minx + (t - q * w);
+  const float4 ge0 = L.geo0[g];
+  const float2 ge1 = L.geo1[g];
+  const float k = ge1.y;
+  // vertex positions -B/C x and -B/A y of the two line minima: a reciprocal is exact enough -- at a minimum the form is flat
+  // in the position, and k is inflated (quadrant_mask)
+  const uint32_t mask = k > 0.f ? quadrant_mask(ge0.x, ge0.y, ge0.z, ge0.w, ge1.x, k, -ge0.w * __builtin_amdgcn_rcpf(ge1.x),
+                                                -ge0.w * __builtin_amdgcn_rcpf(ge0.z), (float)(tx * TILE_X), (float)(ty * TILE_Y)) : 0u;
+  key = (mark_dead && mask == 0u) ? DEAD_KEY : ty * gx + tx;   // tile id only: depth order is already the emission order
+  val = L.idx[g] | (mask << ID_BITS);
+}
+
 __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     int P, int R, const float* __restrict__ emit /* 32-byte emit records, gs_layout.h */, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ incl, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
@@ -191,13 +273,10 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     int mark_dead /* instances that reach no quadrant get DEAD_KEY: the first tile-id pass drops them */,
     const uint32_t* __restrict__ ng_dev /* resident mode: Gaussians left in `order` after the depth sort dropped the culled ones */,
     const uint32_t* __restrict__ first_owner /* ordered_offsets_kernel: owner of slot k * EMIT_SLOTS */) {
-  __shared__ uint32_t s_incl[EMIT_SLOTS + 1];
+  __shared__ EmitLds L;
   if (n_dev) R = (int)min(*n_dev, (uint32_t)R);
   if (ng_dev) P = (int)min(*ng_dev, (uint32_t)P);
   if (P <= 0) return;
-  __shared__ uint32_t s_idx[EMIT_SLOTS + 1];
-  __shared__ uint2 s_bin[EMIT_SLOTS + 1];                              // rect min (x | y << 16), rect max
-  __shared__ __attribute__((aligned(16))) float s_geo[EMIT_SLOTS + 1][8];  // x, y, A, B | C, k, -B/C, -B/A
   const int tid = threadIdx.x;
   const uint32_t s0 = blockIdx.x * EMIT_SLOTS, s1 = min((uint32_t)R, s0 + EMIT_SLOTS);
   if (s0 >= (uint32_t)R) return;
@@ -211,40 +290,34 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
   // reached the culled key (the step is then flagged through status[2] and redone) can leave zero-instance owners between
   // binned ones: the clamp keeps that flagged launch inside the LDS staging arrays.
   const int n_own = min(min(lo, P - 1) - g_lo + 1, EMIT_SLOTS + 1);
-  const uint32_t excl0 = g_lo == 0 ? 0u : incl[g_lo - 1];
-  for (int k = tid; k < n_own; k += 256) {
-    const uint32_t idx = order[g_lo + k];
-    const float4* e = reinterpret_cast<const float4*>(emit + (size_t)idx * EMIT_DWORDS);   // ONE 32-byte gather per owner
-    const float4 e0 = e[0], e1 = e[1];   // x y A B | C opacity rect_min rect_max
-    s_idx[k] = idx; s_incl[k] = incl[g_lo + k]; s_bin[k] = make_uint2(__float_as_uint(e1.z), __float_as_uint(e1.w));
-    const float op = e1.y;
-    float* g = s_geo[k];
-    g[0] = e0.x; g[1] = e0.y; g[2] = e0.z; g[3] = e0.w; g[4] = e1.x;
-    g[5] = (op * 255.0f > 1.0f) ? 2.0f * __logf(255.0f * op) * 1.0001f + 1e-3f : -1.0f;
-    g[6] = -e0.w / e1.x; g[7] = -e0.w / e0.z;   // once per Gaussian instead of once per instance
+  *reinterpret_cast<uint2*>(&L.mark[2 * tid]) = make_uint2(0u, 0u);
+  __syncthreads();
+  for (int k = tid; k <= n_own; k += 256) {
+    const uint32_t start = (g_lo + k == 0) ? 0u : incl[g_lo + k - 1];
+    L.excl[k] = start;
+    if (k < n_own) {
+      emit_mark_owner(L.mark, k, start, s0, 1u);
+      const uint32_t idx = order[g_lo + k];
+      const float4* e = reinterpret_cast<const float4*>(emit + (size_t)idx * EMIT_DWORDS);   // ONE 32-byte gather per owner
+      const float4 e0 = e[0], e1 = e[1];
+      emit_stage_owner(L, k, idx, e0, e1);
+    }
   }
   __syncthreads();
-#pragma unroll
-  for (int it = 0; it < EMIT_SLOTS / 256; it++) {
-    const uint32_t j = s0 + it * 256 + tid;
-    if (j >= s1) break;
-    // owner = first k with s_incl[k] > j
-    int a = 0, b2 = n_own - 1;
-    while (a < b2) { const int mid = (a + b2) >> 1; if (s_incl[mid] > j) b2 = mid; else a = mid + 1; }
-    const int g = a;
-    const uint32_t excl = g == 0 ? excl0 : s_incl[g - 1];
-    const uint2 bb = s_bin[g];
-    const uint32_t t = j - excl;
-    const uint32_t minx = bb.x & 0xFFFFu, miny = bb.x >> 16, w = (bb.y & 0xFFFFu) - minx;
-    uint32_t q = (uint32_t)((float)t / (float)w);
-    if (q * w > t) q--;
-    if ((q + 1) * w <= t) q++;
-    const uint32_t ty = miny + q, tx = minx + (t - q * w);
-    const float4 ge0 = *reinterpret_cast<const float4*>(&s_geo[g][0]), ge1 = *reinterpret_cast<const float4*>(&s_geo[g][4]);
-    const float k = ge1.y;
-    const uint32_t mask = k > 0.f ? quadrant_mask(ge0.x, ge0.y, ge0.z, ge0.w, ge1.x, k, ge1.z, ge1.w, (float)(tx * TILE_X), (float)(ty * TILE_Y)) : 0u;
-    keys[j] = (mark_dead && mask == 0u) ? DEAD_KEY : ty * gx + tx;   // tile id only: depth order is already the emission order
-    vals[j] = s_idx[g] | (mask << ID_BITS);
+  uint32_t m0, inc;
+  emit_scan_begin(L, L.mark, tid, m0, inc);
+  __syncthreads();
+  int g0, g1;
+  emit_scan_end(L, tid, m0, inc, g0, g1);
+  const uint32_t j = s0 + 2 * tid;
+  uint32_t k0 = 0u, v0 = 0u, k1 = 0u, v1 = 0u;
+  if (j < s1) emit_instance(L, g0, j, gx, mark_dead, k0, v0);
+  if (j + 1 < s1) emit_instance(L, g1, j + 1, gx, mark_dead, k1, v1);
+  if (j + 1 < s1) {
+    *reinterpret_cast<uint2*>(keys + j) = make_uint2(k0, k1);
+    *reinterpret_cast<uint2*>(vals + j) = make_uint2(v0, v1);
+  } else if (j < s1) {
+    keys[j] = k0; vals[j] = v0;
   }
 }
 
@@ -414,9 +487,23 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     int nblocks, int nchunks, const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out,
     const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits /* significant bits of this pass's digit */,
     int chunk_tiles /* tiles per chunk of the count kernel that produced the tables */,
-    int pack_shift /* > 0 with vals_in == nullptr and !AUX: the value of entry i is i | min(aux_in[i], tmax) << pack_shift */) {
+    int pack_shift /* > 0 with vals_in == nullptr and !AUX: the value of entry i is i | min(aux_in[i], tmax) << pack_shift */,
+    uint2* __restrict__ ranges_out /* LAST pass of the tile-id sort: the range table (K9) is filled here, see below */,
+    uint32_t* __restrict__ status, uint32_t* __restrict__ status_mirror /* resident mode, with ranges_out: the status words */,
+    int write_keys /* 0: nobody reads the sorted keys of this (last) pass */) {
   const KeyMap km{dmin, dbits};
   const uint32_t dmask = (1u << nbits) - 1u;   // key bits at or above the sort's end_bit are not part of the order
+  if (ranges_out != nullptr && status != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    // resident mode (what identify_tile_ranges_kernel does on the unfused path): overflow word and the host-mapped mirror.
+    // status[0] = instances emitted (ordered_offsets_kernel), `n` = capacity, *n_dev = entries this pass sorts
+    const uint32_t ntot = status[0];
+    const uint32_t over = (ntot > (uint32_t)n || status[2] != 0u) ? 1u : 0u;   // status[2]: depth outside the key range (K1)
+    status[2] = 0u;
+    status[3] = over;
+    const uint32_t live = min(n_dev ? *n_dev : ntot, min(ntot, (uint32_t)n));
+    status[1] = live;
+    if (status_mirror) { status_mirror[0] = ntot; status_mirror[1] = live; status_mirror[3] = over; }
+  }
   if (n_dev) n = (int)min(*n_dev, (uint32_t)n);
   constexpr int NDIG = 1 << BITS;
   constexpr int DPT = NDIG / SORT_THREADS;   // consecutive digits per thread in the prefix step (1 or 2)
@@ -557,9 +644,23 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
       if (k == (K)0x12345677 && gp == 77) keys_out[gp] = k;
       continue;
 #endif
-      keys_out[gp] = k;
+      if (write_keys) keys_out[gp] = k;
       vals_out[gp] = s_vals[lp];
       if (AUX) aux_out[gp] = s_aux[lp];
+      if constexpr (sizeof(K) == 4) {
+        // K9 fused into the last pass (rasterizer_impl.cu:116-138).  The input of an LSD pass is sorted on all lower bits, so
+        // after the reorder by this pass's digit the tile's keys stand in LDS in full-key order: the neighbours in LDS tell
+        // where a tile id starts and ends INSIDE this sort tile, and since a stable sort keeps the sort tiles' order per key,
+        // the list of tile id t is [min over sort tiles of its first position, max of its last + 1).  Two integer atomics per
+        // (sort tile, tile id) pair -- a sort tile of the last pass holds a few dozen distinct ids -- instead of a pass over
+        // all sorted keys.  The table starts out as {0xFFFFFFFF, 0} per tile (K1 / make_depth_keys_kernel); an id without
+        // instances keeps that, which every reader takes as empty (start >= end).
+        if (ranges_out != nullptr) {
+          const K prev = lp > 0 ? s_keys[lp - 1] : ~k, next = lp + 1 < nout ? s_keys[lp + 1] : ~k;
+          if (k != prev) atomicMin(&ranges_out[k].x, (uint32_t)gp);
+          if (k != next) atomicMax(&ranges_out[k].y, (uint32_t)gp + 1u);
+        }
+      }
     }
   }
 }
@@ -569,7 +670,8 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
                                                        const uint32_t*, int, int, int);                                                  \
   template __global__ void radix_scatter_kernel<K, BITS, false>(const K*, const uint32_t*, K*, uint32_t*, int, int, uint32_t, int, \
                                                                 const uint32_t*, const uint32_t*, const uint32_t*, int, int,        \
-                                                                const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int, int);
+                                                                const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int, int, \
+                                                                uint2*, uint32_t*, uint32_t*, int);
 SEGS_INSTANTIATE_RADIX(uint64_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 8)
 SEGS_INSTANTIATE_RADIX(uint32_t, 9)
@@ -578,7 +680,8 @@ SEGS_INSTANTIATE_RADIX(uint32_t, 11)
 #define SEGS_INSTANTIATE_AUX(BITS)                                                                                                     \
   template __global__ void radix_scatter_kernel<uint32_t, BITS, true>(const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, int, int, \
                                                                       uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, \
-                                                                      int, int, const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int, int);
+                                                                      int, int, const uint32_t*, int, uint32_t*, const uint32_t*, uint32_t*, int, int, int, \
+                                                                      uint2*, uint32_t*, uint32_t*, int);
 SEGS_INSTANTIATE_AUX(8)
 SEGS_INSTANTIATE_AUX(9)
 #undef SEGS_INSTANTIATE_AUX
@@ -665,7 +768,7 @@ __global__ void __launch_bounds__(256) make_depth_keys_kernel(int P, const BinIn
                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                                               uint2* __restrict__ ranges, int num_tiles) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  for (int t = i; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // rasterizer_impl.cu:310
+  for (int t = i; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(RANGE_EMPTY_START, 0u);   // rasterizer_impl.cu:310 ({0,0} there)
   if (i >= P) return;
   const uint4 b = reinterpret_cast<const uint4*>(bin)[i];
   keys[i] = b.w ? b.x : dcull;   // culled Gaussians sort strictly after every visible one
@@ -735,6 +838,12 @@ __global__ void __launch_bounds__(1024) point_offsets_kernel(int P, const BinInf
     if (tid == 1023) carry_s = carry + wbase + x;
     __syncthreads();
   }
+}
+
+// Range table as the reference defines it: tiles without instances read {0, 0} (kernels.h RANGE_EMPTY_START).
+__global__ void __launch_bounds__(256) normalize_ranges_kernel(int num_tiles, uint2* __restrict__ ranges) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < num_tiles && ranges[t].y == 0u) ranges[t].x = 0u;
 }
 
 // point_list as the reference defines it: strip the quadrant mask from the sorted values.

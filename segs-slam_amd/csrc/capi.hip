@@ -97,11 +97,29 @@ uint32_t getHigherMsb(uint32_t n) {
 // iota_vals: the values of the input are 0..n-1 and are not read (nor need they have been written).
 // aux_in / aux_final (32-bit keys only): the LAST pass also writes aux_final[position] = aux_in[value] (a gather by the
 // sorted values, fused into the scatter).
+// Tiles per chunk of the count kernel (a workgroup walks its chunk's tiles one after the other; only the chunk totals go
+// through the row scan).  Few tiles: one tile per workgroup -- the launch is latency-bound and a 4-tile walk quadruples
+// that latency for nothing (50 k Gaussians at 640x480: 0.206 -> 0.187 ms per step with one tile per chunk).  Many tiles:
+// longer chunks keep the row scan short (3 M Gaussians at 1080p: 1.102 / 1.108 / 1.126 ms with 4 / 2 / 1).
+int count_chunk_tiles(int nblocks) {
+  // measurement switch; anything but 1, 2 or 4 tiles per chunk is ignored (the tables are sized for chunks of >= 1 tile)
+  static const int chunk_override = [] { const char* e = getenv("SEGS_COUNT_CHUNK"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+  return chunk_override > 0 ? chunk_override : (nblocks <= 256 ? 1 : (nblocks <= 2048 ? 2 : SORT_COUNT_CHUNK_TILES));
+}
+// What the caller of the tile-id sort fuses into its last pass (run_binning).
+struct SortFusion {
+  uint2* ranges = nullptr;           // non-null: the LAST pass fills the range table (K9) -- only valid with >= 2 passes or a
+                                     // single pass whose digit is the whole key (see radix_scatter_kernel)
+  uint32_t* status = nullptr;        // resident mode, with `ranges`: the last pass also writes the status words ...
+  uint32_t* status_mirror = nullptr; // ... and their host-mapped mirror
+  bool keep_sorted_keys = true;      // false: the last pass does not store the sorted keys (nobody reads them)
+};
 template <typename K, int BITS = 8>
 int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t dmin, int dbits, hipStream_t st,
                const uint32_t* n_dev = nullptr, bool drop_dead = false, bool iota_vals = false, const uint32_t* aux_in = nullptr,
                uint32_t* aux_final = nullptr, int pack_shift = 0 /* > 0 (with iota_vals, aux_in, no aux_final): the FIRST pass packs
-               min(aux_in[i], tmax) into the value's bits from pack_shift up; the caller takes the sorted values apart */) {
+               min(aux_in[i], tmax) into the value's bits from pack_shift up; the caller takes the sorted values apart */,
+               const SortFusion& fuse = SortFusion()) {
   if (n <= 0) return SEGS_OK;
   uint32_t* n_live = (uint32_t*)(bin + L.n_live);
   const int passes = (end_bit + BITS - 1) / BITS;
@@ -109,13 +127,7 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
   uint32_t* tile_prefix = (uint32_t*)(bin + L.tile_prefix);
   uint32_t* chunk_hist = (uint32_t*)(bin + L.chunk_hist);
   uint32_t* digit_totals = (uint32_t*)(bin + L.digit_totals);
-  // Tiles per chunk of the count kernel (a workgroup walks its chunk's tiles one after the other; only the chunk totals go
-  // through the row scan).  Few tiles: one tile per workgroup -- the launch is latency-bound and a 4-tile walk quadruples
-  // that latency for nothing (50 k Gaussians at 640x480: 0.206 -> 0.187 ms per step with one tile per chunk).  Many tiles:
-  // longer chunks keep the row scan short (3 M Gaussians at 1080p: 1.102 / 1.108 / 1.126 ms with 4 / 2 / 1).
-  // measurement switch; anything but 1, 2 or 4 tiles per chunk is ignored (the tables are sized for chunks of >= 1 tile)
-  static const int chunk_override = [] { const char* e = getenv("SEGS_COUNT_CHUNK"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
-  const int chunk_tiles = chunk_override > 0 ? chunk_override : (L.nblocks <= 256 ? 1 : (L.nblocks <= 2048 ? 2 : SORT_COUNT_CHUNK_TILES));
+  const int chunk_tiles = count_chunk_tiles(L.nblocks);
   const int nchunks = (L.nblocks + chunk_tiles - 1) / chunk_tiles;
   for (int p = 0; p < passes; p++) {
     const K* kin = (const K*)(bin + L.keys[side]);
@@ -130,6 +142,11 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
     radix_count_kernel<K, BITS><<<(nchunks + 7) / 8 * 8, SORT_THREADS, 0, st>>>(kin, n, shift, dmin, dbits, tile_prefix, chunk_hist, L.nblocks, nchunks, n_in, drop, chunk_tiles, nbits);
     }
     LAUNCH_TRY("radix_count_kernel");
+    const bool last = p == passes - 1;
+    uint2* fr = last ? fuse.ranges : nullptr;
+    uint32_t* fs = last ? fuse.status : nullptr;
+    uint32_t* fm = last ? fuse.status_mirror : nullptr;
+    const int wk = (last && !fuse.keep_sorted_keys) ? 0 : 1;
     { PROF(K_RADIX_SCAN);
     radix_scan_kernel<<<1 << BITS, 256, 0, st>>>(chunk_hist, nchunks, digit_totals);
     }
@@ -141,17 +158,17 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
       if (aux_in && aux_final && p == passes - 1) {
         radix_scatter_kernel<K, BITS, true><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                         digit_totals, L.nblocks, nchunks, n_in, drop,
-                                                                        drop ? n_live : nullptr, aux_in, aux_final, nbits, chunk_tiles, 0);
+                                                                        drop ? n_live : nullptr, aux_in, aux_final, nbits, chunk_tiles, 0, fr, fs, fm, wk);
       } else {
         radix_scatter_kernel<K, BITS, false><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                          digit_totals, L.nblocks, nchunks, n_in, drop,
                                                                          drop ? n_live : nullptr, (pack_shift > 0 && p == 0) ? aux_in : nullptr, nullptr,
-                                                                         nbits, chunk_tiles, (p == 0) ? pack_shift : 0);
+                                                                         nbits, chunk_tiles, (p == 0) ? pack_shift : 0, fr, fs, fm, wk);
       }
     } else {
       radix_scatter_kernel<K, BITS, false><<<scatter_grid, SORT_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, dmin, dbits, tile_prefix, chunk_hist,
                                                                        digit_totals, L.nblocks, nchunks, n_in, drop,
-                                                                       drop ? n_live : nullptr, nullptr, nullptr, nbits, chunk_tiles, 0);
+                                                                       drop ? n_live : nullptr, nullptr, nullptr, nbits, chunk_tiles, 0, nullptr, nullptr, nullptr, 1);
     }
     }
     LAUNCH_TRY("radix_scatter_kernel");
@@ -260,17 +277,27 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
                                                       (uint32_t)(n_cap / EMIT_SLOTS_PER_WG + 2));
   }
   LAUNCH_TRY("ordered_offsets_kernel");
+  const bool unfused = (g_flags & SEGS_RASTER_UNFUSED_BINNING) != 0u;
   { PROF(K_DUPLICATE);
   duplicate_with_keys_kernel<<<(n_cap + EMIT_SLOTS_PER_WG - 1) / EMIT_SLOTS_PER_WG, 256, 0, st>>>(P, n_cap, G.emit(), order, G.offsets(),
                                                                     (uint32_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev,
                                                                     drop_dead ? 1 : 0, ng_dev, first_owner);
   }
   LAUNCH_TRY("duplicate_with_keys_kernel");
-  // (3)
-  rc = wide_digit ? sort_pairs<uint32_t, 11>(bin, BL, n_cap, bit, 0u, 0, st, n_dev, drop_dead)
-                  : sort_pairs<uint32_t>(bin, BL, n_cap, bit, 0u, 0, st, n_dev, drop_dead);
+  // (3)  With two passes the last one fills the range table and the status words itself (radix_scatter_kernel); a single pass
+  // over depth-ordered input would need two atomics per instance for that and keeps the range kernel.
+  SortFusion fuse;
+  const bool fused_ranges = !unfused && tpasses >= 2;
+  if (fused_ranges) {
+    fuse.ranges = ranges;
+    fuse.status = n_dev ? total_out : nullptr;
+    fuse.status_mirror = n_dev ? g_status_mirror : nullptr;
+    fuse.keep_sorted_keys = n_dev == nullptr;   // resident mode: nothing reads the sorted tile ids after this
+  }
+  rc = wide_digit ? sort_pairs<uint32_t, 11>(bin, BL, n_cap, bit, 0u, 0, st, n_dev, drop_dead, false, nullptr, nullptr, 0, fuse)
+                  : sort_pairs<uint32_t>(bin, BL, n_cap, bit, 0u, 0, st, n_dev, drop_dead, false, nullptr, nullptr, 0, fuse);
   if (rc) return rc;
-  { PROF(K_RANGES);
+  if (!fused_ranges) { PROF(K_RANGES);
   identify_tile_ranges_kernel<<<(n_cap + 256 * RANGE_KEYS_PER_THREAD - 1) / (256 * RANGE_KEYS_PER_THREAD), 256, 0, st>>>(n_cap, (const uint32_t*)(bin + BL.keys[0]), ranges, n_dev,
                                                                    n_dev ? total_out : nullptr, n_dev ? g_status_mirror : nullptr,
                                                                    drop_dead ? (const uint32_t*)(bin + BL.n_live) : nullptr);
@@ -529,7 +556,11 @@ int segs_debug_unpack_image(const char* image_buffer, int width, int height, uin
   const ImageLayout IL = image_layout(width, height);
   const char* img = align_ptr(image_buffer);
   const size_t tiles = (size_t)((width + TILE_X - 1) / TILE_X) * ((height + TILE_Y - 1) / TILE_Y);
-  if (ranges) HIP_TRY(hipMemcpyAsync(ranges, img + IL.ranges, tiles * 8, hipMemcpyDeviceToDevice, st));
+  if (ranges) {
+    HIP_TRY(hipMemcpyAsync(ranges, img + IL.ranges, tiles * 8, hipMemcpyDeviceToDevice, st));
+    normalize_ranges_kernel<<<(int)((tiles + 255) / 256), 256, 0, st>>>((int)tiles, (uint2*)ranges);   // empty tiles: {0, 0} as in the reference
+    LAUNCH_TRY("normalize_ranges_kernel");
+  }
   if (final_T) HIP_TRY(hipMemcpyAsync(final_T, img + IL.final_T, (size_t)width * height * 4, hipMemcpyDeviceToDevice, st));
   if (n_contrib) HIP_TRY(hipMemcpyAsync(n_contrib, img + IL.n_contrib, (size_t)width * height * 4, hipMemcpyDeviceToDevice, st));
   return SEGS_OK;

@@ -60,6 +60,11 @@ __global__ void duplicate_with_keys_kernel(int P, int R, const float* __restrict
                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
                                            const uint32_t* __restrict__ n_dev, int mark_dead, const uint32_t* __restrict__ ng_dev,
                                            const uint32_t* __restrict__ first_owner);
+// Range table entry of a tile without instances: {RANGE_EMPTY_START, 0}.  The last tile-id pass fills the table with
+// atomicMin / atomicMax (radix_scatter_kernel), which needs this start value; every reader takes start >= end as empty, and
+// segs_debug_unpack_image hands out the reference's {0, 0} (rasterizer_impl.cu:310).
+constexpr uint32_t RANGE_EMPTY_START = 0xFFFFFFFFu;
+__global__ void normalize_ranges_kernel(int num_tiles, uint2* __restrict__ ranges);
 constexpr uint32_t PREPROCESS_TIGHT_RECT = 0x80000000u;   // internal flag bit of preprocess_fwd_kernel (resident forward)
 constexpr uint32_t DEAD_KEY = 0xFFFFFFFFu;   // tile-id key of an instance that reaches no quadrant of its tile
 template <typename K, int BITS>   // K = uint32_t (the pipeline's own sorts) or uint64_t (segs_sort_pairs); BITS per digit: 8 or 9
@@ -73,7 +78,9 @@ __global__ void radix_scatter_kernel(const K* __restrict__ keys_in, const uint32
                                      uint32_t dmin, int dbits, const uint32_t* __restrict__ tile_prefix, const uint32_t* __restrict__ chunk_prefix,
                                      const uint32_t* __restrict__ digit_totals, int nblocks, int nchunks,
                                      const uint32_t* __restrict__ n_dev, int drop_dead, uint32_t* __restrict__ n_live_out,
-                                     const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits, int chunk_tiles, int pack_shift);
+                                     const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out, int nbits, int chunk_tiles, int pack_shift,
+                                     uint2* __restrict__ ranges_out, uint32_t* __restrict__ status, uint32_t* __restrict__ status_mirror,
+                                     int write_keys);
 __global__ void identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges,
                                             const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ status,
                                             uint32_t* __restrict__ status_mirror, const uint32_t* __restrict__ n_live);

@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     }
   }
   if (ranges)
-    for (int t = idx; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(0u, 0u);   // rasterizer_impl.cu:310
+    for (int t = idx; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(RANGE_EMPTY_START, 0u);   // rasterizer_impl.cu:310 ({0,0} there; see kernels.h)
   // workgroup sum of tiles_touched -> block_sums[blockIdx] (feeds the prefix sum, K5); depth range for the sort
   uint32_t s = touched;
   uint32_t dmax = touched ? dbits_mine : 0u, dnmin = touched ? ~dbits_mine : 0u;

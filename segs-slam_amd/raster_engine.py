@@ -8,6 +8,7 @@ buffer (the RCCL all-reduce bucket / fused-Adam operand), no per-iteration alloc
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -53,6 +54,8 @@ class RasterEngine:
         # SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY (segs_raster.h): candidate-domain inputs of segs_neural_forward
         # SEGS_RASTER_KEEP_DEAD_INSTANCES: resident forwards bin the reference's full bounding squares (R == R_reference)
         self.flags = (1 if skip_nonpositive_opacity else 0) | (2 if keep_dead_instances else 0)
+        # SEGS_RASTER_EXTRA_FLAGS: extra segs_raster.h flag bits for A/B measurements (e.g. 16 = SEGS_RASTER_UNFUSED_BINNING)
+        self.flags |= int(os.environ.get("SEGS_RASTER_EXTRA_FLAGS", "0"), 0)
         self.R_reference = 0
         self.R_live = 0
         self.capacity = 0

@@ -463,3 +463,74 @@ def test_tiles_touched_by_gather_path_gives_the_same_binning():
     for other in outs[1:]:
         for k in ("keys", "point_list", "ranges", "n_contrib", "out_color", "tiles_touched"):
             assert np.array_equal(outs[0][k], other[k]), k
+
+
+def test_range_table_from_the_last_sort_pass_equals_the_range_kernel():
+    """With two tile-id passes the last scatter pass fills the range table and the resident status words itself (two integer
+    atomics per (sort tile, tile id) pair, radix_scatter_kernel) and does not store the sorted keys nobody reads.
+    SEGS_RASTER_UNFUSED_BINNING runs identify_tile_ranges_kernel instead: every list, the range table, n_contrib and the image
+    must be identical -- through the reference-shaped call (full lists, sorted keys kept) and through the resident engine
+    (dead instances dropped by the first pass, status words), including a map that does not fill the engine's rows."""
+    from segs_slam_amd import _capi
+    from segs_slam_amd.raster_engine import RasterEngine
+    sc = scenes.make_scene(150_000, 1200, 680, 600.0, 600.0, seed=909, bg=(0.0, 0.1, 0.0))
+    sc.scales *= 2.5
+    cam = sc.camera
+    outs = []
+    for flags in (0, 16):
+        old = _capi.lib().segs_raster_set_flags(flags)
+        try:
+            args, fwd = gpu_forward(sc)
+            outs.append(gpu_state(sc, fwd))
+            outs[-1]["R"] = fwd[0]
+        finally:
+            _capi.lib().segs_raster_set_flags(old)
+    assert outs[0]["R"] > 257 * 2048, outs[0]["R"]      # two 8-bit tile-id passes, count chunks of two sort tiles
+    for k in ("keys", "point_list", "ranges", "n_contrib", "out_color", "tiles_touched"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    a = dict(bg=_t(sc.bg), m=_t(sc.means3D), c=_t(sc.colors), o=_t(sc.opacity), s=_t(sc.scales), r=_t(sc.rotations),
+             v=_t(cam.world_view_transform), p=_t(cam.full_proj_transform), cp=_t(cam.camera_center))
+    dL = _t(sc.dL_dout_color)
+    res = []
+    for extra in (0, 16):
+        for active in (sc.P, sc.P - 37_111):
+            eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=True)
+            eng.flags |= extra
+            eng.set_active(active)
+            sl = slice(0, active)
+            for _ in range(3):
+                img = eng.forward(a["bg"], a["m"][sl].contiguous(), a["c"][sl].contiguous(), a["o"][sl].contiguous(),
+                                  a["s"][sl].contiguous(), a["r"][sl].contiguous(), a["v"], a["p"], a["cp"], cam.tanfovx, cam.tanfovy)
+                eng.backward(dL)
+            assert eng.check() and eng._last_resident
+            torch.cuda.synchronize()
+            st = _capi_state(eng, cam)
+            res.append((extra, active, img.cpu().numpy().copy(), eng.R, eng.R_live, st,
+                        {k: v.cpu().numpy().copy() for k, v in eng.grads.items()}))
+    for i in (0, 1):
+        f, u = res[i], res[2 + i]
+        assert f[1] == u[1] and f[3] == u[3] and f[4] == u[4] and 0 < f[4] < f[3]
+        assert np.array_equal(f[2], u[2])
+        for k in ("ranges", "n_contrib", "values"):
+            assert np.array_equal(f[5][k], u[5][k]), k
+        for k in f[6]:
+            assert_grad_close(k, f[6][k][:f[1]], u[6][k][:f[1]])
+    assert np.array_equal(res[0][2], outs[0]["out_color"])
+
+
+def _capi_state(eng, cam):
+    """ranges / n_contrib / sorted instance values of a resident engine's last forward."""
+    import ctypes as C
+    from segs_slam_amd import _capi
+    lib = _capi.lib()
+    tiles = ((cam.width + 15) // 16) * ((cam.height + 15) // 16)
+    ranges = torch.zeros((tiles, 2), dtype=torch.int32, device=DEV)
+    ncontrib = torch.zeros((cam.height, cam.width), dtype=torch.int32, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream(DEV).cuda_stream)
+    _capi.check(lib.segs_debug_unpack_image(C.c_void_p(eng._img_r.data_ptr()), cam.width, cam.height, C.c_void_p(ranges.data_ptr()),
+                                            None, C.c_void_p(ncontrib.data_ptr()), st), "segs_debug_unpack_image")
+    vals = torch.zeros(eng.capacity, dtype=torch.int32, device=DEV)
+    _capi.check(lib.segs_debug_instance_values(C.c_void_p(eng._bin_r.data_ptr()), eng.capacity, C.c_void_p(vals.data_ptr()), st),
+                "segs_debug_instance_values")
+    torch.cuda.synchronize()
+    return dict(ranges=ranges.cpu().numpy(), n_contrib=ncontrib.cpu().numpy(), values=vals.cpu().numpy()[:eng.R_live])
