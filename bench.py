@@ -77,6 +77,8 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (exercises the RCCL calls on a one-GPU box)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra blocks of the line (mapper_step, config3, render_only_ms): A/B runs and profiles")
     return ap.parse_args()
 
 
@@ -218,15 +220,19 @@ def main():
             step()
         torch.cuda.synchronize()
     fence()
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one record per step: p10 / p50 / p90
     with KernelProfile(LIVE_EVENT_KERNELS if graph is None else []) as prof_live:
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        step_events[0].record()
+        for i in range(args.steps):
             if graph is not None:
                 graph.replay()
             else:
                 step()
+            step_events[i + 1].record()
         fence()
         elapsed = time.perf_counter() - t0
+    per_step_ms = sorted(step_events[i].elapsed_time(step_events[i + 1]) for i in range(args.steps))
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -330,6 +336,18 @@ def main():
             out["raster"].update(pair_rates(eng, cam, per_step))
         except Exception as e:  # noqa: BLE001  (measurement garnish only; never fail the bench line over it)
             out["raster"]["pairs_error"] = str(e)
+        pct = lambda q: per_step_ms[min(len(per_step_ms) - 1, int(q * len(per_step_ms)))]  # noqa: E731
+        out["step_ms"] = {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90), "min": per_step_ms[0], "max": per_step_ms[-1],
+                          "source": "one HIP event per step on the launch stream, inside the timed region (device time between "
+                                    "step ends; the line's ms_per_step is the host clock over all K steps)"}
+        if world == 1 and args.mode == "raster" and not args.no_extras:
+            extras = [("render_only_ms", lambda: render_only(eng, (bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy))),
+                      ("mapper_step", lambda: mapper_step_block(dev)), ("config3", lambda: config3_block(dev))]
+            for key, fn in extras:
+                try:
+                    out[key] = fn()
+                except Exception as e:  # noqa: BLE001  (extra blocks never fail the bench line)
+                    out[key] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc)
         if args.breakdown:
@@ -338,6 +356,104 @@ def main():
         print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def _percentiles(ms):
+    ms = sorted(ms)
+    q = lambda f: ms[min(len(ms) - 1, int(f * len(ms)))]  # noqa: E731
+    return {"mean": sum(ms) / len(ms), "p10": q(0.1), "p50": q(0.5), "p90": q(0.9)}
+
+
+def render_only(eng, fwd_args, iters: int = 50):
+    """Forward-only render of the headline workload through the resident path: the reference's own per-frame figure
+    (render_time.txt of renderAndRecordKeyframe, src/gaussian_mapper.cpp:1791-1808), HIP events per call."""
+    import torch
+    for _ in range(3):
+        eng.forward(*fwd_args)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        eng.forward(*fwd_args)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    eng.check()
+    out = _percentiles([ev[i].elapsed_time(ev[i + 1]) for i in range(iters)])
+    out["what"] = f"forward-only raster (preprocess, binning, render), resident path, {iters} frames, HIP events per frame"
+    return out
+
+
+def mapper_step_block(dev, steps: int = 50, warmup: int = 10):
+    """The real mapper iteration at BASELINE config 5's size, untimed-region block of the bench line: 300 k anchors x 10
+    offsets (3 M candidate Gaussians) at 1200x680, ScanNet model dimensions (appearance_dim 16, no feature bank):
+    prefilter + neural-Gaussian MLPs fwd/bwd + raster fwd/bwd + L1/SSIM + fused Adam."""
+    import numpy as np
+    import torch
+    from segs_slam_amd import neural_gaussians as ng, scenes
+    cam = scenes.make_config_camera("c5")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    dims = ng.ModelDims(appearance_dim=16, use_feat_bank=False)
+    model = ng.synthetic_model(300_000, dims, cam, dev, seed=0)
+    tstep = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    gt = torch.rand(3, cam.height, cam.width, device=dev)
+    tstep.keyframe_for = lambda step, n: 0
+    for _ in range(warmup):
+        tstep.training_once([kf], [gt])
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        tstep.training_once([kf], [gt])
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    pc = _percentiles([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)])
+    phases = tstep.profile_phases(kf, gt, 20)
+    for _ in range(3):
+        tstep.render(kf)
+    rev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+    rev[0].record()
+    for i in range(20):
+        tstep.render(kf)
+        rev[i + 1].record()
+    torch.cuda.synchronize()
+    eng = tstep.engine
+    eng.check()
+    return {"workload": f"anchor-level mapper step, config-5 size: {model.A} anchors x {dims.n_offsets} offsets -> {eng.P_active} candidate "
+                        f"Gaussians, {cam.width}x{cam.height}, appearance_dim 16, no feature bank; instances binned {eng.R}, live {eng.R_live}",
+            "iters_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "steps": steps, "warmup": warmup, "step_ms": pc,
+            "phase_ms": {k: round(v, 4) for k, v in phases.items()},
+            "render_only_ms": _percentiles([rev[i].elapsed_time(rev[i + 1]) for i in range(20)]),
+            "dropped_steps": tstep.dropped_steps()}
+
+
+def config3_block(dev, max_iters: int = 3000, target_anchors: int = 200_000, steady_iters: int = 200):
+    """SURVEY 8d config 3, untimed-region block: the mapper loop with statistics + anchor growing + pruning on the synthetic
+    64-keyframe orbit (segs_slam_amd.config3) from ~50 k anchors until anchors x 10 ~ 2 M Gaussians, then `steady_iters` more
+    iterations at that size.  The Replica gradient threshold (2e-4) grows this synthetic map to ~64 k anchors and stops
+    (profiles/r03_config3_growth.txt); the block runs the SAME loop with the threshold at 2e-5 so that the sizes SURVEY names
+    are reached inside a bounded run -- stated in `densify_grad_threshold`."""
+    import torch
+    from segs_slam_amd import config3, densify
+    params = densify.DensifyParams(start_stat=100, update_from=300, update_interval=100, update_until=10 ** 9,
+                                   densify_grad_threshold=2e-5)
+    run = config3.Config3Run(dev, params=params)
+    res = run.run(max_iters, target_anchors)
+    params.update_until = 0            # steady state at the final size: statistics and adjust_anchor off
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steady_iters):
+        run.step.training_once(run.keyframes, run.targets)
+    torch.cuda.synchronize()
+    steady = steady_iters / (time.perf_counter() - t0)
+    finite = bool(torch.isfinite(run.model.params).all())
+    res.update({"densify_grad_threshold": params.densify_grad_threshold, "schedule": "statistics from iteration 100, adjust_anchor from 300 every 100",
+                "keyframes": len(run.keyframes), "image": f"{run.cam.width}x{run.cam.height}", "iters_per_s_at_final_size": steady,
+                "parameters_finite": finite,
+                "what": "wall clock over all iterations of the growth run, adjust_anchor iterations and their host synchronisations included"})
+    return res
 
 
 def pair_rates(eng, cam, per_step):

@@ -561,6 +561,43 @@ class ScaffoldTrainerStep:
             self.model.grads.zero_()      # outside this rank's shard the bucket still holds its own contribution
         return loss
 
+    def profile_phases(self, kf: Keyframe, gt: torch.Tensor, iters: int = 20) -> Dict[str, float]:
+        """Mean milliseconds per phase of one iteration (HIP events on the current stream between the same calls
+        training_once issues; measurement support for bench.py, single rank, no densification)."""
+        names = ("prefilter_voxel", "neural_forward", "raster_forward", "loss", "raster_backward", "neural_backward", "adam")
+        tot = {n: 0.0 for n in names}
+        ng = self.neural
+        for _ in range(iters):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+            self.iteration += 1
+            lrs = self.learning_rates(self.iteration)
+            ev[0].record()
+            radii = self.prefilter_voxel(kf)
+            ev[1].record()
+            ng.forward(kf.campos, kf.pose7, radii)
+            ev[2].record()
+            self.engine.set_active(ng.P)
+            image = self.engine.forward(self.bg, ng.means3D, ng.colors, ng.opacity, ng.scales, ng.rotations, kf.view, kf.proj,
+                                        kf.campos, kf.tanfovx, kf.tanfovy)
+            ev[3].record()
+            _, dL = self.loss_fn(image, gt)
+            ev[4].record()
+            g = self.engine.backward(dL)
+            ev[5].record()
+            ng.backward(g["means3D"], g["colors"], g["opacity"], g["scales"], g["rotations"], self.scaling_reg_weight)
+            ev[6].record()
+            groups = self.model.adam_groups(lrs)
+            if self._anchor_count is None:
+                self._adam(groups, self._mlp_count, None)
+            else:
+                self._adam(groups[:4], self._anchor_count, None)
+                self._adam(groups[4:], self._mlp_count, None)
+            ev[7].record()
+            torch.cuda.synchronize(self.model.device)
+            for i, n in enumerate(names):
+                tot[n] += ev[i].elapsed_time(ev[i + 1])
+        return {n: v / iters for n, v in tot.items()}
+
     def dropped_steps(self) -> int:
         """Iterations the device dropped so far (overflowed resident capacity on some rank; synchronises).  Their returned
         loss is invalid and their keyframe use was still counted; the reference never drops an iteration."""

@@ -150,15 +150,27 @@ def _small_rotation(seed: int, max_deg: float = 5.0) -> np.ndarray:
     return R.astype(np.float32)
 
 
-def make_scene(P: int, width: int, height: int, fx: float, fy: float, seed: int = 0x5E65,
-               bg=(0.0, 0.0, 0.0), name: str = "custom", keyframe: int = 0) -> Scene:
-    """Seeded scene of SURVEY.md section 8d.  `keyframe` perturbs only the camera pose (same Gaussians),
-    which is what keyframe-parallel training needs (section 8e)."""
+def keyframe_camera(width: int, height: int, fx: float, fy: float, seed: int = 0x5E65, keyframe: int = 0) -> Camera:
+    """The camera of keyframe `keyframe` of a seeded scene: a rotation of at most 5 degrees and (keyframe > 0) a shift of at most
+    0.1 m per axis around the scene's camera at the origin -- the poses of the synthetic keyframe orbit."""
     R = _small_rotation(seed + 7919 * keyframe)
     t = np.zeros(3, dtype=np.float32)
     if keyframe:
         t = ((uniform01(3, 901, seed + 7919 * keyframe) - 0.5) * 0.2).astype(np.float32)
-    cam = make_camera(width, height, fx, fy, R, t)
+    return make_camera(width, height, fx, fy, R, t)
+
+
+def make_config_camera(name: str, keyframe: int = 0, seed_offset: int = 0) -> Camera:
+    """Camera of make_config_scene(name, keyframe=keyframe) without generating its Gaussians."""
+    P, W, H, fx, fy = CONFIGS[name]
+    return keyframe_camera(W, H, fx, fy, 0x5E65 + list(CONFIGS).index(name) + seed_offset, keyframe)
+
+
+def make_scene(P: int, width: int, height: int, fx: float, fy: float, seed: int = 0x5E65,
+               bg=(0.0, 0.0, 0.0), name: str = "custom", keyframe: int = 0) -> Scene:
+    """Seeded scene of SURVEY.md section 8d.  `keyframe` perturbs only the camera pose (same Gaussians),
+    which is what keyframe-parallel training needs (section 8e)."""
+    cam = keyframe_camera(width, height, fx, fy, seed, keyframe)
     tanx, tany = cam.tanfovx, cam.tanfovy
 
     u = lambda stream: uniform01(P, stream, seed)  # noqa: E731
