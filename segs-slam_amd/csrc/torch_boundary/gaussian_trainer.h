@@ -8,18 +8,28 @@
 //   segs_visible_filter -> segs_neural_forward -> segs_rasterize_forward[_resident] -> segs_l1_ssim_loss
 //   -> segs_rasterize_backward[_resident] -> segs_neural_backward -> segs_adam_step_device.
 // LibTorch is plumbing only: device memory (torch::Tensor), the current HIP stream and two elementwise ops of the
-// prefilter.  This is the C++ twin of segs-slam_amd/neural_gaussians.py::ScaffoldTrainerStep (single rank, no
-// densification); tests/test_cpp_trainer.py runs both on the same model and compares losses and parameters.
+// prefilter and the tensor bookkeeping of adjust_anchor.  This is the C++ twin of
+// segs-slam_amd/neural_gaussians.py::ScaffoldTrainerStep: the iteration itself, the densification schedule of
+// trainForOneIteration (training_statis / adjust_anchor, src/gaussian_mapper.cpp:957-968 -> anchor_densifier.h) and the
+// keyframe-parallel exchange (keyframe_exchange.h); tests/test_cpp_trainer.py runs both twins on the same model and compares
+// losses, parameters and the map after an adjust_anchor iteration, and two C++ ranks against each other.
 #pragma once
 #include <torch/torch.h>
 
+#include <torch/csrc/distributed/c10d/Backend.hpp>
+
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../../include/segs_neural.h"
+#include "../../../include/segs_train.h"
 
 namespace segs_host {
+
+class AnchorDensifier;
+class KeyframeExchange;
 
 // Model.* keys of cfg/gaussian_mapper/RGB-D/Replica/office0.yaml:13-26 that shape the MLPs
 struct ScaffoldDims {
@@ -44,6 +54,36 @@ struct ScaffoldOptimization {
   double beta1 = 0.9, beta2 = 0.999, eps = 1e-15;   // src/gaussian_model.cpp:632-661
 };
 
+// Anchors + MLPs in one flat parameter bucket (plus same-shaped gradient and Adam-moment buckets): the reference's six
+// anchor tensors and its Sequential MLPs (src/gaussian_model.cpp:60-150, 327-381) as the fused Adam's operand.  The anchor
+// segments are laid out for `capacity` >= A anchors so that densification appends and prunes rows in place; views cover
+// the first A rows.  C++ twin of neural_gaussians.py::ScaffoldModel.
+struct ScaffoldModelState {
+  ScaffoldModelState(int64_t num_anchors, const ScaffoldDims& dims, torch::Device device, int64_t capacity = 0);
+  void reserve(int64_t capacity);   // grow the buckets, keeping the first A rows of every segment and the MLP block
+  int64_t width(const std::string& name) const;
+  torch::Tensor view(const torch::Tensor& bucket, const std::string& name, int64_t rows = -1) const;
+  torch::Tensor param(const std::string& name, int64_t rows = -1) const { return view(params, name, rows); }
+  torch::Tensor grad(const std::string& name, int64_t rows = -1) const { return view(grads, name, rows); }
+  torch::Tensor mlp_params() const { return params.slice(0, mlp_offset, n_params); }
+  float* seg_ptr(const torch::Tensor& bucket, const std::string& name) const { return bucket.data_ptr<float>() + seg_offset.at(name); }
+  // (offset, count, lr slot) of the Adam groups in the reference's order (src/gaussian_model.cpp:632-690): four anchor groups,
+  // then the MLP groups; `kind` of an MLP group: 0 opacity, 1 cov, 2 color, 3 appearance, 4 feature bank
+  std::vector<std::pair<int64_t, int64_t>> anchor_groups() const;
+
+  ScaffoldDims dims;
+  segs_neural_dims cdims;
+  torch::Device dev;
+  int64_t A = 0, capacity = 0, n_params = 0, mlp_offset = 0, mlp_total = 0;
+  std::map<std::string, int64_t> seg_offset;
+  std::vector<std::pair<int64_t, int64_t>> mlp_group_rel;   // (offset inside the MLP block, count)
+  std::vector<int> mlp_group_kind;
+  torch::Tensor params, grads, exp_avg, exp_avg_sq, rotation, opacity;
+
+ private:
+  void allocate(int64_t capacity);
+};
+
 // what the step needs of a GaussianKeyframe (src/gaussian_keyframe.cpp:151-184): device tensors + scalars
 struct KeyframeView {
   torch::Tensor view, proj, campos, pose7;   // (4,4) transposed layouts, (3), (t_xyz, q_wxyz)
@@ -54,49 +94,74 @@ class GaussianTrainerStep {
  public:
   GaussianTrainerStep(int64_t num_anchors, const ScaffoldDims& dims, int width, int height, torch::Device device,
                       const ScaffoldOptimization& opt = ScaffoldOptimization(), float scaling_reg_weight = 0.f,
-                      double spatial_lr_scale = 1.0);
+                      double spatial_lr_scale = 1.0, int64_t capacity = 0);
+  ~GaussianTrainerStep();
 
+  ScaffoldModelState& model() { return model_; }
   // views into the flat parameter bucket (the Adam operand): "anchor" (A,3), "offset" (A,n_offsets,3),
   // "anchor_feat" (A,32), "scaling" (A,6); the MLP block in the order of segs_neural_param_layout
-  torch::Tensor param(const std::string& name);
-  torch::Tensor mlp_params() { return params_.slice(0, mlp_offset_, n_params_); }
-  torch::Tensor params_flat() { return params_; }
-  torch::Tensor grads_flat() { return grads_; }
+  torch::Tensor param(const std::string& name) { return model_.param(name); }
+  torch::Tensor mlp_params() { return model_.mlp_params(); }
+  torch::Tensor params_flat() { return model_.params; }
+  torch::Tensor grads_flat() { return model_.grads; }
 
-  // One iteration on one keyframe; returns the L1/SSIM part of the loss as a 1-element device tensor (the scaling
-  // regulariser's value is in scaling_reg()).  Nothing in it waits for the device except the first, calibrating pass.
+  // training_statis / adjust_anchor on the schedule of trainForOneIteration (src/gaussian_mapper.cpp:961-968); the random keep
+  // masks come from a CPU generator seeded identically on every rank.  The step does not own the densifier.
+  void enable_densification(AnchorDensifier* densifier, uint64_t seed);
+  // keyframe-parallel training: N > 1 ranks each render their own keyframe, the gradient bucket is exchanged before the
+  // optimizer (keyframe_exchange.h).  `pg` null = single process.
+  void set_process_group(c10::intrusive_ptr<c10d::Backend> pg, bool sharded_optimizer = true, bool single_rank_collectives = false);
+  int world() const;
+  int rank() const;
+
+  // One iteration on one keyframe (the caller picks keyframe (iteration * world + rank) mod n, or the mapper's walk); returns
+  // the L1/SSIM part of the loss as a 1-element device tensor (the scaling regulariser's value is in scaling_reg()).
+  // Nothing in it waits for the device except the first, calibrating pass and the adjust_anchor iterations.
   torch::Tensor trainingOnce(const KeyframeView& kf, const torch::Tensor& gt_image);
 
   torch::Tensor image() { return out_color_; }
   torch::Tensor scaling_reg() { return scaling_reg_; }
   int64_t iteration() const { return iteration_; }
-  int64_t steps_taken();        // optimizer steps really taken (device-side count; synchronises)
+  int64_t steps_taken();        // optimizer steps really taken by the MLP groups (device-side count; synchronises)
+  int64_t anchor_steps_taken(); // ... by the anchor groups (they skip the adjust_anchor iterations, src/gaussian_model.cpp:1677)
+  // candidate-domain state of the last pass, for the statistics (anchor_densifier.h)
+  torch::Tensor neural_opacity() { return neural_opacity_; }
+  torch::Tensor visible_radii() { return visible_radii_; }
+  torch::Tensor radii() { return radii_; }
+  torch::Tensor dL_dmean2D() { return dL_dmean2D_; }
   bool last_pass_resident() const { return last_resident_; }
 
  private:
+  struct StepCount {   // torch::optim::Adam's per-group step count, on the device: two int64 words used in turn
+    torch::Tensor words;
+    int calls = 0;
+  };
   void learning_rates(int64_t it, std::vector<double>& lr_of_group) const;
   void prefilter(const KeyframeView& kf);
   void render(const KeyframeView& kf);
   void resolve_status();
+  void forward_backward(const KeyframeView& kf, const torch::Tensor& gt_image);
+  void adam(const std::vector<segs_adam_segment>& groups, StepCount& count, const uint32_t* guard);
+  void allocate_candidate_buffers();
+  KeyframeExchange& exchange();
 
-  ScaffoldDims dims_;
-  segs_neural_dims cdims_;
+  ScaffoldModelState model_;
   ScaffoldOptimization opt_;
-  int64_t A_, P_;
   int W_, H_;
   torch::Device dev_;
   float reg_weight_;
   double spatial_lr_scale_;
   int64_t iteration_ = 0;
-
-  // flat buckets
-  int64_t n_params_ = 0, mlp_offset_ = 0, mlp_total_ = 0;
-  std::map<std::string, std::pair<int64_t, int64_t>> seg_;          // name -> (offset, count)
-  std::vector<std::pair<int64_t, int64_t>> mlp_group_;              // Adam groups inside the MLP block (offset, count)
-  std::vector<int> mlp_group_kind_;                                 // 0 opacity, 1 cov, 2 color, 3 appearance, 4 feature bank
-  torch::Tensor params_, grads_, exp_avg_, exp_avg_sq_, rotation_, rot_normalized_;
-  torch::Tensor step_words_;                                        // 2 x int64, segs_adam_step_device
-  int adam_calls_ = 0;
+  int64_t cand_capacity_ = 0;                                       // anchors the candidate-domain buffers are sized for
+  torch::Tensor rot_normalized_;
+  int64_t rot_rows_ = -1;
+  StepCount mlp_count_, anchor_count_;
+  bool anchor_count_split_ = false;
+  AnchorDensifier* densifier_ = nullptr;
+  at::Generator densify_generator_;
+  c10::intrusive_ptr<c10d::Backend> pg_;
+  bool sharded_optimizer_ = true, single_rank_collectives_ = false;
+  std::unique_ptr<KeyframeExchange> ex_;
 
   // candidate-domain buffers of the neural Gaussians and their gradients
   torch::Tensor means3D_, colors_, opacity_, scales_, rotations_, neural_opacity_, neural_temp_, visible_radii_;

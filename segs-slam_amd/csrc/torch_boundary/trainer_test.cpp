@@ -1,14 +1,36 @@
-// trainer_test.cpp -- drives segs_host::GaussianTrainerStep (gaussian_trainer.h) on a model read from a file; the Python test
-// tests/test_cpp_trainer.py runs segs-slam_amd/neural_gaussians.py::ScaffoldTrainerStep on the same model and compares.
+// trainer_test.cpp -- drives segs_host::GaussianTrainerStep (gaussian_trainer.h) on a model read from a file; the Python tests
+// tests/test_cpp_trainer.py run segs-slam_amd/neural_gaussians.py::ScaffoldTrainerStep on the same model and compare.
+//
 //   trainer_test <in.bin> <out.bin>
-// in.bin : int32 A, W, H, appearance_dim, use_feat_bank, n_steps ; float tanfovx, tanfovy, scaling_reg_weight ; float32 arrays
-//          anchor(A,3) offset(A,10,3) anchor_feat(A,32) scaling(A,6) mlp(block) view(16) proj(16) campos(3) pose7(7) gt(3,H,W)
-// out.bin: float32 loss[n_steps] ; scaling_reg[n_steps] ; steps_taken ; resident passes ; params(flat bucket) ; image(3,H,W)
+//     in.bin : int32 A, W, H, appearance_dim, use_feat_bank, n_steps ; float tanfovx, tanfovy, scaling_reg_weight ; float32 arrays
+//              anchor(A,3) offset(A,10,3) anchor_feat(A,32) scaling(A,6) mlp(block) view(16) proj(16) campos(3) pose7(7) gt(3,H,W)
+//     out.bin: float32 loss[n_steps] ; scaling_reg[n_steps] ; steps_taken ; resident passes ; params(flat bucket) ; image(3,H,W)
+//
+//   trainer_test --mapper <in.bin> <out.bin> [--world N --rank r --store FILE [--dense] | --nccl1 FILE]
+//     the mapper loop with densification (anchor_densifier.h) and, with --world, the keyframe-parallel exchange
+//     (keyframe_exchange.h) between N processes of this program, rank r rendering keyframe (iteration * N + r) mod n_keyframes.
+//     in.bin : int32 A, W, H, appearance_dim, use_feat_bank, n_steps, n_keyframes, start_stat, update_from, update_interval, seed ;
+//              float tanfovx, tanfovy, scaling_reg_weight, voxel_size, densify_grad_threshold ; model arrays as above ;
+//              per keyframe: view(16) proj(16) campos(3) pose7(7) gt(3,H,W)
+//     out.bin: int32 A_final, capacity, mlp_steps, anchor_steps, A after every step [n_steps] ; float32 loss[n_steps] ;
+//              live rows of anchor / offset / anchor_feat / scaling, the MLP block, the four statistics (live rows)
+//     --world: the collectives run over a c10d::Backend defined HERE on top of c10d::FileStore (host staging, rank-ordered sums:
+//     a rehearsal transport for a one-GPU box, where RCCL refuses two ranks on one device); --nccl1: a ONE-rank
+//     c10d::ProcessGroupNCCL with every collective forced (reduce_scatter / all_gather through RCCL from C++).
 #include <cstdio>
+#include <cstring>
 #include <fstream>
+#include <string>
 #include <vector>
 
+#include <torch/csrc/distributed/c10d/FileStore.hpp>
+#ifdef SEGS_TEST_WITH_NCCL
+#include <torch/csrc/distributed/c10d/ProcessGroupNCCL.hpp>
+#endif
+
+#include "anchor_densifier.h"
 #include "gaussian_trainer.h"
+#include "keyframe_exchange.h"
 
 static torch::Tensor rd(std::ifstream& f, std::vector<int64_t> shape) {
   int64_t n = 1;
@@ -22,9 +44,56 @@ static void wr(std::ofstream& f, const torch::Tensor& t) {
   f.write(reinterpret_cast<const char*>(c.data_ptr<float>()), c.numel() * 4);
 }
 
-int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: trainer_test in.bin out.bin\n"); return 2; }
-  std::ifstream f(argv[1], std::ios::binary);
+namespace {
+// A c10d::Backend over a Store: every rank publishes its tensor's bytes, reads every rank's, and combines them in rank order
+// (so every rank computes the same words).  Test transport only.
+class StoreWork : public c10d::Work {
+ public:
+  StoreWork() : c10d::Work(-1, c10d::OpType::UNKNOWN) { finish(); }
+  bool wait(std::chrono::milliseconds) override { return true; }
+};
+class StoreBackend : public c10d::Backend {
+ public:
+  StoreBackend(c10::intrusive_ptr<c10d::Store> store, int rank, int size) : c10d::Backend(rank, size), store_(std::move(store)) {}
+  const std::string getBackendName() const override { return "store"; }
+  c10::intrusive_ptr<c10d::Work> allreduce(std::vector<at::Tensor>& ts, const c10d::AllreduceOptions& = c10d::AllreduceOptions()) override {
+    auto parts = exchange(ts[0]);
+    auto sum = parts[0].clone();
+    for (int r = 1; r < getSize(); r++) sum += parts[r];
+    ts[0].copy_(sum.to(ts[0].device()));
+    return c10::make_intrusive<StoreWork>();
+  }
+  c10::intrusive_ptr<c10d::Work> allgather(std::vector<std::vector<at::Tensor>>& outs, std::vector<at::Tensor>& ins,
+                                          const c10d::AllgatherOptions& = c10d::AllgatherOptions()) override {
+    auto parts = exchange(ins[0]);
+    for (int r = 0; r < getSize(); r++) outs[0][r].copy_(parts[r].to(outs[0][r].device()));
+    return c10::make_intrusive<StoreWork>();
+  }
+
+ private:
+  std::vector<at::Tensor> exchange(const at::Tensor& t) {
+    auto host = t.detach().contiguous().cpu();
+    const size_t bytes = host.numel() * host.element_size();
+    const std::string base = "x" + std::to_string(seq_++) + "_";
+    std::vector<uint8_t> mine((const uint8_t*)host.data_ptr(), (const uint8_t*)host.data_ptr() + bytes);
+    store_->set(base + std::to_string(getRank()), mine);
+    std::vector<at::Tensor> parts;
+    for (int r = 0; r < getSize(); r++) {
+      auto v = store_->get(base + std::to_string(r));
+      TORCH_CHECK(v.size() == bytes, "store exchange: size mismatch");
+      auto p = torch::empty_like(host);
+      std::memcpy(p.data_ptr(), v.data(), bytes);
+      parts.push_back(p);
+    }
+    return parts;
+  }
+  c10::intrusive_ptr<c10d::Store> store_;
+  int64_t seq_ = 0;
+};
+}  // namespace
+
+static int run_single(const char* in, const char* out) {
+  std::ifstream f(in, std::ios::binary);
   int32_t hdr[6]; float tf[3];
   f.read(reinterpret_cast<char*>(hdr), sizeof(hdr));
   f.read(reinterpret_cast<char*>(tf), sizeof(tf));
@@ -51,7 +120,7 @@ int main(int argc, char** argv) {
     resident += step.last_pass_resident() ? 1 : 0;
   }
   torch::cuda::synchronize();
-  std::ofstream o(argv[2], std::ios::binary);
+  std::ofstream o(out, std::ios::binary);
   o.write(reinterpret_cast<const char*>(losses.data()), losses.size() * 4);
   o.write(reinterpret_cast<const char*>(regs.data()), regs.size() * 4);
   const float extra[2] = {(float)step.steps_taken(), (float)resident};
@@ -60,4 +129,90 @@ int main(int argc, char** argv) {
   wr(o, step.image());
   std::printf("trainer_test ok A=%d %dx%d steps=%d (resident passes %d)\n", A, W, H, n_steps, resident);
   return 0;
+}
+
+static int run_mapper(int argc, char** argv) {
+  const char* in = argv[2];
+  const char* out = argv[3];
+  int world = 1, rank = 0;
+  bool dense = false, nccl1 = false;
+  std::string store_path;
+  for (int i = 4; i < argc; i++) {
+    const std::string a = argv[i];
+    if (a == "--world" && i + 1 < argc) world = std::atoi(argv[++i]);
+    else if (a == "--rank" && i + 1 < argc) rank = std::atoi(argv[++i]);
+    else if (a == "--store" && i + 1 < argc) store_path = argv[++i];
+    else if (a == "--nccl1" && i + 1 < argc) { nccl1 = true; store_path = argv[++i]; }
+    else if (a == "--dense") dense = true;
+  }
+  std::ifstream f(in, std::ios::binary);
+  int32_t hdr[11]; float tf[5];
+  f.read(reinterpret_cast<char*>(hdr), sizeof(hdr));
+  f.read(reinterpret_cast<char*>(tf), sizeof(tf));
+  const int A = hdr[0], W = hdr[1], H = hdr[2], n_steps = hdr[5], n_kf = hdr[6];
+  segs_host::ScaffoldDims dims;
+  dims.appearance_dim = hdr[3];
+  dims.use_feat_bank = hdr[4] != 0;
+  const torch::Device dev(torch::kCUDA, 0);
+  segs_host::GaussianTrainerStep step(A, dims, W, H, dev, segs_host::ScaffoldOptimization(), tf[2]);
+  step.param("anchor").copy_(rd(f, {A, 3}));
+  step.param("offset").copy_(rd(f, {A, dims.n_offsets, 3}));
+  step.param("anchor_feat").copy_(rd(f, {A, dims.feat_dim}));
+  step.param("scaling").copy_(rd(f, {A, 6}));
+  step.mlp_params().copy_(rd(f, {step.mlp_params().numel()}));
+  std::vector<segs_host::KeyframeView> kfs(n_kf);
+  std::vector<torch::Tensor> gts(n_kf);
+  for (int k = 0; k < n_kf; k++) {
+    kfs[k].view = rd(f, {4, 4}); kfs[k].proj = rd(f, {4, 4}); kfs[k].campos = rd(f, {3}); kfs[k].pose7 = rd(f, {7});
+    kfs[k].tanfovx = tf[0]; kfs[k].tanfovy = tf[1];
+    gts[k] = rd(f, {3, H, W});
+  }
+  segs_host::DensifyParams dp;
+  dp.start_stat = hdr[7]; dp.update_from = hdr[8]; dp.update_interval = hdr[9]; dp.update_until = 1000000000;
+  dp.voxel_size = (double)tf[3]; dp.densify_grad_threshold = (double)tf[4];
+  segs_host::AnchorDensifier dens(step.model(), dp);
+  step.enable_densification(&dens, (uint64_t)hdr[10]);
+  c10::intrusive_ptr<c10d::Backend> pg;
+  if (nccl1) {
+#ifdef SEGS_TEST_WITH_NCCL
+    auto store = c10::make_intrusive<c10d::FileStore>(store_path, 1);
+    auto opts = c10d::ProcessGroupNCCL::Options::create();
+    pg = c10::make_intrusive<c10d::ProcessGroupNCCL>(store, 0, 1, opts);
+    step.set_process_group(pg, !dense, /*single_rank_collectives=*/true);
+#else
+    std::fprintf(stderr, "built without SEGS_TEST_WITH_NCCL\n");
+    return 3;
+#endif
+  } else if (world > 1) {
+    auto store = c10::make_intrusive<c10d::FileStore>(store_path, world);
+    pg = c10::make_intrusive<StoreBackend>(store, rank, world);
+    step.set_process_group(pg, !dense);
+  }
+  std::vector<float> losses;
+  std::vector<int32_t> sizes;
+  for (int it = 0; it < n_steps; it++) {
+    const int k = (it * world + rank) % n_kf;
+    auto loss = step.trainingOnce(kfs[k], gts[k]);
+    losses.push_back(loss.item<float>());
+    sizes.push_back((int32_t)step.model().A);
+  }
+  torch::cuda::synchronize();
+  auto& m = step.model();
+  std::ofstream o(out, std::ios::binary);
+  const int32_t head[4] = {(int32_t)m.A, (int32_t)m.capacity, (int32_t)step.steps_taken(), (int32_t)step.anchor_steps_taken()};
+  o.write(reinterpret_cast<const char*>(head), sizeof(head));
+  o.write(reinterpret_cast<const char*>(sizes.data()), sizes.size() * 4);
+  o.write(reinterpret_cast<const char*>(losses.data()), losses.size() * 4);
+  for (const char* name : {"anchor", "offset", "anchor_feat", "scaling"}) wr(o, m.param(name));
+  wr(o, m.mlp_params());
+  for (const char* name : {"opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"}) wr(o, dens.stat(name));
+  std::printf("trainer_test --mapper ok rank %d/%d A %d -> %d capacity %d steps %d/%d\n", rank, world, A, (int)m.A, (int)m.capacity,
+              (int)step.steps_taken(), (int)step.anchor_steps_taken());
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 4 && std::string(argv[1]) == "--mapper") return run_mapper(argc, argv);
+  if (argc < 3) { std::fprintf(stderr, "usage: trainer_test in.bin out.bin | trainer_test --mapper in.bin out.bin [...]\n"); return 2; }
+  return run_single(argv[1], argv[2]);
 }

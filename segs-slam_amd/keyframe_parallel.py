@@ -144,7 +144,8 @@ class BucketExchange:
             return
         assert bucket.numel() == self.n
         lo, hi = self.shard_range()
-        self._shard.zero_()
+        if hi - lo < self.shard_len:
+            self._shard[hi - lo:].zero_()          # (only the last rank's shard has a padded tail)
         self._shard[:hi - lo].copy_(bucket[lo:hi])
         if self._emulate:
             parts = [torch.empty_like(self._shard) for _ in range(self.world)]

@@ -21,8 +21,12 @@ def test_trainer_twin_is_built_and_links_the_c_abi():
     subprocess.check_call(["make", "-C", TB, "-s", "-j4"])
     out = subprocess.check_output(["nm", "-DC", os.path.join(TB, "libgaussian_trainer.so")], text=True)
     assert any("segs_host::GaussianTrainerStep::trainingOnce(" in l and " T " in l for l in out.splitlines())
+    for cls in ("segs_host::AnchorDensifier::adjust_anchor(", "segs_host::AnchorDensifier::training_statis(",
+                "segs_host::KeyframeExchange::reduce_gradients(", "segs_host::KeyframeExchange::gather("):
+        assert any(cls in l and " T " in l for l in out.splitlines()), cls
     for sym in ("segs_visible_filter", "segs_neural_forward", "segs_rasterize_forward_resident", "segs_l1_ssim_loss",
-                "segs_rasterize_backward_resident", "segs_neural_backward", "segs_adam_step_device"):
+                "segs_rasterize_backward_resident", "segs_neural_backward", "segs_adam_step_device", "segs_training_statis_guarded",
+                "segs_anchor_growing_level"):
         assert any(l.strip().endswith("U " + sym) for l in out.splitlines()), sym      # resolved from libsegs_raster.so
     assert os.path.exists(os.path.join(TB, "trainer_test"))
 
@@ -84,3 +88,141 @@ def test_cpp_trainer_matches_python_step(tmp_path, cfg):
     bad = err > 2e-3 * np.abs(upd) + 1e-6
     assert moved.mean() > 0.05 and bad.mean() < 5e-3, (float(moved.mean()), float(bad.mean()), float(err.max()))
     assert err.max() <= 2 * n_steps * 0.08, float(err.max())
+
+
+# ---- the mapper loop in C++: densification (anchor_densifier.{h,cpp}) and the keyframe-parallel exchange (keyframe_exchange.{h,cpp})
+def _mapper_case(tmp_path, n_steps=12, A=3000, W=320, H=240, seed=3):
+    from segs_slam_amd import neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    cams, kfs = [], []
+    for k in range(2):
+        ang = 0.04 * (k + 1)
+        R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], dtype=np.float32)
+        cam = scenes.make_camera(W, H, 300.0, 300.0, R, np.array([0.05 * k, 0.0, 0.0], dtype=np.float32))
+        pose7 = np.array([0.05 * k, 0.0, 0.0, 1.0, 0.0, ang, 0.0], dtype=np.float32)
+        cams.append((cam, pose7))
+    dims = ng.ModelDims()
+    model = ng.synthetic_model(A, dims, cams[0][0], dev, seed=7)
+    gts = [np.full((3, H, W), 0.3 + 0.2 * k, dtype=np.float32) for k in range(2)]
+    dp = dict(voxel_size=0.01, start_stat=2, update_from=5, update_interval=10, densify_grad_threshold=1e-7)
+    fin = tmp_path / "mapper_in.bin"
+    with open(fin, "wb") as f:
+        np.array([A, W, H, dims.appearance_dim, int(dims.use_feat_bank), n_steps, 2, dp["start_stat"], dp["update_from"],
+                  dp["update_interval"], seed], np.int32).tofile(f)
+        np.array([cams[0][0].tanfovx, cams[0][0].tanfovy, 0.0, dp["voxel_size"], dp["densify_grad_threshold"]], np.float32).tofile(f)
+        for name in ("anchor", "offset", "anchor_feat", "scaling"):
+            model.param(name).cpu().numpy().astype(np.float32).tofile(f)
+        model.mlp_params.cpu().numpy().astype(np.float32).tofile(f)
+        for (cam, pose7), gt in zip(cams, gts):
+            for a in (cam.world_view_transform, cam.full_proj_transform, cam.camera_center, pose7, gt):
+                np.ascontiguousarray(a, np.float32).tofile(f)
+    return dict(fin=fin, model=model, dims=dims, cams=cams, gts=gts, dp=dp, n_steps=n_steps, A=A, W=W, H=H, seed=seed, dev=dev)
+
+
+def _read_mapper_out(path, n_steps, dims):
+    raw = np.fromfile(path, np.uint8)
+    head = raw[:16].view(np.int32)
+    A, capacity, mlp_steps, anchor_steps = (int(v) for v in head)
+    off = 16
+    sizes = raw[off:off + 4 * n_steps].view(np.int32).copy(); off += 4 * n_steps
+    fl = raw[off:].view(np.float32)
+    out = dict(A=A, capacity=capacity, steps=(mlp_steps, anchor_steps), sizes=sizes, losses=fl[:n_steps].copy())
+    p = n_steps
+    no = dims.n_offsets
+    for name, w in (("anchor", 3), ("offset", 3 * no), ("anchor_feat", dims.feat_dim), ("scaling", 6)):
+        out[name] = fl[p:p + A * w].copy(); p += A * w
+    n_stats = 2 * A + 2 * A * no
+    out["mlp"] = fl[p:fl.size - n_stats].copy()
+    p = fl.size - n_stats
+    for name, n in (("opacity_accum", A), ("anchor_demon", A), ("offset_gradient_accum", A * no), ("offset_denom", A * no)):
+        out[name] = fl[p:p + n].copy(); p += n
+    return out
+
+
+@pytest.mark.gpu
+def test_cpp_mapper_loop_grows_and_prunes_like_the_python_loop(tmp_path):
+    """trainingOnce with densification in C++ (statistics every iteration of the window, adjust_anchor at iteration 10, the Adam
+    state migrated with the rows, the anchor groups skipping that iteration's step) against the Python loop on the same model,
+    keyframes and random keep masks (same LibTorch CPU generator stream on both sides).  The statistics are float sums of
+    atomically accumulated gradients, so the two runs agree the way two runs of either twin do: the map size to 0.5 %, the
+    integer counters exactly, the losses to 1e-4 before the map changes."""
+    from segs_slam_amd import densify, neural_gaussians as ng
+    c = _mapper_case(tmp_path)
+    exe = os.path.join(TB, "trainer_test")
+    fout = tmp_path / "mapper_out.bin"
+    subprocess.check_call([exe, "--mapper", str(c["fin"]), str(fout)])
+    cpp = _read_mapper_out(fout, c["n_steps"], c["dims"])
+
+    dev = c["dev"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kfs = [ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center), t(p7), cam.tanfovx, cam.tanfovy)
+           for cam, p7 in c["cams"]]
+    gts = [t(g) for g in c["gts"]]
+    step = ng.ScaffoldTrainerStep(c["model"], c["W"], c["H"])
+    dp = c["dp"]
+    dens = densify.AnchorDensifier(c["model"], densify.DensifyParams(voxel_size=dp["voxel_size"], start_stat=dp["start_stat"],
+                                                                      update_from=dp["update_from"], update_interval=dp["update_interval"],
+                                                                      update_until=10 ** 9, densify_grad_threshold=dp["densify_grad_threshold"]))
+    step.enable_densification(dens, seed=c["seed"])
+    losses, sizes = [], []
+    for _ in range(c["n_steps"]):
+        losses.append(float(step.training_once(kfs, gts)))
+        sizes.append(c["model"].A)
+    torch.cuda.synchronize()
+    assert cpp["steps"] == (c["n_steps"], c["n_steps"] - 1) == (step._mlp_count.value(), step._anchor_count.value())
+    assert list(cpp["sizes"][:9]) == sizes[:9] == [c["A"]] * 9 and cpp["sizes"][-1] != c["A"]
+    assert abs(int(cpp["sizes"][-1]) - sizes[-1]) <= 0.005 * sizes[-1], (cpp["sizes"][-1], sizes[-1])
+    np.testing.assert_allclose(cpp["losses"][:10], losses[:10], rtol=1e-4)
+    np.testing.assert_allclose(cpp["losses"][10:], losses[10:], rtol=2e-2)
+    assert cpp["capacity"] >= cpp["A"] and np.isfinite(cpp["mlp"]).all() and np.isfinite(cpp["anchor"]).all()
+    # integer-valued view counters (reset only for the anchors seen in more than 80 % of the window): same set of values
+    m = c["model"]
+    assert np.array_equal(np.unique(cpp["anchor_demon"]), np.unique(dens.stat("anchor_demon").cpu().numpy()))
+    assert abs(float(cpp["anchor_demon"].sum()) - float(dens.stat("anchor_demon").sum())) <= 0.01 * float(cpp["anchor_demon"].sum())
+    # the MLP block took the same 12 steps from the same start: close wherever the update is more than noise
+    mlp_py = m.mlp_params.cpu().numpy()
+    assert np.mean(np.abs(cpp["mlp"] - mlp_py) > 2e-2 * np.abs(mlp_py) + 1e-3) < 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["dense", "sharded"])
+def test_two_cpp_ranks_keep_bit_identical_replicas_through_adjust_anchor(tmp_path, mode):
+    """Two processes of trainer_test (both on cuda:0) as keyframe-parallel ranks: each renders its own keyframe, the overflow
+    word and the gradient bucket are exchanged through KeyframeExchange (over the test's store-backed c10d::Backend: host
+    staging, rank-ordered sums), the densification statistics are summed over ranks before adjust_anchor.  Everything the
+    ranks hold must be bit-identical afterwards, in both exchange modes."""
+    c = _mapper_case(tmp_path)
+    exe = os.path.join(TB, "trainer_test")
+    store = tmp_path / f"store_{mode}"
+    procs = []
+    for r in range(2):
+        cmd = [exe, "--mapper", str(c["fin"]), str(tmp_path / f"out_{mode}_{r}.bin"), "--world", "2", "--rank", str(r), "--store", str(store)]
+        if mode == "dense":
+            cmd.append("--dense")
+        procs.append(subprocess.Popen(cmd))
+    assert [p.wait(timeout=300) for p in procs] == [0, 0]
+    r0, r1 = (_read_mapper_out(tmp_path / f"out_{mode}_{r}.bin", c["n_steps"], c["dims"]) for r in range(2))
+    assert r0["steps"] == r1["steps"] == (c["n_steps"], c["n_steps"] - 1)
+    assert r0["A"] == r1["A"] != c["A"] and list(r0["sizes"]) == list(r1["sizes"]) and r0["sizes"][8] == c["A"]
+    for k in ("anchor", "offset", "anchor_feat", "scaling", "mlp", "opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert not np.array_equal(r0["losses"], r1["losses"])          # (each rank reports its own keyframe's loss)
+    # two views per iteration of the window (iterations 3..12) are counted, and the counters are whole numbers
+    assert 10.0 < r0["anchor_demon"].max() <= 2.0 * (c["n_steps"] - 2) and np.array_equal(r0["anchor_demon"], np.round(r0["anchor_demon"]))
+
+
+@pytest.mark.gpu
+def test_cpp_exchange_through_a_one_rank_rccl_group(tmp_path):
+    """The same loop with a ONE-rank c10d::ProcessGroupNCCL constructed in C++ and every collective forced: the overflow word's
+    all-reduce, reduce_scatter -> Adam on the shard -> all_gather (and the dense all-reduce of the adjust_anchor iteration)
+    run through RCCL from the C++ host.  With one rank they are identities: the run must behave like the plain one."""
+    c = _mapper_case(tmp_path)
+    exe = os.path.join(TB, "trainer_test")
+    plain, nccl = tmp_path / "plain.bin", tmp_path / "nccl.bin"
+    subprocess.check_call([exe, "--mapper", str(c["fin"]), str(plain)])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.check_call([exe, "--mapper", str(c["fin"]), str(nccl), "--nccl1", str(tmp_path / "nccl_store")], env=env)
+    a, b = (_read_mapper_out(p, c["n_steps"], c["dims"]) for p in (plain, nccl))
+    assert a["steps"] == b["steps"] == (c["n_steps"], c["n_steps"] - 1)
+    assert list(a["sizes"][:9]) == list(b["sizes"][:9]) and abs(a["A"] - b["A"]) <= 0.005 * a["A"]
+    np.testing.assert_allclose(a["losses"][:10], b["losses"][:10], rtol=1e-4)
