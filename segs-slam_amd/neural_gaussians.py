@@ -327,6 +327,10 @@ class ScaffoldTrainerStep:
         self.neural = NeuralGaussians(model)
         self.engine = RasterEngine(self.neural.P_capacity, width, height, dev, resident=True, skip_nonpositive_opacity=True)
         self.loss_fn = FusedL1SSIM(height, width, dev, self.opt.lambda_dssim)
+        # Gaussian-pyramid training (src/gaussian_mapper.cpp:837-858, 872-875, 913-915): a keyframe is trained at the size of
+        # its current pyramid level, i.e. of the target image it hands over.  One rasterizer engine + loss object per size,
+        # made on first use; `engine` / `loss_fn` / `W` / `H` always name the level of the iteration in flight.
+        self._levels = {(self.W, self.H): (self.engine, self.loss_fn)}
         self.bg = torch.zeros(3, dtype=torch.float32, device=dev)      # Model.white_background: set_background(True)
         self.visible_radii = torch.zeros(model.capacity, dtype=torch.int32, device=dev)
         self.spatial_lr_scale = float(spatial_lr_scale)
@@ -438,11 +442,27 @@ class ScaffoldTrainerStep:
         _capi.check(st, "segs_visible_filter")
         return self.visible_radii
 
+    def use_level(self, width: int, height: int):
+        """Make (width, height) the size of the iteration in flight (a pyramid level of the keyframe: same field of view,
+        fewer pixels)."""
+        key = (int(width), int(height))
+        if key == (self.W, self.H):
+            return
+        lv = self._levels.get(key)
+        if lv is None:
+            lv = self._levels[key] = (RasterEngine(self.neural.P_capacity, key[0], key[1], self.model.device, resident=True,
+                                                   skip_nonpositive_opacity=True),
+                                      FusedL1SSIM(key[1], key[0], self.model.device, self.opt.lambda_dssim))
+        self._levels[(self.W, self.H)] = (self.engine, self.loss_fn)     # (a caller may have wrapped the current level's loss)
+        self.engine, self.loss_fn = lv
+        self.W, self.H = key
+
     def render(self, kf: Keyframe) -> torch.Tensor:
         ng = self.neural
-        if self.model.capacity * self.model.dims.n_offsets > self.engine.P:   # the map outgrew the engine's buffers
+        if self.model.capacity * self.model.dims.n_offsets > self.engine.P:   # the map outgrew the engines' buffers
             self.engine = RasterEngine(self.model.capacity * self.model.dims.n_offsets, self.W, self.H, self.model.device,
                                        resident=True, skip_nonpositive_opacity=True)
+            self._levels = {(self.W, self.H): (self.engine, self.loss_fn)}   # the other levels' engines are re-made on use
             self.visible_radii = torch.zeros(self.model.capacity, dtype=torch.int32, device=self.model.device)
         ng.forward(kf.campos, kf.pose7, self.prefilter_voxel(kf))
         self.engine.set_active(ng.P)
@@ -450,6 +470,7 @@ class ScaffoldTrainerStep:
                                    kf.campos, kf.tanfovx, kf.tanfovy)
 
     def _forward_backward(self, kf: Keyframe, gt: torch.Tensor, exchange=None):
+        self.use_level(gt.shape[-1], gt.shape[-2])
         if self.model.A == 0:
             # every anchor was pruned: the reference's rasterizer short-circuits P == 0 to a zero image
             # (src/rasterize_points.cu:81) and nothing receives a gradient

@@ -266,3 +266,48 @@ def test_second_slab_of_persistent_workgroups_is_consistent():
         assert torch.equal(big.grad(name), torch.cat([s1.grad(name), s2.grad(name)], dim=0)), name
     ref = s1.mlp_grads + s2.mlp_grads
     assert float((big.mlp_grads - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_scaffold_step_alternates_pyramid_levels_on_one_step_object():
+    """Gaussian-pyramid training (src/gaussian_mapper.cpp:837-858: a keyframe is trained at the size of its current pyramid
+    level): one ScaffoldTrainerStep takes targets of two sizes in turn.  Every iteration's render must equal, bit for bit, a
+    reference-shaped render of the same neural Gaussians at that size; the optimizer takes every step; the loss of each level
+    goes down; and the first low-resolution iteration equals the first iteration of a step built for that size alone."""
+    from segs_slam_amd import neural_gaussians as ng, scenes
+    from segs_slam_amd.raster_engine import RasterEngine
+    dev = torch.device("cuda:0")
+    sizes = [(320, 240), (160, 120)]
+    cam = scenes.make_camera(320, 240, 300.0, 300.0, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    g = torch.Generator().manual_seed(5)
+    full = torch.rand(3, 240, 320, generator=g)
+    gts = {sizes[0]: full.to(dev), sizes[1]: torch.nn.functional.avg_pool2d(full[None], 2)[0].contiguous().to(dev)}
+
+    model = ng.synthetic_model(3000, ng.ModelDims(), cam, dev, seed=9)
+    step = ng.ScaffoldTrainerStep(model, *sizes[0])
+    alone = ng.ScaffoldTrainerStep(ng.synthetic_model(3000, ng.ModelDims(), cam, dev, seed=9), *sizes[1])
+    loss_alone = float(alone.training_once([kf], [gts[sizes[1]]]))
+    losses = {s: [] for s in sizes}
+    order = [sizes[1], sizes[0], sizes[1], sizes[0], sizes[1], sizes[0]]
+    for it, sz in enumerate(order):
+        loss = float(step.training_once([kf], [gts[sz]]))
+        assert (step.W, step.H) == sz and step.engine.out_color.shape == (3, sz[1], sz[0])
+        losses[sz].append(loss)
+        if it == 0:
+            assert loss == loss_alone
+        # the image this iteration rendered (from the parameters BEFORE its update): re-render now-current parameters instead and
+        # compare with the reference-shaped path at the same size
+        img = step.render(kf).clone()
+        ngs = step.neural
+        ref = RasterEngine(ngs.P_capacity, sz[0], sz[1], dev, resident=False, skip_nonpositive_opacity=True)
+        ref.set_active(ngs.P)
+        img_ref = ref.forward(step.bg, ngs.means3D, ngs.colors, ngs.opacity, ngs.scales, ngs.rotations, kf.view, kf.proj, kf.campos,
+                              kf.tanfovx, kf.tanfovy)
+        assert torch.equal(img, img_ref), (it, sz)
+    torch.cuda.synchronize()
+    assert step._mlp_count.value() == len(order) and step.dropped_steps() == 0
+    for sz in sizes:
+        assert losses[sz][-1] < losses[sz][0], (sz, losses[sz])
+    assert len(step._levels) == 2

@@ -100,17 +100,75 @@ def assert_forward_parity(sc, o, g, R):
 
 
 GRAD_REL, GRAD_FLOOR, GRAD_PURE_FRACTION = 1e-4, 1e-5, 0.99
+STAGE_TENSORS = ("dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot")     # outputs of the per-Gaussian backward stage (K12 + K13 + cov3D)
 
 
-def assert_grad_close(name, a, b):
+def pure_fraction(err, ref):
+    nz = ref != 0
+    return float((err[nz] <= GRAD_REL * np.abs(ref[nz])).mean()) if nz.any() else 1.0
+
+
+def assert_grad_close(name, a, b, arbiter=None):
+    """The gradient bar (a = device, b = float32 CPU oracle):
+      (1) every entry within 1e-4 relative + 1e-5 of the tensor's largest entry (the floor covers entries that are the float32
+          sum of large terms of both signs -- SURVEY 8c asks for 1e-7 absolute, which float atomics in arbitrary order cannot
+          give on such entries; profiles/r02_grad_error.txt);
+      (2) at least 99 % of the non-zero entries inside the PURE 1e-4 relative bound, no floor;
+      (3) where (2) fails on an output of the per-Gaussian backward stage -- scenes whose few visible Gaussians each cover
+          thousands of pixels: float32 sums of both signs in the ORACLE too -- `arbiter(name)` evaluates that stage in float64
+          from its defining equations on the oracle's own inputs (oracle/preprocess_backward_f64.py) and returns
+          (device stage output, oracle stage output, float64 value): the device passes iff it is inside (1) against the
+          float64 value and inside the pure bound on at least as many entries as the oracle is (-0.5 %).  The oracle is only as
+          good a reference as float32 lets it be; the rule says so instead of a hand-kept list of accepted seeds."""
     err = np.abs(a - b)
     tol = GRAD_REL * np.abs(b) + GRAD_FLOOR * (np.abs(b).max() + 1e-30)
     bad = err > tol
     assert not bad.any(), (name, int(bad.sum()), float(err.max()), float(np.abs(b).max()))
     nz = b != 0
     if nz.sum() >= 1000:     # most entries must pass WITHOUT the floor (it only covers the cancellation-dominated ones)
-        pure = float((err[nz] <= GRAD_REL * np.abs(b[nz])).mean())
-        assert pure >= GRAD_PURE_FRACTION, (name, pure)
+        pure = pure_fraction(err, b)
+        if pure >= GRAD_PURE_FRACTION:
+            return "pure"
+        assert arbiter is not None and name in STAGE_TENSORS, (name, pure)
+        dev64, ora64, truth = arbiter(name)
+        e_dev, e_ora = np.abs(dev64 - truth), np.abs(ora64 - truth)
+        top = np.abs(truth).max()
+        assert np.all(e_dev <= GRAD_REL * np.abs(truth) + GRAD_FLOOR * top), (name, "device vs float64", float(e_dev.max() / top))
+        f_dev, f_ora = pure_fraction(e_dev, truth), pure_fraction(e_ora, truth)
+        assert f_dev >= f_ora - 0.005, (name, "device worse than the oracle against float64", f_dev, f_ora, pure)
+        return f"arbiter: device {f_dev:.4f} / oracle {f_ora:.4f} of the entries within 1e-4 of float64 (device vs oracle {pure:.4f})"
+    return "pure"
+
+
+def stage_arbiter(sc, o, ref):
+    """name -> (device, oracle, float64) outputs of the per-Gaussian backward stage, all three fed the ORACLE's dL_dmean2D /
+    dL_dconic (so that only this stage's arithmetic is compared).  Evaluated lazily, once."""
+    import ctypes as C
+    from segs_slam_amd import _capi
+    from oracle.preprocess_backward_f64 import stage_f64
+    cache = {}
+
+    def get(name):
+        if not cache:
+            cam, P = sc.camera, sc.P
+            m3, sca, rot = _t(sc.means3D), _t(sc.scales), _t(sc.rotations)
+            view, proj = _t(cam.world_view_transform), _t(cam.full_proj_transform)
+            radii = _t(o.get("radii"), torch.int32)
+            d2, dc = _t(ref["dL_dmean2D"]), _t(ref["dL_dconic"])
+            outs = [torch.empty((P, n), device=DEV) for n in (3, 6, 3, 4)]
+            p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+            _capi.check(_capi.lib().segs_debug_preprocess_backward(P, cam.width, cam.height, p(m3), p(radii), p(sca), 1.0, p(rot), None,
+                                                                   p(view), p(proj), cam.tanfovx, cam.tanfovy, p(d2), p(dc),
+                                                                   *[p(x) for x in outs],
+                                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "segs_debug_preprocess_backward")
+            torch.cuda.synchronize()
+            truth = stage_f64(sc.means3D, sc.scales, sc.rotations, cam.world_view_transform, cam.full_proj_transform, cam.width,
+                              cam.height, cam.tanfovx, cam.tanfovy, ref["dL_dmean2D"], ref["dL_dconic"], o.get("radii"))
+            for x, k in zip(outs, STAGE_TENSORS):
+                cache[k] = (x.cpu().numpy().astype(np.float64), ref[k].astype(np.float64).reshape(truth[k].shape), truth[k])
+        return cache[name]
+    return get
 
 
 def run_parity(sc, backward=True):
@@ -127,8 +185,11 @@ def run_parity(sc, backward=True):
         dL[:, unstable] = 0.0
         ref = o.backward(dL)
         got = gpu_backward(sc, args, fwd, dL)
+        arb = stage_arbiter(sc, o, ref)
+        how = {}
         for k in ("dL_dmean2D", "dL_dcolor", "dL_dopacity", "dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot"):
-            assert_grad_close(k, got[k].reshape(ref[k].shape), ref[k])
+            how[k] = assert_grad_close(k, got[k].reshape(ref[k].shape), ref[k], arbiter=arb)
+        o.grad_verdicts = how
     return o, g
 
 
@@ -178,18 +239,11 @@ def test_degenerate_inputs():
         rp.RasterizeGaussiansCUDA(e, torch.zeros(4, 2, device=DEV), e, e, e, e, 1.0, e, e, e, 1.0, 1.0, 8, 8, e, 0, e, False)
 
 
-def test_preprocess_backward_alone_matches_float64_evaluation():
-    """K12 + K13 + cov3D backward alone, fed the oracle's dL_dmean2D / dL_dconic.  The device code is derived from the forward
-    map (preprocess.hip: dL/dC = -k adj(C) G adj(C), factorised through U = M2 L) instead of following backward.cu's
-    expression tree, so device and oracle are two float32 evaluations of the same function; the arbiter is a float64
-    evaluation of the defining equations (oracle/preprocess_backward_f64.py).  Both must sit within float32 rounding of it:
-    1e-5 relative + 4e-6 of the tensor's largest entry (measured: device 1e-7 ... 1e-6, oracle 2e-7 ... 2.4e-6 of max|truth|)."""
+def _stage_outputs(sc, o, ref, cov3D_precomp=None):
+    """(device outputs, float64 truth) of the per-Gaussian backward stage fed the oracle's dL_dmean2D / dL_dconic."""
     import ctypes as C
     from oracle.preprocess_backward_f64 import stage_f64
     from segs_slam_amd import _capi
-    sc = scenes.make_scene(4000, 128, 96, 100.0, 100.0, seed=77, bg=(0.2, 0.2, 0.2))
-    sc.scales *= 3.0
-    o, ref = gs_oracle.run_scene(sc)
     cam = sc.camera
     P = sc.P
     m3, sca, rot = _t(sc.means3D), _t(sc.scales), _t(sc.rotations)
@@ -198,20 +252,76 @@ def test_preprocess_backward_alone_matches_float64_evaluation():
     d2, dc = _t(ref["dL_dmean2D"]), _t(ref["dL_dconic"])
     outs = [torch.empty((P, n), device=DEV) for n in (3, 6, 3, 4)]
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    st = _capi.lib().segs_debug_preprocess_backward(P, cam.width, cam.height, p(m3), p(radii), p(sca), 1.0, p(rot), None,
+    pre = _t(cov3D_precomp) if cov3D_precomp is not None else None
+    st = _capi.lib().segs_debug_preprocess_backward(P, cam.width, cam.height, p(m3), p(radii), None if pre is not None else p(sca), 1.0,
+                                                    None if pre is not None else p(rot), p(pre) if pre is not None else None,
                                                     p(view), p(proj), cam.tanfovx, cam.tanfovy, p(d2), p(dc),
-                                                    *[p(t) for t in outs], C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                                    p(outs[0]), p(outs[1]), None if pre is not None else p(outs[2]),
+                                                    None if pre is not None else p(outs[3]), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _capi.check(st, "segs_debug_preprocess_backward")
     torch.cuda.synchronize()
-    ref2 = o.backward(sc.dL_dout_color, ref["dL_dmean2D"], ref["dL_dconic"])
     truth = stage_f64(sc.means3D, sc.scales, sc.rotations, cam.world_view_transform, cam.full_proj_transform, cam.width, cam.height,
                       cam.tanfovx, cam.tanfovy, ref["dL_dmean2D"], ref["dL_dconic"], o.get("radii"))
-    for t, k in zip(outs, ("dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot")):
+    return outs, truth
+
+
+def test_preprocess_backward_alone_matches_float64_evaluation():
+    """K12 + K13 + cov3D backward alone, fed the oracle's dL_dmean2D / dL_dconic.  The device code is derived from the forward
+    map (preprocess.hip: dL/dC = -k adj(C) G adj(C), factorised through U = M2 L) instead of following backward.cu's
+    expression tree, so device and oracle are two float32 evaluations of the same function; the arbiter is a float64
+    evaluation of the defining equations (oracle/preprocess_backward_f64.py).  Both must sit within float32 rounding of it:
+    1e-5 relative + 4e-6 of the tensor's largest entry (measured: device 1e-7 ... 1e-6, oracle 2e-7 ... 2.4e-6 of max|truth|)."""
+    sc = scenes.make_scene(4000, 128, 96, 100.0, 100.0, seed=77, bg=(0.2, 0.2, 0.2))
+    sc.scales *= 3.0
+    o, ref = gs_oracle.run_scene(sc)
+    outs, truth = _stage_outputs(sc, o, ref)
+    ref2 = o.backward(sc.dL_dout_color, ref["dL_dmean2D"], ref["dL_dconic"])
+    for t, k in zip(outs, STAGE_TENSORS):
         want = truth[k]
         assert np.abs(want).max() > 0
         for who, got in (("device", t.cpu().numpy().astype(np.float64)), ("oracle", ref2[k].astype(np.float64))):
             err = np.abs(got - want)
             assert np.all(err <= 1e-5 * np.abs(want) + 4e-6 * np.abs(want).max()), (who, k, float(err.max()), float(np.abs(want).max()))
+
+
+def test_preprocess_backward_clamped_jacobian_and_precomputed_covariance_branches():
+    """Two branches of the stage that ordinary scenes reach only by chance (fuzz sweeps), pinned deterministically:
+      * the clamped Jacobian (backward.cu:175-176, forward.cu:84-89: t.x / t.z limited to 1.3 tan(fov/2), the clamped
+        coordinate passes no gradient): a scene widened to 1.5 tan(fov/2) with Gaussians large enough to stay visible there;
+      * cov3D_precomp (backward.cu:287-290 is skipped, dL_dcov3D is the output): the same scene handed over as covariances."""
+    sc = scenes.make_scene(4000, 128, 96, 100.0, 100.0, seed=78, bg=(0.0, 0.0, 0.0))
+    sc.means3D[:, :2] *= 1.25          # make_scene draws |x| <= 1.2 z tan(fov/2): now up to 1.5
+    sc.scales *= 10.0
+    o, ref = gs_oracle.run_scene(sc)
+    cam = sc.camera
+    V = cam.world_view_transform.reshape(4, 4).astype(np.float64)
+    t = sc.means3D.astype(np.float64) @ V[:3, :3] + V[3, :3]
+    vis = o.get("radii") > 0
+    clamped = vis & ((np.abs(t[:, 0] / t[:, 2]) > 1.3 * cam.tanfovx) | (np.abs(t[:, 1] / t[:, 2]) > 1.3 * cam.tanfovy))
+    assert clamped.sum() > 100, int(clamped.sum())
+    outs, truth = _stage_outputs(sc, o, ref)
+    ref2 = o.backward(sc.dL_dout_color, ref["dL_dmean2D"], ref["dL_dconic"])
+    for tns, k in zip(outs, STAGE_TENSORS):
+        want = truth[k]
+        sub = want[clamped]
+        assert np.abs(sub).max() > 0
+        for who, got in (("device", tns.cpu().numpy().astype(np.float64)), ("oracle", ref2[k].astype(np.float64))):
+            err = np.abs(got - want)
+            assert np.all(err <= 1e-5 * np.abs(want) + 4e-6 * np.abs(want).max()), (who, k, float(err.max()), float(np.abs(want).max()))
+    # the same Gaussians as precomputed covariances (R S S^T R^T, the quaternion used as given, forward.cu:118-152)
+    r, x, y, z = sc.rotations.astype(np.float64).T
+    R = np.stack([np.stack([1 - 2 * (y*y + z*z), 2 * (x*y - r*z), 2 * (x*z + r*y)], 1),
+                  np.stack([2 * (x*y + r*z), 1 - 2 * (x*x + z*z), 2 * (y*z - r*x)], 1),
+                  np.stack([2 * (x*z - r*y), 2 * (y*z + r*x), 1 - 2 * (x*x + y*y)], 1)], 1)
+    L = R * sc.scales.astype(np.float64)[:, None, :]
+    S = L @ L.transpose(0, 2, 1)
+    cov6 = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)
+    outs_pre, _ = _stage_outputs(sc, o, ref, cov3D_precomp=cov6)
+    for tns, k in zip(outs_pre[:2], STAGE_TENSORS[:2]):
+        want = truth[k]
+        err = np.abs(tns.cpu().numpy().astype(np.float64) - want)
+        # (the covariances were rounded to float32 once more on the way in: 1e-5 relative + 1e-5 of max)
+        assert np.all(err <= 1e-5 * np.abs(want) + 1e-5 * np.abs(want).max()), (k, float(err.max()), float(np.abs(want).max()))
 
 
 # sizes on both sides of the count kernel's chunk policy (1 / 2 / 4 tiles per chunk at <= 256 / <= 2048 / more sort tiles) and
@@ -441,6 +551,30 @@ def test_device_gradients_match_independent_float64_autograd():
         nz = want != 0
         pure = float((err[nz] <= 1e-4 * np.abs(want[nz])).mean())
         assert pure >= 0.95, (k, pure)
+
+
+def fuzz_scene(seed):
+    """The scene tools/fuzz_raster.py builds for one seed."""
+    rng = np.random.default_rng(seed)
+    P = int(rng.choice([1, 3, 50, 700, 4000, 20000, 60000]))
+    W, H = int(rng.integers(17, 400)), int(rng.integers(17, 300))
+    f = float(rng.uniform(0.4, 1.5)) * max(W, H)
+    bg = tuple(float(x) for x in rng.choice([0.0, 0.5, 1.0], size=3))
+    sc = scenes.make_scene(P, W, H, f, f, seed=seed, bg=bg)
+    sc.scales *= float(rng.choice([0.3, 1.0, 3.0, 10.0]))
+    if rng.random() < 0.3:
+        sc.opacity[:] = (sc.opacity * float(rng.choice([0.02, 0.2]))).astype(np.float32)
+    return sc
+
+
+@pytest.mark.parametrize("seed", [21117, 41105, 51072])
+def test_extreme_overdraw_cases_pass_under_the_float64_arbiter_rule(seed):
+    """The three cases of round 2's fuzz sweeps (profiles/r02_fuzz_summary.txt) that fell under the 99 % pure-relative bar
+    against the float32 oracle -- tens of thousands of Gaussians at 10x scale on a ~150x60 image, a few hundred visible, each
+    covering thousands of pixels -- as tests under rule (3) of assert_grad_close instead of accepted failures of a tool."""
+    sc = fuzz_scene(seed)
+    o, _ = run_parity(sc, backward=True)
+    assert all(v == "pure" or v.startswith("arbiter") for v in o.grad_verdicts.values()), o.grad_verdicts
 
 
 def test_tiles_touched_by_gather_path_gives_the_same_binning():

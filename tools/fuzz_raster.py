@@ -85,34 +85,30 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 fails = 0
 for i in range(n_cases):
-    rng = np.random.default_rng(seed0 + i)
-    P = int(rng.choice([1, 3, 50, 700, 4000, 20000, 60000]))
-    W, H = int(rng.integers(17, 400)), int(rng.integers(17, 300))
-    f = float(rng.uniform(0.4, 1.5)) * max(W, H)
-    bg = tuple(float(x) for x in rng.choice([0.0, 0.5, 1.0], size=3))
-    sc = scenes.make_scene(P, W, H, f, f, seed=seed0 + i, bg=bg)
-    sc.scales *= float(rng.choice([0.3, 1.0, 3.0, 10.0]))
-    if rng.random() < 0.3:
-        sc.opacity[:] = (sc.opacity * float(rng.choice([0.02, 0.2]))).astype(np.float32)   # many Gaussians near / below 1/255
+    sc = t.fuzz_scene(seed0 + i)
+    P, W, H = sc.P, sc.camera.width, sc.camera.height
     try:
         # the oracle comparison needs a scene whose compositing decisions are not threshold-adjacent on > 1 % of the pixels
         # (dim, huge Gaussians put most alphas next to 1/255); such scenes still go through the resident-vs-sync check
         o, _ = t.gs_oracle.run_scene(sc, backward=False)
         comparable = o.unstable_pixels(1e-5).mean() < 0.01
+        status = "ok" if comparable else "ok (resident vs sync only)"
         if comparable:
-            t.run_parity(sc, backward=True)
+            o2, _ = t.run_parity(sc, backward=True)      # rule (3) of assert_grad_close: float64 arbiter for the per-Gaussian stage
+            arb = {k: v for k, v in o2.grad_verdicts.items() if v != "pure"}
+            if arb:
+                status = "ok (" + "; ".join(f"{k}: {v}" for k, v in arb.items()) + ")"
         if P > 0:
             resident_matches_sync(sc)
-        status = "ok" if comparable else "ok (resident vs sync only)"
     except AssertionError as e:
         verdict = None
-        if "dL_d" in str(e):   # a gradient tensor off the bar: who is closer to the float64 truth?
+        if "dL_d" in str(e):   # a tensor outside the stage (or a small scene): the independent float64 autograd formulation
             verdict = float64_arbiter(sc)
         if verdict == "ok":
-            status = "ok (float64 arbiter; against the float32 oracle: " + str(e)[:80] + ")"
+            status = "ok (float64 autograd arbiter; against the float32 oracle: " + str(e)[:80] + ")"
         else:
             status = "FAIL " + str(e)[:200] + (" | arbiter: " + verdict if verdict else "")
             fails += 1
-    print(f"case {i:3d} seed {seed0 + i} P={P:6d} {W}x{H} f={f:7.1f} bg={bg} scale_mul={float(sc.scales.mean()):.4f}: {status}", flush=True)
+    print(f"case {i:3d} seed {seed0 + i} P={P:6d} {W}x{H} scale_mul={float(sc.scales.mean()):.4f}: {status}", flush=True)
 print("failures:", fails)
 sys.exit(1 if fails else 0)
