@@ -51,8 +51,8 @@ def algorithmic_bytes(P, P_vis, R, W, H, passes_depth, passes_tile):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)      # 20 warm-up + 100 timed iterations, median and p10 / p90
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="1080p_3m", help="scene config name (segs_slam_amd.scenes.CONFIGS)")
     ap.add_argument("--mode", default="raster", choices=["raster", "trainer", "scaffold"],
                     help="raster: fwd+bwd raster (+all-reduce); trainer: + fused L1/SSIM loss and fused Adam over the "
