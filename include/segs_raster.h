@@ -58,9 +58,6 @@ const char* segs_last_error(void);
 /* SEGS_RASTER_UNFUSED_BINNING (A/B measurements and tests): fill the range table and the status words with their own kernel
  * (identify_tile_ranges) after the tile-id sort instead of inside its last scatter pass.  Same results. */
 #define SEGS_RASTER_UNFUSED_BINNING 16u
-/* SEGS_RASTER_SUBBLOCK_FORWARD (resident forward; A/B measurements): the tile forward with per-4x4-sub-block lists
- * (render_fwd_sub_kernel).  Same image, final_T and n_contrib bit for bit. */
-#define SEGS_RASTER_SUBBLOCK_FORWARD 64u
 uint32_t segs_raster_set_flags(uint32_t flags);
 
 /* Resident mode only, per host thread; returns the previous pointer.  When set, segs_rasterize_forward_resident also

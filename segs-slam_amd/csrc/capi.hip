@@ -685,10 +685,6 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
   if (rc) return rc;
   // status[3] (overflow) and the host mirror are written by identify_tile_ranges_kernel at the end of run_binning
   { PROF(K_RENDER_FWD);
-  if (g_flags & SEGS_RASTER_SUBBLOCK_FORWARD)
-    render_fwd_sub_kernel<<<gx * gy, 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(), background,
-                                                    (float*)(img + IL.final_T), (uint32_t*)(img + IL.n_contrib), out_color);
-  else
   render_fwd_kernel<<<gx * gy, 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(), background,
                                                   (float*)(img + IL.final_T), (uint32_t*)(img + IL.n_contrib), out_color);
   }

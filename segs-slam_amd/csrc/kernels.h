@@ -89,9 +89,6 @@ __global__ void identify_tile_ranges_kernel(int L, const uint32_t* __restrict__ 
 __global__ void render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
                                   const float* __restrict__ rec, const float* __restrict__ bg,
                                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color);
-__global__ void render_fwd_sub_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
-                                      const float* __restrict__ rec, const float* __restrict__ bg,
-                                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color);
 __global__ void render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
                                   const float* __restrict__ rec, const float* __restrict__ bg,
                                   const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,

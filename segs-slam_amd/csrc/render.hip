@@ -217,193 +217,6 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(
   }
 }
 
-// ---- forward with 4x4 sub-block lists (A/B variant of render_fwd_kernel, SEGS_RASTER_SUBBLOCK_FORWARD) -------------------------
-// At 3 M Gaussians 56 % of render_fwd_kernel's pixel evaluations land on pixels the Gaussian cannot reach: an 8x8 quadrant is
-// far larger than a splat of one or two pixels sigma.  Here a wave still owns an 8x8 quadrant, but each of its four 16-lane rows
-// is a 4x4 SUB-BLOCK that walks its own list: the compacted entries of the quadrant are collected into batches of up to 64
-// (across list chunks), every lane tests ITS entry against the four sub-blocks (exact minimum of the conic form over the 4x4
-// pixel rectangle, the emitter's test at a finer grain), four ballots + mbcnt turn the four bit columns into four index lists
-// in LDS, and iteration i evaluates, in row r, the i-th entry of row r's list.  A pixel sees exactly the entries whose bit
-// for its sub-block is set, in list order; the others are entries the reference `continue`s on for every pixel of the
-// sub-block, so image, final_T and n_contrib are unchanged bit for bit.  The wave runs max_r len(list_r) iterations per batch
-// instead of the batch's length.
-constexpr int FS_BATCH = 64;
-struct FwdSubLds {
-  float4 rec[FS_BATCH + 1][FWD_REC / 4];   // [FS_BATCH] = the null record (opacity 0) short rows fall through to
-  uint32_t list[4][FS_BATCH];              // per sub-block: indices into rec, padded with FS_BATCH
-};
-
-// bit s set: sub-block s (x half = s & 1, y half = s >> 1) of the 8x8 quadrant at pixel (fx, fy) holds a pixel with
-// q(d) = A dx^2 + 2 B dx dy + C dy^2 <= k, d = centre - pixel.  Same construction as binning.hip's quadrant_mask: the form is
-// convex, so over a rectangle that does not hold the centre its minimum lies on an edge facing the centre.
-__device__ __forceinline__ uint32_t subblock_mask(float cx, float cy, float A, float B, float C, float k, float fx, float fy) {
-  const float nb_c = -B * fast_rcp(C), nb_a = -B * fast_rcp(A);
-  const float x_lo[2] = {fx - cx, fx + 4.f - cx}, x_hi[2] = {fx + 3.f - cx, fx + 7.f - cx};
-  const float y_lo[2] = {fy - cy, fy + 4.f - cy}, y_hi[2] = {fy + 3.f - cy, fy + 7.f - cy};
-  const float B2 = 2.f * B;
-  float xn[2], yn[2], axx[2], bx2[2], tv[2], cyy[2], by2[2], th[2];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    xn[i] = fminf(x_hi[i], fmaxf(x_lo[i], 0.f));
-    yn[i] = fminf(y_hi[i], fmaxf(y_lo[i], 0.f));
-    axx[i] = A * xn[i] * xn[i]; bx2[i] = B2 * xn[i]; tv[i] = nb_c * xn[i];
-    cyy[i] = C * yn[i] * yn[i]; by2[i] = B2 * yn[i]; th[i] = nb_a * yn[i];
-  }
-  uint32_t mask = 0u;
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const int sx = s & 1, sy = s >> 1;
-    const float yy = fminf(y_hi[sy], fmaxf(y_lo[sy], tv[sx]));
-    const float v = axx[sx] + yy * (bx2[sx] + C * yy);
-    const float xx = fminf(x_hi[sx], fmaxf(x_lo[sx], th[sy]));
-    const float h = cyy[sy] + xx * (by2[sy] + A * xx);
-    if (fminf(v, h) <= k) mask |= 1u << s;
-  }
-  return mask;
-}
-
-__global__ void __launch_bounds__(256) render_fwd_sub_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
-    const float* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color) {
-  __shared__ FwdSubLds lds_all[4];
-  const uint32_t tiles_x = (W + TILE_X - 1) / TILE_X;
-  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
-  const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  FwdSubLds& L = lds_all[wv];
-  // lane = (sub-block row r, pixel i of the 4x4 block)
-  const int r = lane >> 4, pi = lane & 15;
-  const uint32_t qx0 = tile_x * TILE_X + (wv & 1) * 8, qy0 = tile_y * TILE_Y + (wv >> 1) * 8;
-  const uint32_t px = qx0 + (r & 1) * 4 + (pi & 3), py = qy0 + (r >> 1) * 4 + (pi >> 2);
-  const bool inside = px < (uint32_t)W && py < (uint32_t)H;
-  const float pxf = (float)px, pyf = (float)py;
-  const uint32_t qbit = 1u << (ID_BITS + wv);
-  const float qx0f = (float)qx0, qy0f = (float)qy0;
-
-  const uint2 range = ranges[tile];
-  float T = inside ? 1.0f : 0.f, thr = inside ? 0.0001f : -1.f;
-  float Tfin = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-  uint32_t last = 0u, lastfin = 0u;
-  if (lane == 0) { L.rec[FS_BATCH][0] = make_float4(0.f, 0.f, 0.f, 0.f); L.rec[FS_BATCH][1] = L.rec[FS_BATCH][0]; L.rec[FS_BATCH][2] = L.rec[FS_BATCH][0]; }
-
-  uint32_t v_nxt, v_nn = 0u;
-  Compacted cc;
-  float4 r0, r1; float rb;
-  {
-    const uint32_t i0 = range.x + lane, i1 = range.x + 64 + lane;
-    const uint32_t v0 = i0 < range.y ? point_list[i0] : 0u;
-    v_nxt = i1 < range.y ? point_list[i1] : 0u;
-    cc = compact_chunk<false>(v0, qbit, lane);
-    r0 = make_float4(0.f, 0.f, 0.f, 0.f); r1 = r0; rb = 0.f;
-    if (lane < cc.n) {
-      const float4* p = reinterpret_cast<const float4*>(rec + (size_t)(cc.val & ID_MASK) * REC_DWORDS);
-      r0 = p[0]; r1 = p[1]; rb = reinterpret_cast<const float*>(p)[8];
-    }
-  }
-  bool alive = true;  // wave-uniform: some pixel of this 8x8 block still accumulates
-  int fill = 0;       // records staged in L.rec, wave-uniform
-  const uint32_t* my_list = L.list[r];
-  for (uint32_t base = range.x; alive; base += 64) {
-    const bool tail = base >= range.y;    // one more pass after the last chunk flushes the final partial batch
-    const int n = tail ? 0 : __builtin_amdgcn_readfirstlane(cc.n);
-    const float4 c0 = r0, c1 = r1;
-    const float4 c2 = make_float4(rb, __uint_as_float(base - range.x + cc.pos + 1u), 0.f, 0.f);
-    if (!tail) {   // put the next chunk's records and the one after's list entries in flight
-      const uint32_t i2 = base + 128 + lane;
-      v_nn = i2 < range.y ? point_list[i2] : 0u;
-      cc = compact_chunk<false>(v_nxt, qbit, lane);
-      if (lane < cc.n) {
-        const float4* p = reinterpret_cast<const float4*>(rec + (size_t)(cc.val & ID_MASK) * REC_DWORDS);
-        r0 = p[0]; r1 = p[1]; rb = reinterpret_cast<const float*>(p)[8];
-      }
-      v_nxt = v_nn;
-    }
-    int taken = 0;
-    do {
-      const int take = min(FS_BATCH - fill, n - taken);
-      if (lane >= taken && lane < taken + take) {
-        const int s = fill + lane - taken;
-        L.rec[s][0] = c0; L.rec[s][1] = c1; L.rec[s][2] = c2;
-      }
-      fill += take; taken += take;
-      if (fill < FS_BATCH && !(tail && fill > 0)) continue;   // batch not full yet: the next chunk tops it up
-      const int nb = fill;
-      fill = 0;
-      wave_lds_fence();
-      // ---- per-entry sub-block masks (lane e <-> entry e of the batch) and the four per-row index lists
-      uint32_t sub = 0u;
-      if (lane < nb) {
-        const float4 q0 = L.rec[lane][0];
-        const float2 q1 = *reinterpret_cast<const float2*>(&L.rec[lane][1]);
-        const float o = q1.y;
-        if (o * 255.0f > 1.0f) {
-          // alpha >= 1/255  <=>  -(A2 dx^2 + B2 dx dy + C2 dy^2) <= log2(255 o); inflated so that rounding stays on the safe side
-          const float k = __builtin_amdgcn_logf(255.0f * o) * 1.0001f + 1e-3f;
-          sub = subblock_mask(q0.x, q0.y, -q0.z, -0.5f * q0.w, -q1.x, k, qx0f, qy0f);
-        }
-      }
-      *reinterpret_cast<uint4*>(&L.list[lane >> 4][(lane & 15) * 4]) = make_uint4(FS_BATCH, FS_BATCH, FS_BATCH, FS_BATCH);
-      wave_lds_fence();
-      int niter = 0;
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const bool on = (sub >> s) & 1u;
-        const uint64_t m = __ballot(on);
-        if (on) L.list[s][__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)lane;
-        niter = max(niter, __popcll(m));
-      }
-      wave_lds_fence();
-      // ---- row r evaluates the entries of its own list, four per round
-      const int n4 = (niter + 3) & ~3;
-      for (int k0 = 0; k0 < n4 && alive; k0 += 4) {
-        const uint4 idx4 = *reinterpret_cast<const uint4*>(my_list + k0);
-        const uint32_t idx[4] = {idx4.x, idx4.y, idx4.z, idx4.w};
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const float4* rp = L.rec[idx[u]];
-          const float4 q0 = rp[0], q1 = rp[1];
-          const float2 q2 = *reinterpret_cast<const float2*>(&rp[2]);
-          const float dx = q0.x - pxf, dy = q0.y - pyf;
-          const float power2 = dx * (q0.z * dx + q0.w * dy) + (q1.x * dy) * dy;  // log2e * power
-          const float alpha = fminf(0.99f, q1.y * fast_exp2(power2));
-          const bool ok = power2 <= 0.0f && alpha >= 1.0f / 255.0f;
-          const float ae = ok ? alpha : 0.f;
-          float w = ae * T;
-          float test_T = T - w;
-          const bool stop = test_T < thr;  // forward.cu:420-425; never true for dead pixels (thr = -1)
-          if (__ballot(stop) != 0ull) {    // rare: some pixel saturates at this Gaussian
-            Tfin = stop ? T : Tfin;
-            lastfin = stop ? last : lastfin;
-            thr = stop ? -1.f : thr;
-            w = stop ? 0.f : w;
-            test_T = stop ? 0.f : test_T;
-            alive = __ballot(thr > 0.f) != 0ull;
-          }
-          T = test_T;
-          C0 += q1.z * w; C1 += q1.w * w; C2 += q2.x * w;
-          last = ok ? __float_as_uint(q2.y) : last;
-          if (!alive) break;
-        }
-      }
-      wave_lds_fence();
-    } while (taken < n && alive);
-    if (tail) break;
-  }
-  if (inside) {
-    const bool dead = thr < 0.f;
-    const size_t pix_id = (size_t)W * py + px;
-    const size_t HW = (size_t)H * W;
-    const float Tout = dead ? Tfin : T;
-    final_T[pix_id] = Tout;
-    n_contrib[pix_id] = dead ? lastfin : last;
-    out_color[pix_id] = C0 + Tout * bg[0];
-    out_color[HW + pix_id] = C1 + Tout * bg[1];
-    out_color[2 * HW + pix_id] = C2 + Tout * bg[2];
-  }
-}
-
 // ---- cross-lane helpers -----------------------------------------------------------------------
 // lanes 0-31 <- a[l] + a[l+32], lanes 32-63 <- b[l-32] + b[l]
 __device__ __forceinline__ float fold32(float a, float b) {

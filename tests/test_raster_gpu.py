@@ -668,34 +668,3 @@ def _capi_state(eng, cam):
                 "segs_debug_instance_values")
     torch.cuda.synchronize()
     return dict(ranges=ranges.cpu().numpy(), n_contrib=ncontrib.cpu().numpy(), values=vals.cpu().numpy()[:eng.R_live])
-
-
-@pytest.mark.parametrize("shape", ["dense_small_splats", "large_splats", "ragged_image"])
-def test_subblock_forward_variant_is_bit_identical(shape):
-    """render_fwd_sub_kernel (SEGS_RASTER_SUBBLOCK_FORWARD: every 16-lane row of a wave is a 4x4 sub-block walking its own list)
-    against render_fwd_kernel through the resident engine: image, final_T and n_contrib bit for bit -- a pixel must see exactly
-    the entries that can reach its sub-block, in list order."""
-    from segs_slam_amd.raster_engine import RasterEngine
-    if shape == "dense_small_splats":
-        sc = scenes.make_scene(400_000, 640, 368, 320.0, 320.0, seed=31, bg=(0.1, 0.0, 0.2))
-        sc.scales *= 0.5
-    elif shape == "large_splats":
-        sc = scenes.make_scene(30_000, 320, 240, 260.0, 260.0, seed=32, bg=(0.0, 0.0, 0.0))
-        sc.scales *= 4.0
-    else:
-        sc = scenes.make_scene(60_000, 333, 171, 200.0, 200.0, seed=33, bg=(1.0, 1.0, 1.0))
-    cam = sc.camera
-    a = [_t(x) for x in (sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, sc.rotations, cam.world_view_transform,
-                         cam.full_proj_transform, cam.camera_center)]
-    outs = []
-    for extra in (0, 64):
-        eng = RasterEngine(sc.P, cam.width, cam.height, DEV, resident=True)
-        eng.flags |= extra
-        for _ in range(3):
-            img = eng.forward(*a, cam.tanfovx, cam.tanfovy)
-        assert eng.check() and eng._last_resident
-        st = _capi_state(eng, cam)
-        outs.append((img.cpu().numpy().copy(), st["n_contrib"], st["ranges"]))
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
-    assert outs[0][1].max() > 0
