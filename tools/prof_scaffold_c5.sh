@@ -7,6 +7,7 @@ TAG=${1:-rXX}
 rm -rf gpurun_out/${TAG}_scaf_c5
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_scaf_c5 -o run -- python3 bench.py --mode scaffold --workload c2 --anchors 300000 --appearance-dim 16 --no-feat-bank --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_scaffold_c5_line_under_rocprof.json 2> gpurun_out/${TAG}_scaf_c5.log
 cp gpurun_out/${TAG}_scaf_c5/run_kernel_stats.csv gpurun_out/${TAG}_scaffold_c5_kernel_stats.csv
+rm -rf gpurun_out/${TAG}_scaf_c5
 python3 bench.py --mode scaffold --workload c2 --anchors 300000 --appearance-dim 16 --no-feat-bank --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_scaffold_c5_line.json 2>/dev/null
 python3 - <<PY
 import csv, json
