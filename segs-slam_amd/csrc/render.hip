@@ -257,8 +257,9 @@ constexpr int BW_SLOTS = 16;
 constexpr int BW_STRIDE = 65;  // padded row of the transposed tiles: conflict-free in both roles
 struct BwdLds {                  // 9088 B per wave -> 16 single-wave workgroups per CU
   float4 rec[BW_SLOTS][3];      // staged records of the current batch: [0] x y a2 b2  [1] c2 o r g  [2] b pos id -
-  float wt[BW_SLOTS][BW_STRIDE];
-  float at[BW_SLOTS][BW_STRIDE];  // its first 16x12 floats are reused as the moment exchange area `mom`
+  float2 wa[BW_SLOTS][BW_STRIDE];   // (w, alpha T) per (slot, pixel): ONE 8-byte LDS write per pair in the pixel role, one 8-byte read
+                                    // per pair in the Gaussian role (two 4-byte tiles before: 7 -> 5 LDS instructions per pair);
+                                    // its first 16x12 floats are reused as the moment exchange area `mom`
 };
 
 
@@ -299,8 +300,7 @@ __device__ __forceinline__ void pixel_role(BwdLds& L, int nb, int lane, float px
     float dL_dalpha = diff * T;
     if (USE_BG) dL_dalpha += (-T_final * rinv) * bg_dot_dpixel;
     accd += ae * diff;
-    L.wt[sl][lane] = aw * dL_dalpha;     // = dL_dG * G
-    L.at[sl][lane] = ae * T;             // = dchannel_dcolor
+    L.wa[sl][lane] = make_float2(aw * dL_dalpha /* = dL_dG * G */, ae * T /* = dchannel_dcolor */);
   }
 }
 
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
   // leaves over (fewer than BW_SLOTS records) stays staged in L.rec and the next chunk tops it up, so both roles always
   // run on full batches (at 3 M Gaussians a chunk holds ~18 entries of this quadrant: per-chunk batches were 58 % full).
   // One more pass of the loop after the last chunk (tail) flushes the final partial batch.
-  float (*mom)[12] = reinterpret_cast<float (*)[12]>(&L.at[0][0]);
+  float (*mom)[12] = reinterpret_cast<float (*)[12]>(&L.wa[0][0]);
   int fill = 0;   // records staged in L.rec, wave-uniform
   for (int32_t cbase = cfirst;; cbase -= 64) {
     const bool tail = cbase < 0;
@@ -424,11 +424,11 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
       float S0, S1x, S1y, Sxx, Sxy, Syy, Sr = 0.f, Sg = 0.f, Sb = 0.f;
       {
         float R0[2] = {0.f, 0.f}, R1[2] = {0.f, 0.f}, R2[2] = {0.f, 0.f};
-        const float* wrow = &L.wt[gs][part * 16];
-        const float* arow = &L.at[gs][part * 16];
+        const float2* warow = &L.wa[gs][part * 16];
 #define GAUSS_STEP(i)                                                                         \
         {                                                                                     \
-          const float w = wrow[i], a = arow[i];                                               \
+          const float2 wa_i = warow[i];                                                       \
+          const float w = wa_i.x, a = wa_i.y;                                                 \
           R0[(i) >> 3] += w; R1[(i) >> 3] += w * px8[(i) & 7]; R2[(i) >> 3] += w * px8q[(i) & 7]; \
           fmac_row_bcast<(i)>(Sr, dp0, a); fmac_row_bcast<(i)>(Sg, dp1, a); fmac_row_bcast<(i)>(Sb, dp2, a); \
         }
