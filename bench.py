@@ -61,6 +61,10 @@ def parse_args():
     ap.add_argument("--anchors", type=int, default=50000)
     ap.add_argument("--appearance-dim", type=int, default=32, help="scaffold mode: Model.appearance_dim (ScanNet configurations: 16)")
     ap.add_argument("--no-feat-bank", action="store_true", help="scaffold mode: Model.use_feat_bank = 0 (ScanNet configurations)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "sharded", "dense"],
+                    help="N > 1: gradient exchange. sharded = reduce-scatter -> Adam on the rank's shard -> all-gather; dense = one "
+                         "all-reduce (the overflow word rides in it) and a full Adam on every rank; auto = by bucket size "
+                         "(keyframe_parallel.BucketExchange.AUTO_SHARD_BYTES)")
     ap.add_argument("--dense-allreduce", action="store_true",
                     help="trainer / scaffold mode with N > 1: one all-reduce and a full Adam on every rank instead of "
                          "reduce-scatter -> sharded Adam -> all-gather")
@@ -115,6 +119,7 @@ def spawn_ranks(n: int) -> int:
 
 def main():
     args = parse_args()
+    sharded_opt = False if (args.dense_allreduce or args.exchange == "dense") else (True if args.exchange == "sharded" else "auto")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
 
@@ -164,7 +169,7 @@ def main():
         dims = ng.ModelDims(appearance_dim=args.appearance_dim, use_feat_bank=not args.no_feat_bank)
         model = ng.synthetic_model(args.anchors, dims, cam, dev, seed=0)   # replicas must be identical; the keyframe differs per rank
         tstep = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
-        tstep.sharded_optimizer = not args.dense_allreduce
+        tstep.sharded_optimizer = sharded_opt
         tstep.single_rank_collectives = args.force_dist
         eng = tstep.engine
         kfs = [ng.Keyframe(view, proj, campos, torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)]
@@ -172,7 +177,7 @@ def main():
         tstep.keyframe_for = lambda step, n: 0
     elif args.mode == "trainer":
         from segs_slam_amd.gaussian_trainer import TrainerStep, keyframe_tensors
-        tstep = TrainerStep.on_gpu(sc, dev, sharded_optimizer=not args.dense_allreduce, single_rank_collectives=args.force_dist)
+        tstep = TrainerStep.on_gpu(sc, dev, sharded_optimizer=sharded_opt, single_rank_collectives=args.force_dist)
         eng = tstep.engine
         kfs = [keyframe_tensors(cam, dev)]
         gts = [torch.rand(3, cam.height, cam.width, device=dev)]
@@ -185,8 +190,9 @@ def main():
         # steps use: reduce-scatter of the gradients + all-gather of a parameter-sized bucket (what follows the sharded Adam),
         # or one dense all-reduce -- the same bytes per link either way
         from segs_slam_amd.keyframe_parallel import BucketExchange
-        raster_ex = BucketExchange(eng.grads_flat.numel(), dev, None, sharded=not args.dense_allreduce,
-                                   single_rank_collectives=args.force_dist)
+        # (no optimizer in this mode, so nothing for a sharded exchange to save: "auto" means the dense one here)
+        raster_ex = BucketExchange(eng.grads_flat.numel(), dev, None, sharded=False if sharded_opt == "auto" else sharded_opt,
+                                   single_rank_collectives=args.force_dist, grads=eng.grads_flat)
         raster_params = torch.zeros_like(eng.grads_flat) if raster_ex.sharded else None
 
     def step():
@@ -196,6 +202,9 @@ def main():
         eng.forward(bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy)
         eng.backward(dL)
         if raster_ex is not None:     # sum of per-keyframe parameter gradients over xGMI (RCCL)
+            status = getattr(eng, "_status", None)
+            raster_ex.reduce_flag_async(status[3:4] if (status is not None and eng._last_resident) else None)
+            raster_ex.wait_flag()
             raster_ex.reduce_gradients(eng.grads_flat)
             if raster_params is not None:
                 raster_ex.gather(raster_params)
@@ -290,14 +299,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {eng.P_active} Gaussians, {cam.width}x{cam.height}, 1 keyframe per GPU, "
-                                   "fwd+bwd raster" + ((", RCCL all-reduce of parameter grads" if args.dense_allreduce else
+                                   "fwd+bwd raster" + ((", RCCL all-reduce of parameter grads" if not raster_ex.sharded else
                                                         ", RCCL reduce-scatter of parameter grads + all-gather of the parameter bucket")
                                                        if world > 1 and tstep is None else "")
                                    + (" + L1/SSIM loss + fused Adam" if args.mode == "trainer" else "")
                                    + (f"; anchor-level mapper step: {args.anchors} anchors x 10 offsets -> neural Gaussians "
                                       f"(appearance_dim {args.appearance_dim}, feature bank {'off' if args.no_feat_bank else 'on'}; MLPs fwd+bwd), "
                                       "L1/SSIM, fused Adam" if args.mode == "scaffold" else "")
-                                   + ((", dense all-reduce" if args.dense_allreduce else ", reduce-scatter -> sharded Adam -> all-gather")
+                                   + ((", dense all-reduce" if not tstep._exchange_sharded() else ", reduce-scatter -> sharded Adam -> all-gather")
                                       if (world > 1 and tstep is not None) else ""),
                        "P": eng.P_active, "P_visible": P_vis, "num_rendered": R_ref, "instances_binned": eng.R, "instances_live": R_live,
                        "width": cam.width, "height": cam.height,

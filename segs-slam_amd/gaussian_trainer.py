@@ -153,7 +153,7 @@ class TorchAdam:
     def step(self, params_flat, grads_flat, lrs, P, grad_scale, exchange=None, guard=None):
         """`exchange`: update only this rank's shard (moments outside it are not kept current, as in FusedAdam)."""
         o = self.opt
-        if guard is not None and int(guard.reshape(-1)[0]) != 0:
+        if guard is not None and float(guard.reshape(-1)[0]) != 0:
             grads_flat.zero_()
             return
         self.step_count += 1
@@ -187,7 +187,7 @@ class TrainerStep:
         self.render_backward, self.optimizer, self.opt = render_backward, optimizer, opt
         self.pg = process_group
         self.exchange = BucketExchange(params_flat.numel(), params_flat.device, process_group, sharded=sharded_optimizer,
-                                       single_rank_collectives=single_rank_collectives)
+                                       single_rank_collectives=single_rank_collectives, grads=grads_flat)
         self.world, self.rank = self.exchange.world, self.exchange.rank
         self.iteration = 0
         # a backend that knows an overflow word (the HIP engine) takes a hook it calls right after its forward
@@ -209,6 +209,9 @@ class TrainerStep:
         loss = (1.0 - self.opt.lambda_dssim) * Ll1 + self.opt.lambda_dssim * (1.0 - loss_utils.ssim(img, gt))
         (dL,) = torch.autograd.grad(loss, img)
         return loss.detach(), dL.contiguous()
+
+    def _exchange_sharded(self) -> bool:
+        return self.exchange.sharded
 
     def keyframe_for(self, step: int, n_keyframes: int) -> int:
         """Deterministic shared schedule: rank r takes keyframe (step * world + r) mod n."""

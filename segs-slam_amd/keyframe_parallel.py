@@ -37,12 +37,19 @@ class BucketExchange:
     """Gradient / parameter exchange over one flat fp32 bucket of `n` elements (see module docstring)."""
 
     ALIGN = 4      # shard boundaries fall on 16-byte boundaries (float4 accesses of the fused Adam)
+    # sharded="auto": the sharded exchange pays two more collective launches and a pass over the gradient bucket per step
+    # (measured with one rank: +0.075 ... 0.105 ms against +0.03 ... 0.05 ms for the dense one, profiles/
+    # r03_single_rank_exchange_cost.txt) and saves (N-1)/N of the optimizer's 28 B per parameter: worth it from about here
+    AUTO_SHARD_BYTES = 32 << 20
 
-    def __init__(self, n: int, device, process_group=None, sharded: bool = True, single_rank_collectives: bool = False):
+    def __init__(self, n: int, device, process_group=None, sharded=True, single_rank_collectives: bool = False,
+                 grads: Optional[torch.Tensor] = None):
         self.pg = process_group
         self.world, self.rank = _group_info(process_group)
         self.n = int(n)
         self.device = torch.device(device)
+        if sharded == "auto":
+            sharded = self.n * 4 >= self.AUTO_SHARD_BYTES
         # single_rank_collectives: issue every collective even with ONE rank in an initialised group (bench.py --force-dist,
         # tests/test_rccl_single_rank_gpu.py): the reduce_scatter_tensor / all_gather_into_tensor calls of the N > 1 path then
         # run under the real RCCL backend on a one-GPU box, where they must leave the dense path's parameters
@@ -55,6 +62,14 @@ class BucketExchange:
         # gloo (only used to rehearse the N > 1 path, on the CPU or with every rank on one GPU) has no tensor-shaped
         # reduce-scatter / all-gather for device tensors: same result from an all-reduce + slice and a list all-gather
         self._emulate = (self.active and self.device.type == "cuda" and dist.get_backend(process_group) != "nccl")
+        # DENSE exchange with a gradient bucket that has one spare element behind it (raster_engine / ScaffoldModel allocate
+        # four): the overflow word rides there through the gradient all-reduce itself -- no collective of its own, no second
+        # stream -- which is most of the dense exchange's fixed cost on a 0.3 ms step.  `_ext` = the bucket + that element.
+        self._ext, self._piggy = None, False
+        if grads is not None and self.active and not self.sharded and grads.dtype == torch.float32:
+            st, off = grads.untyped_storage(), grads.storage_offset()
+            if grads.numel() == self.n and grads.is_contiguous() and st.nbytes() >= (off + self.n + 1) * 4:
+                self._ext = torch.empty(0, dtype=torch.float32, device=grads.device).set_(st, off, (self.n + 1,))
         if self.sharded:
             f = dict(dtype=torch.float32, device=self.device)
             # staging in equal-sized shards: the collectives need world * shard_len elements, the bucket has n
@@ -82,11 +97,22 @@ class BucketExchange:
         return out
 
     # ---- flag
-    def reduce_flag_async(self, local_flag: Optional[torch.Tensor]):
+    def reduce_flag_async(self, local_flag: Optional[torch.Tensor], allow_piggyback: bool = True):
         """Start the all-reduce of this step's overflow word (a 1-element int32 device tensor, or None for 0).  With one rank
-        the word itself is the guard: no copy, no launch."""
+        the word itself is the guard: no copy, no launch.  Dense exchange over a bucket with a spare tail element: the word is
+        only PLACED there (as a float) and summed by reduce_gradients(); `allow_piggyback=False` for the steps that must read
+        the summed word on the host before the gradients are exchanged (adjust_anchor iterations)."""
+        self._piggy = False
         if not self.active:
             self._local = local_flag
+            return
+        if self._ext is not None and allow_piggyback:
+            tail = self._ext[self.n:]
+            if local_flag is None:
+                tail.zero_()
+            else:
+                tail.copy_(local_flag.reshape(1))       # int32 0 / 1 -> float 0.0 / 1.0
+            self._piggy = True
             return
         if local_flag is None:
             self.flag.zero_()
@@ -96,6 +122,8 @@ class BucketExchange:
 
     def wait_flag(self) -> torch.Tensor:
         """Make the current stream wait for the flag; returns the device word (non-zero: some rank's pass is invalid)."""
+        if self._piggy:
+            return self._ext[self.n:]          # holds the sum once reduce_gradients() has run: any non-zero bit pattern = drop
         if not self.active:
             if getattr(self, "_local", None) is not None:
                 return self._local
@@ -116,6 +144,10 @@ class BucketExchange:
         optimizer (a densification that re-sizes the bucket): every element must then hold the sum, whoever updates it."""
         assert grads.numel() == self.n
         if not self.active:
+            return
+        if self._piggy:
+            assert grads.data_ptr() == self._ext.data_ptr(), "the exchange was built for another gradient bucket"
+            dist.all_reduce(self._ext, group=self.pg)      # gradients + the overflow word behind them
             return
         if dense or not self.sharded:
             dist.all_reduce(grads, group=self.pg)

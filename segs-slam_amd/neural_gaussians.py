@@ -135,7 +135,7 @@ class ScaffoldModel:
         self.n_params = pos + self.mlp_total
         f = dict(dtype=torch.float32, device=self.device)
         self.params = torch.zeros(self.n_params, **f)
-        self.grads = torch.zeros(self.n_params, **f)
+        self.grads = torch.zeros(self.n_params + 4, **f)[:self.n_params]   # (+4: keyframe_parallel.BucketExchange's spare tail)
         self.exp_avg = torch.zeros(self.n_params, **f)       # Adam moments, same layout (torch::optim::Adam state)
         self.exp_avg_sq = torch.zeros(self.n_params, **f)
         self.mlp_layout = {n: (pos + o, c) for n, (o, c) in self._mlp_rel.items()}
@@ -344,8 +344,8 @@ class ScaffoldTrainerStep:
         # share the MLPs' count until the first densification.
         self._mlp_count = DeviceStepCount(dev)
         self._anchor_count = None
-        # N > 1: reduce-scatter -> Adam on this rank's shard -> all-gather (keyframe_parallel.BucketExchange); False = dense
-        # all-reduce and a full Adam on every rank
+        # N > 1: True = reduce-scatter -> Adam on this rank's shard -> all-gather (keyframe_parallel.BucketExchange); False = dense
+        # all-reduce and a full Adam on every rank; "auto" = by bucket size (BucketExchange.AUTO_SHARD_BYTES)
         self.sharded_optimizer = True
         self.single_rank_collectives = False   # keyframe_parallel.BucketExchange: run the collectives with one rank too
         self.densifier = None            # densify.AnchorDensifier, see enable_densification()
@@ -469,19 +469,22 @@ class ScaffoldTrainerStep:
         return self.engine.forward(self.bg, ng.means3D, ng.colors, ng.opacity, ng.scales, ng.rotations, kf.view, kf.proj,
                                    kf.campos, kf.tanfovx, kf.tanfovy)
 
-    def _forward_backward(self, kf: Keyframe, gt: torch.Tensor, exchange=None):
+    def _forward_backward(self, kf: Keyframe, gt: torch.Tensor, exchange=None, flag_on_host: bool = False):
+        """`flag_on_host`: the caller reads the summed overflow word on the host before the gradient exchange (adjust_anchor
+        iterations), so it needs its own collective instead of riding with the gradients."""
         self.use_level(gt.shape[-1], gt.shape[-2])
         if self.model.A == 0:
             # every anchor was pruned: the reference's rasterizer short-circuits P == 0 to a zero image
             # (src/rasterize_points.cu:81) and nothing receives a gradient
             if exchange is not None:
-                exchange.reduce_flag_async(None)
+                exchange.reduce_flag_async(None, allow_piggyback=not flag_on_host)
             return self.loss_fn(torch.zeros(3, self.H, self.W, device=self.model.device), gt)[0]
         image = self.render(kf)
         if exchange is not None:
             # the overflow word is final once the forward's binning has run: its all-reduce hides behind loss and backward
             status = getattr(self.engine, "_status", None)
-            exchange.reduce_flag_async(status[3:4] if (status is not None and self.engine._last_resident) else None)
+            exchange.reduce_flag_async(status[3:4] if (status is not None and self.engine._last_resident) else None,
+                                       allow_piggyback=not flag_on_host)
         mask = None
         if self.row_mask:
             mask, gt = self._row_mask_of(gt)
@@ -532,7 +535,7 @@ class ScaffoldTrainerStep:
         d = self.densifier
         in_stat_window = d is not None and self.model.A > 0 and d.p.start_stat < self.iteration < d.p.update_until  # gaussian_mapper.cpp:961-968
         adjust_now = in_stat_window and self.iteration > d.p.update_from and self.iteration % d.p.update_interval == 0
-        loss = self._forward_backward(keyframes[k], gt_images[k], ex)
+        loss = self._forward_backward(keyframes[k], gt_images[k], ex, flag_on_host=adjust_now)
         flag = ex.wait_flag()
         if adjust_now:
             # adjust_anchor reads tensor sizes on the host and must see a valid pass on every rank: resolve the summed
@@ -542,7 +545,7 @@ class ScaffoldTrainerStep:
                     break
                 self.engine.check(raise_on_overflow=False)     # the rank that overflowed re-calibrates in its next forward
                 self.model.grads.zero_()
-                loss = self._forward_backward(keyframes[k], gt_images[k], ex)
+                loss = self._forward_backward(keyframes[k], gt_images[k], ex, flag_on_host=True)
                 flag = ex.wait_flag()
             else:
                 raise RuntimeError("resident rasterizer kept overflowing its re-sized scratch")
@@ -619,6 +622,9 @@ class ScaffoldTrainerStep:
                 tot[n] += ev[i].elapsed_time(ev[i + 1])
         return {n: v / iters for n, v in tot.items()}
 
+    def _exchange_sharded(self) -> bool:
+        return self._exchange().sharded
+
     def dropped_steps(self) -> int:
         """Iterations the device dropped so far (overflowed resident capacity on some rank; synchronises).  Their returned
         loss is invalid and their keyframe use was still counted; the reference never drops an iteration."""
@@ -628,9 +634,9 @@ class ScaffoldTrainerStep:
         """The step's BucketExchange over the model's flat bucket (rebuilt when densification re-sized the bucket)."""
         from .keyframe_parallel import BucketExchange
         ex = getattr(self, "_ex", None)
-        if ex is None or ex.n != self.model.params.numel():
+        if ex is None or ex.n != self.model.params.numel() or (ex._ext is not None and ex._ext.data_ptr() != self.model.grads.data_ptr()):
             ex = self._ex = BucketExchange(self.model.params.numel(), self.model.device, self.pg, sharded=self.sharded_optimizer,
-                                           single_rank_collectives=self.single_rank_collectives)
+                                           single_rank_collectives=self.single_rank_collectives, grads=self.model.grads)
         return ex
 
 

@@ -66,7 +66,8 @@ class RasterEngine:
         f = dict(dtype=torch.float32, device=self.device)
         self.out_color = torch.zeros((3, self.H, self.W), **f)
         self.radii = torch.zeros((self.P,), dtype=torch.int32, device=self.device)
-        self.grads_flat = torch.zeros((FLOATS_PER_GAUSSIAN * self.P,), **f)
+        # (+4 floats behind the bucket: keyframe_parallel.BucketExchange lets the overflow word ride there in a dense exchange)
+        self.grads_flat = torch.zeros((FLOATS_PER_GAUSSIAN * self.P + 4,), **f)[:FLOATS_PER_GAUSSIAN * self.P]
         self.grads = split_flat(self.grads_flat, self.P)
         self.dL_dmean2D = torch.zeros((self.P, 3), **f)
         # dL/dcov3D has no consumer when the Gaussians come as scales + rotations (the training path): written on request only;

@@ -204,3 +204,56 @@ def test_dense_reduce_survives_a_bucket_resize_between_exchange_and_optimizer(tm
     mp.spawn(_resize_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r = [np.load(tmp_path / f"bad_{k}.npy") for k in range(2)]
     assert r[0][0] or r[1][0], "the scenario must exercise elements that change owner"
+
+
+def _piggy_worker(rank, world, port, out_dir):
+    """Dense exchange over a gradient bucket with a spare element behind it: the overflow word rides through the gradient
+    all-reduce (no collective of its own) and every rank sees the SUM of the words afterwards; without the spare element, or
+    with allow_piggyback=False, the word takes its own all-reduce -- same values either way; "auto" picks dense below
+    AUTO_SHARD_BYTES and sharded above."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segs_slam_amd.keyframe_parallel import BucketExchange
+    n = 1003
+    store = torch.zeros(n + 4)
+    grads = store[:n]
+    own = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    for allow in (True, False):
+        for my_flag in (0, 1 if rank == 1 else 0):
+            ex = BucketExchange(n, "cpu", None, sharded=False, grads=grads)
+            assert ex._ext is not None and not ex.sharded
+            grads.copy_(own)
+            calls = []
+            orig = dist.all_reduce
+            dist.all_reduce = lambda t, **k: (calls.append(t.numel()), orig(t, **k))[1]
+            try:
+                ex.reduce_flag_async(torch.tensor([my_flag], dtype=torch.int32), allow_piggyback=allow)
+                flag = ex.wait_flag()
+                ex.reduce_gradients(grads)
+            finally:
+                dist.all_reduce = orig
+            assert torch.equal(grads, torch.arange(n, dtype=torch.float32) * 3.0)
+            want = float(my_flag) if rank == 1 else float(1 if (my_flag == 0 and False) else 0)
+            total = float(flag.reshape(-1)[0])
+            # rank 0 always contributes 0, rank 1 contributes my_flag (both ranks run the same loop index)
+            assert total in (0.0, 1.0)
+            assert calls == ([n + 1] if allow else [1, n]), (allow, calls)
+            np.save(os.path.join(out_dir, f"flag_{rank}_{int(allow)}_{my_flag}.npy"), np.array([total]))
+    # no spare element: falls back to the word's own collective
+    plain = torch.zeros(n)
+    ex = BucketExchange(n, "cpu", None, sharded=False, grads=plain)
+    assert ex._ext is None
+    assert BucketExchange(n, "cpu", None, sharded="auto").sharded is False
+    assert BucketExchange(BucketExchange.AUTO_SHARD_BYTES // 4, "cpu", None, sharded="auto").sharded is True
+    dist.destroy_process_group()
+
+
+def test_overflow_word_rides_in_the_dense_gradient_all_reduce(tmp_path):
+    port = 29500 + (os.getpid() % 2000) + 19
+    mp.spawn(_piggy_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for allow in (0, 1):
+        # second loop value: rank 1 raised its word -> both ranks must have seen the sum 1
+        a, b = (float(np.load(tmp_path / f"flag_{r}_{allow}_{1 if r == 1 else 0}.npy")[0]) for r in range(2))
+        assert (a, b) == (1.0, 1.0), (allow, a, b)

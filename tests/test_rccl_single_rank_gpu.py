@@ -31,18 +31,21 @@ def _worker(rank, world, port, outdir):
         grads = [torch.randn(n, generator=g).to(dev) * 1e-3 for _ in range(3)]
         lrs = {"means3D": 1.6e-4, "scales": 5e-3, "rotations": 1e-3, "opacity": 5e-2, "colors": 2.5e-3}
         res = {}
-        for mode in ("plain", "dense", "sharded"):
+        for mode in ("plain", "dense", "dense_word_in_bucket", "sharded"):
             params = p0.clone()
             opt = OptimizationParams()
             adam = FusedAdam(n, dev, opt)
             ex = None
+            gb = torch.zeros(n + 4, device=dev)[:n]           # a bucket with the spare tail the engines allocate
             if mode != "plain":
-                ex = BucketExchange(n, dev, None, sharded=(mode == "sharded"), single_rank_collectives=True)
+                ex = BucketExchange(n, dev, None, sharded=(mode == "sharded"), single_rank_collectives=True,
+                                    grads=gb if mode == "dense_word_in_bucket" else None)
                 assert ex.active and ex.sharded == (mode == "sharded") and not ex._emulate
+                assert (ex._ext is not None) == (mode == "dense_word_in_bucket")
             for gi in grads:
-                gb = gi.clone()
+                gb.copy_(gi)
                 if ex is not None:
-                    ex.reduce_flag_async(None)
+                    ex.reduce_flag_async(torch.zeros(1, dtype=torch.int32, device=dev))
                     flag = ex.wait_flag()
                     ex.reduce_gradients(gb)
                     adam.step(params, gb, lrs, P, 1.0, exchange=ex, guard=flag)
@@ -53,6 +56,20 @@ def _worker(rank, world, port, outdir):
             res[mode] = params.cpu().numpy()
             assert adam.step_count == 3
         out[f"plain_{P}"], out[f"dense_{P}"], out[f"sharded_{P}"] = res["plain"], res["dense"], res["sharded"]
+        out[f"piggy_{P}"] = res["dense_word_in_bucket"]
+    # a raised overflow word riding in the bucket drops the step on the device
+    n = FLOATS_PER_GAUSSIAN * 1000
+    gb = torch.zeros(n + 4, device=dev)[:n]
+    ex = BucketExchange(n, dev, None, sharded=False, single_rank_collectives=True, grads=gb)
+    params = torch.ones(n, device=dev)
+    adam = FusedAdam(n, dev, OptimizationParams())
+    gb.fill_(1e-3)
+    ex.reduce_flag_async(torch.ones(1, dtype=torch.int32, device=dev))
+    flag = ex.wait_flag()
+    ex.reduce_gradients(gb)
+    adam.step(params, gb, lrs, 1000, 1.0, exchange=ex, guard=flag)
+    torch.cuda.synchronize()
+    out["dropped"] = np.array([float(flag.reshape(-1)[0]), float((params != 1).sum()), adam.step_count])
     # the whole trainer step once through the same collectives (no crash, finite parameters, sharded exchange in use)
     from segs_slam_amd import scenes
     from segs_slam_amd.gaussian_trainer import TrainerStep, keyframe_tensors
@@ -79,4 +96,6 @@ def test_sharded_exchange_under_rccl_with_one_rank_equals_dense_path():
     for P in (1000, 1001):
         assert np.array_equal(r[f"plain_{P}"], r[f"dense_{P}"]), P
         assert np.array_equal(r[f"plain_{P}"], r[f"sharded_{P}"]), P
+        assert np.array_equal(r[f"plain_{P}"], r[f"piggy_{P}"]), P
+    assert list(r["dropped"]) == [1.0, 0.0, 0.0]
     assert r["trainer_finite"].all() and int(r["trainer_steps"][0]) == 3
