@@ -377,27 +377,47 @@ __device__ __forceinline__ f32x16 layer2(const float* __restrict__ img, const Sm
 
 constexpr int NEURAL_GRID = 512;   // persistent forward workgroups (2 per CU; 4 per CU was slower: 112 -> 141 us at 300 k anchors), each loops over 128-anchor slabs
 
+// 2048 anchors per workgroup (eight rounds of 256) and ONE returning atomic on the list's count per workgroup: the count is a
+// single word, which takes about 12 ns per returning atomic whatever the parallelism -- with one per 256 anchors this kernel
+// spent 14 of its 17 us at 300 k anchors queueing on it.
+constexpr int CV_ROUNDS = 8;
 __global__ void __launch_bounds__(256) compact_visible_kernel(int A, const int* __restrict__ radii, uint32_t* __restrict__ count,
                                                               uint32_t* __restrict__ vis, float* __restrict__ opacity,
                                                               float* __restrict__ neural_opacity) {
-  __shared__ uint32_t wave_n[4], block_base;
-  const int a = blockIdx.x * 256 + threadIdx.x;
-  const bool v = a < A && (radii == nullptr || radii[a] > 0);
-  const uint64_t m = __ballot(v);
+  __shared__ uint32_t wave_n[CV_ROUNDS][4], block_base;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) wave_n[wv] = (uint32_t)__popcll(m);
+  const int a0 = blockIdx.x * (256 * CV_ROUNDS) + threadIdx.x;
+  uint32_t mine = 0u, below[CV_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < CV_ROUNDS; r++) {
+    const int a = a0 + r * 256;
+    const bool v = a < A && (radii == nullptr || radii[a] > 0);
+    const uint64_t m = __ballot(v);
+    if (lane == 0) wave_n[r][wv] = (uint32_t)__popcll(m);
+    below[r] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    mine |= (v ? 1u : 0u) << r;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {   // one returning atomic per workgroup (one per wave on a single word cost 10 us at A = 50 k)
-    const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+#pragma unroll
+    for (int r = 0; r < CV_ROUNDS; r++) tot += wave_n[r][0] + wave_n[r][1] + wave_n[r][2] + wave_n[r][3];
     block_base = tot ? atomicAdd(count, tot) : 0u;
   }
   __syncthreads();
   uint32_t base = block_base;
-  for (int w = 0; w < wv; w++) base += wave_n[w];
-  if (v) vis[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)a;
-  if (a < A && !v) {
 #pragma unroll
-    for (int k = 0; k < NO; k++) { opacity[(size_t)a * NO + k] = 0.f; neural_opacity[(size_t)a * NO + k] = 0.f; }
+  for (int r = 0; r < CV_ROUNDS; r++) {
+    const int a = a0 + r * 256;
+    uint32_t mybase = base;
+    for (int w = 0; w < wv; w++) mybase += wave_n[r][w];
+    const bool v = (mine >> r) & 1u;
+    if (v) vis[mybase + below[r]] = (uint32_t)a;
+    if (a < A && !v) {
+#pragma unroll
+      for (int k = 0; k < NO; k++) { opacity[(size_t)a * NO + k] = 0.f; neural_opacity[(size_t)a * NO + k] = 0.f; }
+    }
+    base += wave_n[r][0] + wave_n[r][1] + wave_n[r][2] + wave_n[r][3];
   }
 }
 
@@ -1142,7 +1162,7 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
   static_assert(N_IMG_BWD == 262 && sizeof(Small) <= 8192, "temp_carve sizes");
   // T.count: [0] visible anchors, [1] kept candidates; cleared (with the regulariser sum) by pack_tables_kernel
   pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small, T.count, T.gsum + L.total + 8);
-  const int nb = (A + 255) / 256;
+  const int nb = (A + 256 * CV_ROUNDS - 1) / (256 * CV_ROUNDS);
   compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity);
   neural_fwd_kernel<<<NEURAL_GRID, 256, N_IMG_FWD * 64 * sizeof(float) + sizeof(Small), st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
                                         camera_center, means3D, colors, opacity, scales, rotations, neural_opacity, T.count + 1);
