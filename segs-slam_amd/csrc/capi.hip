@@ -450,7 +450,7 @@ static int rasterize_backward_impl(int P, int D, int M, int R, const float* back
   { PROF(K_PREPROCESS_BWD);
   preprocess_bwd_kernel<<<G.L.nblocks, 256, 0, st>>>(P, means3D, radii, cov3D_precomp ? nullptr : scales, rotations,
                                                      scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
-                                                     tan_fovx, tan_fovy, G.gacc(), G.emit(), (float)width, (float)height, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                                                     tan_fovx, tan_fovy, G.gacc(), (float)width, (float)height, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
                                                      dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, self_clean ? 1 : 0);
   }
   LAUNCH_TRY("preprocess_bwd_kernel");
@@ -578,7 +578,7 @@ int segs_debug_preprocess_backward(int P, int width, int height, const float* me
   const float focal_y = height / (2.0f * tan_fovy), focal_x = width / (2.0f * tan_fovx);
   preprocess_bwd_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, means3D, radii, cov3D_precomp ? nullptr : scales, rotations,
                                                          scale_modifier, cov3D_precomp, viewmatrix, projmatrix, focal_x, focal_y,
-                                                         tan_fovx, tan_fovy, nullptr, nullptr, (float)width, (float)height, const_cast<float*>(dL_dmean2D),
+                                                         tan_fovx, tan_fovy, nullptr, (float)width, (float)height, const_cast<float*>(dL_dmean2D),
                                                          const_cast<float*>(dL_dconic), nullptr, nullptr, dL_dmean3D, dL_dcov3D,
                                                          dL_dscale, dL_drot, 0);
   LAUNCH_TRY("preprocess_bwd_kernel");

@@ -31,8 +31,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr int REC_DWORDS = 16;
 enum RecField { REC_X = 0, REC_Y, REC_A2, REC_B2, REC_C2, REC_O, REC_R, REC_G, REC_B, REC_CA, REC_CB, REC_CC, REC_DEPTH };
 
-// Per-Gaussian EMIT record, 8 dwords = 32 B (written for binned Gaussians only): what the instance emitter and the
-// per-Gaussian backward gather by index -- one 32-byte access instead of a 16-byte Bin record plus a 64-byte render record:
+// Per-Gaussian EMIT record, 8 dwords = 32 B (written for binned Gaussians only): what the instance emitter gathers by index in
+// depth order -- one 32-byte access instead of a 16-byte Bin record plus a 64-byte render record (the per-Gaussian backward,
+// which read it too until round 3, recomputes the conic and gets dL/dopacity ready-made from the tile kernel):
 //  [0] x  [1] y  [2] A  [3] B   [4] C  [5] opacity  [6] rect_min (x | y << 16)  [7] rect_max (x | y << 16)
 // (A, B, C = the conic as the reference stores it, conic_opacity.xyz)
 constexpr int EMIT_DWORDS = 8;
@@ -48,8 +49,8 @@ constexpr uint32_t ID_BITS = 28;                    // sort value = gaussian idx
 constexpr uint32_t ID_MASK = (1u << ID_BITS) - 1u;
 constexpr int MAX_GAUSSIANS = 1 << ID_BITS;
 
-// Gradient accumulation row, 16 dwords (64 B): [0,1] dL/dmean2D.xy  [2,3,4] dL/dconic (xx,xy,yy)
-// [5] dL/dopacity  [6,7,8] dL/dcolor.
+// Gradient accumulation row, 16 dwords (64 B), raw moments of the tile backward (render.hip): [0,1] Mx My  [2,3,4] Mxx Mxy Myy
+// [5] dL/dopacity (= S0 / opacity)  [6,7,8] dL/dcolor.
 constexpr int GACC_DWORDS = 16;
 
 constexpr size_t ALIGN = 256;

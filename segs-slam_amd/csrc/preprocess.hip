@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     int P, const float* __restrict__ means3D, const int* __restrict__ radii, const float* __restrict__ scales,
     const float* __restrict__ rotations, float mod, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ view, const float* __restrict__ proj, float h_x, float h_y, float tan_fovx, float tan_fovy,
-    float* __restrict__ gacc, const float* __restrict__ emit_in, float img_w, float img_h,
+    float* __restrict__ gacc, float img_w, float img_h,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
@@ -414,28 +414,25 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
   float g2x = 0.f, g2y = 0.f;            // dL/dmean2D, NDC-scaled (backward.cu:541-542)
   Sym2 G{0.f, 0.f, 0.f};                 // dL/dconic
   float dcol0 = 0.f, dcol1 = 0.f, dcol2 = 0.f, dop = 0.f;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;   // the tile kernel's row: Mx My Mxx Mxy | Myy dL/dopacity Sr Sg | Sb
   if (gacc) {
-    // Rows hold raw moments (render.hip): Mx My Mxx Mxy | Myy S0 Sr Sg | Sb = sums over the (pixel, Gaussian) pairs of
-    // w = dL/dG * G times 1, dx, dy, dx^2, ...; the reference's per-pair terms (backward.cu:541-554) are linear in them:
-    //   dL/dmean2D.x = -(A Mx + B My) W/2,  .y = -(C My + B Mx) H/2,  dL/dconic = -(Mxx, Mxy, Myy)/2,  dL/dopacity = S0 / o
+    // Rows hold raw moments (render.hip): sums over the (pixel, Gaussian) pairs of w = dL/dG * G times 1, dx, dy, dx^2, ...;
+    // the reference's per-pair terms (backward.cu:541-554) are linear in them:
+    //   dL/dmean2D.x = -(A Mx + B My) W/2,  .y = -(C My + B Mx) H/2,  dL/dconic = -(Mxx, Mxy, Myy)/2
+    // with (A, B, C) the conic, formed below from this kernel's own 2D covariance (round 2 gathered it -- and the opacity, which
+    // the tile kernel now divides out itself -- from the 32-byte emit record: 9 % of this kernel's traffic).
     if (binned) {
       float4* row = reinterpret_cast<float4*>(gacc + (size_t)idx * GACC_DWORDS);
-      const float4 a0 = row[0], a1 = row[1];
-      const float a8 = gacc[(size_t)idx * GACC_DWORDS + 8];
+      a0 = row[0]; a1 = row[1];
+      dcol2 = gacc[(size_t)idx * GACC_DWORDS + 8];
       if (clean_gacc) {   // only binned Gaussians' rows can have been touched by the tile kernel
         row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f);
         gacc[(size_t)idx * GACC_DWORDS + 8] = 0.f;
       }
-      const float4 e0 = reinterpret_cast<const float4*>(emit_in + (size_t)idx * EMIT_DWORDS)[0];   // x, y, A, B
-      const float2 e1 = reinterpret_cast<const float2*>(emit_in + (size_t)idx * EMIT_DWORDS)[2];   // C, opacity
-      const float cA = e0.z, cB = e0.w, cC = e1.x, op = e1.y;
-      g2x = -(cA * a0.x + cB * a0.y) * (0.5f * img_w);
-      g2y = -(cC * a0.y + cB * a0.x) * (0.5f * img_h);
       G.xx = -0.5f * a0.z; G.xy = -0.5f * a0.w; G.yy = -0.5f * a1.x;
-      dop = a1.y != 0.f ? a1.y / op : 0.f;
-      dcol0 = a1.z; dcol1 = a1.w; dcol2 = a8;
+      dop = a1.y;
+      dcol0 = a1.z; dcol1 = a1.w;
     }
-    store_row3(dL_dmean2D, P, lds, g2x, g2y, 0.f);
     store_row3(dL_dcolor, P, lds, dcol0, dcol1, dcol2);
     if (live) {
       if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(G.xx, G.xy, 0.f, G.yy);   // internal product: optional
@@ -498,6 +495,12 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     // ---- Dc = -k adj(C) G adj(C)
     const float det = a * c - b * b;
     const float k = 1.0f / (det * det + 0.0000001f);
+    if (gacc) {   // dL/dmean2D from the moments and the conic (c, -b, a) / det (forward.cu:217-218)
+      const float di = 1.0f / det;
+      const float cA = c * di, cB = -b * di, cC = a * di;
+      g2x = -(cA * a0.x + cB * a0.y) * (0.5f * img_w);
+      g2y = -(cC * a0.y + cB * a0.x) * (0.5f * img_h);
+    }
     const float h0 = c * G.xx - b * G.xy, h1 = c * G.xy - b * G.yy;     // rows of adj(C) G
     const float h2 = a * G.xy - b * G.xx, h3 = a * G.yy - b * G.xy;
     Sym2 Dc;
@@ -567,6 +570,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
       out_rot[3] = 2.f * (r * (GR[1][0] - GR[0][1]) + x * (GR[0][2] + GR[2][0]) + y * (GR[1][2] + GR[2][1])) - 4.f * z * (GR[0][0] + GR[1][1]);
     }
   }
+  if (gacc) store_row3(dL_dmean2D, P, lds, g2x, g2y, 0.f);
   store_row3(dL_dmean3D, P, lds, out_mean[0], out_mean[1], out_mean[2]);
   if (dL_dscale) store_row3(dL_dscale, P, lds, out_scale[0], out_scale[1], out_scale[2]);
   if (!live) return;

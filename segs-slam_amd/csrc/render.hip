@@ -245,8 +245,8 @@ __device__ __forceinline__ float fold_rows4(float a, float b, float c, float d) 
 //      Sum aT*dL/dpixel[rgb] with plain FMAs -- no cross-lane reduction per pair.  Four row partials per slot are
 //      folded with permlane swaps, shifted from quadrant-local to Gaussian-relative moments, and leave as one
 //      float-atomic wave instruction per 4 Gaussians (36 contiguous bytes per Gaussian).
-// The accumulated row holds raw moments (Mx, My, Mxx, Mxy, Myy, S0, Sr, Sg, Sb); preprocess_bwd_kernel turns
-// them into the reference's dL/dmean2D, dL/dconic, dL/dopacity (backward.cu:541-554) with the per-Gaussian conic.
+// The accumulated row holds raw moments (Mx, My, Mxx, Mxy, Myy, S0 / o, Sr, Sg, Sb); preprocess_bwd_kernel turns
+// them into the reference's dL/dmean2D and dL/dconic (backward.cu:541-554) with the per-Gaussian conic; S0 / o IS dL/dopacity.
 // acc += a * (value of `v` in lane I of this lane's 16-lane row): the DPP row broadcast rides on the FMA itself, so the
 // Gaussian role gets dL/dpixel of pixel 16*part + I straight from the pixel lanes' registers -- no LDS read.
 template <int I>
@@ -458,9 +458,13 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
         const float Mxy = hx * (hy * m0.x - m0.z) - hy * m0.y + m1.x;
         const float Myy = hy * (hy * m0.x - 2.f * m0.z) + m1.y;
         wave_lds_fence();
+        // S0 = sum of w = o * sum of G dL/dalpha leaves as dL/dopacity = S0 / o (backward.cu:554): the per-Gaussian backward
+        // then needs no opacity -- and with its conic recomputed there, no record gather at all
+        const float inv_o = fast_rcp(reinterpret_cast<const float*>(&L.rec[gs][1])[1]);
+        wave_lds_fence();
         if (part == 0) {
           *reinterpret_cast<float4*>(&mom[gs][0]) = make_float4(Mx, My, Mxx, Mxy);
-          *reinterpret_cast<float4*>(&mom[gs][4]) = make_float4(Myy, m0.x, m1.z, m1.w);
+          *reinterpret_cast<float4*>(&mom[gs][4]) = make_float4(Myy, m0.x * inv_o, m1.z, m1.w);
           mom[gs][8] = m8;
         }
       }
