@@ -209,7 +209,7 @@ struct EmitLds {
 constexpr uint32_t EMIT_OWNER_MASK = 1023u;
 
 __device__ __forceinline__ void emit_stage_owner(EmitLds& L, int k, uint32_t idx, const float4& e0, const float4& e1) {
-  // e0, e1: the 32-byte emit record  x y A B | C opacity rect_min rect_max
+  // e0, e1: x y A B | C opacity rect_min rect_max, picked from the Gaussian's record
   const uint32_t rmin = __float_as_uint(e1.z), rmax = __float_as_uint(e1.w);
   L.idx[k] = idx;
   L.bin[k] = make_uint2(rmin, (rmax & 0xFFFFu) - (rmin & 0xFFFFu));
@@ -267,7 +267,7 @@ __device__ __forceinline__ void emit_instance(const EmitLds& L, int g, uint32_t 
 }
 
 __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
-    int P, int R, const float* __restrict__ emit /* 32-byte emit records, gs_layout.h */, const uint32_t* __restrict__ order,
+    int P, int R, const float* __restrict__ rec /* the 64-byte per-Gaussian records, gs_layout.h */, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ incl, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
     const uint32_t* __restrict__ n_dev /* resident mode: R lives on the device, `R` is the capacity */,
     int mark_dead /* instances that reach no quadrant get DEAD_KEY: the first tile-id pass drops them */,
@@ -298,9 +298,10 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     if (k < n_own) {
       emit_mark_owner(L.mark, k, start, s0, 1u);
       const uint32_t idx = order[g_lo + k];
-      const float4* e = reinterpret_cast<const float4*>(emit + (size_t)idx * EMIT_DWORDS);   // ONE 32-byte gather per owner
-      const float4 e0 = e[0], e1 = e[1];
-      emit_stage_owner(L, k, idx, e0, e1);
+      const float4* r = reinterpret_cast<const float4*>(rec + (size_t)idx * REC_DWORDS);   // ONE line per owner (gs_layout.h)
+      const float4 q0 = r[0], q2 = r[2], q3 = r[3];
+      const float op = reinterpret_cast<const float*>(r)[REC_O];
+      emit_stage_owner(L, k, idx, make_float4(q0.x, q0.y, q2.y, q2.z), make_float4(q2.w, op, q3.y, q3.z));
     }
   }
   __syncthreads();

@@ -189,7 +189,6 @@ struct Geom {
   uint32_t* clamped() const { return (uint32_t*)(base + L.clamped); }
   float* gacc() const { return (float*)(base + L.gacc); }
   uint32_t* touched() const { return (uint32_t*)(base + L.touched); }
-  float* emit() const { return (float*)(base + L.emit); }
 };
 Geom geom_at(char* p, int P) { return Geom{geom_layout(P), align_ptr(p)}; }
 // Resident buffers are carved up for the `rows` they were ALLOCATED (and zero-filled) for, so that the self-cleaned
@@ -215,7 +214,7 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
                                                      proj, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, radii,
                                                      G.rec(), G.bin(), G.block_sums(), G.block_sums() + (G.L.nblocks + 1), shs, D, M, cam_pos,
                                                      G.clamped(), g_flags | extra_flags, depth_keys, depth_vals, ranges, (int)(gx * gy),
-                                                     depth_overflow, G.touched(), G.emit());
+                                                     depth_overflow, G.touched());
   }
   LAUNCH_TRY("preprocess_fwd_kernel");
   return SEGS_OK;
@@ -279,7 +278,7 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   LAUNCH_TRY("ordered_offsets_kernel");
   const bool unfused = (g_flags & SEGS_RASTER_UNFUSED_BINNING) != 0u;
   { PROF(K_DUPLICATE);
-  duplicate_with_keys_kernel<<<(n_cap + EMIT_SLOTS_PER_WG - 1) / EMIT_SLOTS_PER_WG, 256, 0, st>>>(P, n_cap, G.emit(), order, G.offsets(),
+  duplicate_with_keys_kernel<<<(n_cap + EMIT_SLOTS_PER_WG - 1) / EMIT_SLOTS_PER_WG, 256, 0, st>>>(P, n_cap, G.rec(), order, G.offsets(),
                                                                     (uint32_t*)(bin + BL.keys[side]), (uint32_t*)(bin + BL.vals[side]), gx, n_dev,
                                                                     drop_dead ? 1 : 0, ng_dev, first_owner);
   }

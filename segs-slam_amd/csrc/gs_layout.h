@@ -27,16 +27,13 @@ constexpr float LOG2E = 1.4426950408889634f;
 //  [6..8] r g b            colour (colors_precomp, or SH->RGB result)
 //  [9..11] A B C           conic as the reference stores it (conic_opacity.xyz)
 //  [12] depth              view-space z (GeometryState::depths)
-//  [13..15] reserved
+//  [13] rect_min  [14] rect_max   tile rectangle, x | y << 16 each (bit patterns)     [15] reserved
+// The tile kernels read [0..8]; the instance emitter gathers x, y, opacity, the conic [9..11] and the rectangle of every owner
+// from the SAME record (a random gather pulls the whole 128-byte line whatever it reads, tools/ubench_gather.hip), so there
+// is no second per-Gaussian record: until round 3 a 32-byte "emit record" duplicated those fields for the emitter and the
+// per-Gaussian backward -- a sixth of preprocess_fwd_kernel's traffic.
 constexpr int REC_DWORDS = 16;
-enum RecField { REC_X = 0, REC_Y, REC_A2, REC_B2, REC_C2, REC_O, REC_R, REC_G, REC_B, REC_CA, REC_CB, REC_CC, REC_DEPTH };
-
-// Per-Gaussian EMIT record, 8 dwords = 32 B (written for binned Gaussians only): what the instance emitter gathers by index in
-// depth order -- one 32-byte access instead of a 16-byte Bin record plus a 64-byte render record (the per-Gaussian backward,
-// which read it too until round 3, recomputes the conic and gets dL/dopacity ready-made from the tile kernel):
-//  [0] x  [1] y  [2] A  [3] B   [4] C  [5] opacity  [6] rect_min (x | y << 16)  [7] rect_max (x | y << 16)
-// (A, B, C = the conic as the reference stores it, conic_opacity.xyz)
-constexpr int EMIT_DWORDS = 8;
+enum RecField { REC_X = 0, REC_Y, REC_A2, REC_B2, REC_C2, REC_O, REC_R, REC_G, REC_B, REC_CA, REC_CB, REC_CC, REC_DEPTH, REC_RECT_MIN, REC_RECT_MAX };
 
 // Per-Gaussian bin record (uint4): depth bits, rect_min (x | y<<16), rect_max (x | y<<16), tiles_touched.
 struct BinInfo { uint32_t depth_bits, rect_min, rect_max, tiles_touched; };
@@ -57,7 +54,7 @@ constexpr size_t ALIGN = 256;
 inline size_t align_up(size_t v, size_t a = ALIGN) { return (v + a - 1) / a * a; }
 
 struct GeomLayout {
-  size_t rec, bin, offsets, radii_internal, block_sums, clamped, num_rendered, gacc, touched, emit, total;
+  size_t rec, bin, offsets, radii_internal, block_sums, clamped, num_rendered, gacc, touched, total;
   int P, nblocks;
 };
 // Mirrors GeometryState::fromChunk (rasterizer_impl.cu:155-170) in role, not in layout.
@@ -75,7 +72,6 @@ inline GeomLayout geom_layout(int P) {
   g.num_rendered = o;   o = align_up(o + 64);
   g.gacc = o;           o = align_up(o + (size_t)P * GACC_DWORDS * 4);
   g.touched = o;        o = align_up(o + (size_t)P * 4);  // tiles_touched once more, dense: the depth-ordered prefix gathers 4 B, not a 16-B BinInfo
-  g.emit = o;           o = align_up(o + (size_t)P * EMIT_DWORDS * 4);
   g.total = o + ALIGN;  // slack so the base pointer can be aligned up
   return g;
 }

@@ -20,8 +20,7 @@ __global__ void preprocess_fwd_kernel(
     int* __restrict__ radii, float* __restrict__ rec, BinInfo* __restrict__ bin, uint32_t* __restrict__ block_sums,
     uint32_t* __restrict__ depth_range, const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos,
     uint32_t* __restrict__ clamped, uint32_t flags, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ depth_vals,
-    uint2* __restrict__ ranges, int num_tiles, uint32_t* __restrict__ depth_overflow, uint32_t* __restrict__ touched_dense,
-    float* __restrict__ emit);
+    uint2* __restrict__ ranges, int num_tiles, uint32_t* __restrict__ depth_overflow, uint32_t* __restrict__ touched_dense);
 // Resident depth sort: every binned Gaussian has view depth > 0.2 (auxiliary.h:155), so its float bits exceed those of
 // 0.2f; 27 bits above that (16 binades: depths below 13 107.2) are sorted in three 9-bit passes.
 constexpr uint32_t DEPTH_KEY_MIN = 0x3E4CCCCDu;   // bits of 0.2f
@@ -55,7 +54,7 @@ __global__ void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nb
 __global__ void ordered_offsets_kernel(int P, const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ incl,
                                        uint32_t* __restrict__ total_out, const uint32_t* __restrict__ ng_dev,
                                        uint32_t* __restrict__ first_owner, uint32_t owner_entries);
-__global__ void duplicate_with_keys_kernel(int P, int R, const float* __restrict__ emit,
+__global__ void duplicate_with_keys_kernel(int P, int R, const float* __restrict__ rec,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ incl,
                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t gx,
                                            const uint32_t* __restrict__ n_dev, int mark_dead, const uint32_t* __restrict__ ng_dev,

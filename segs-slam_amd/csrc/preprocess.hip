@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
     const float* __restrict__ shs, int D, int M, const float* __restrict__ cam_pos, uint32_t* __restrict__ clamped,
     uint32_t flags, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ depth_vals, uint2* __restrict__ ranges,
     int num_tiles, uint32_t* __restrict__ depth_overflow /* resident: set when a binned depth leaves the 27-bit key range */,
-    uint32_t* __restrict__ touched_dense, float* __restrict__ emit) {
+    uint32_t* __restrict__ touched_dense) {
   __shared__ float lds[3 * 768];
   __shared__ uint32_t wave_sums[4], wave_dmax[4], wave_dnmin[4];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -278,10 +278,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       r4[0] = make_float4(g.px, g.py, (-0.5f * LOG2E) * g.conic.x, (-LOG2E) * g.conic.y);
       r4[1] = make_float4((-0.5f * LOG2E) * g.conic.z, op, col.x, col.y);
       r4[2] = make_float4(col.z, g.conic.x, g.conic.y, g.conic.z);
-      r4[3] = make_float4(g.depth, 0.f, 0.f, 0.f);
-      float4* e4 = reinterpret_cast<float4*>(emit + (size_t)idx * EMIT_DWORDS);   // gs_layout.h: the emitter's / backward's gather
-      e4[0] = make_float4(g.px, g.py, g.conic.x, g.conic.y);
-      e4[1] = make_float4(g.conic.z, op, __uint_as_float(b.rect_min), __uint_as_float(b.rect_max));
+      r4[3] = make_float4(g.depth, __uint_as_float(b.rect_min), __uint_as_float(b.rect_max), 0.f);   // the emitter's rectangle
     }
     radii[idx] = g.radius;
     // BinInfo feeds make_depth_keys_kernel and the parity-test unpackers of the reference-shaped path; the resident path
