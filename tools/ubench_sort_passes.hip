@@ -45,7 +45,8 @@ void run(const char* name, const std::vector<uint32_t>& keys, int end_bit, uint3
       radix_scan_kernel<<<1 << BITS, 256>>>(chunk_hist, nchunks, digit_totals);
       CK(hipEventRecord(ev[e++]));
       radix_scatter_kernel<uint32_t, BITS, false><<<(L.nblocks + 7) / 8 * 8, SORT_THREADS>>>(kin, (iota && p == 0) ? nullptr : vin, kout, vout, n, shift, dmin, dbits, tile_prefix,
-                                                                          chunk_hist, digit_totals, L.nblocks, nchunks, nullptr, 0, nullptr, nullptr, nullptr, nbits, chunk_tiles, 0);
+                                                                          chunk_hist, digit_totals, L.nblocks, nchunks, nullptr, 0, nullptr, nullptr, nullptr, nbits, chunk_tiles, 0,
+                                                                          nullptr, nullptr, nullptr, 1);
       CK(hipEventRecord(ev[e++]));
       side ^= 1;
     }
