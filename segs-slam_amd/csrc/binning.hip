@@ -201,21 +201,22 @@ struct EmitLds {
   uint32_t excl[EMIT_SLOTS + 2];   // first slot of owner k (= inclusive offset of the Gaussian before it); n_own + 1 entries
   uint32_t idx[EMIT_SLOTS + 1];    // Gaussian index of owner k
   uint2 bin[EMIT_SLOTS + 1];       // rect min (x | y << 16), rect width in tiles
-  float4 geo0[EMIT_SLOTS + 1];     // x, y, A, B
-  float2 geo1[EMIT_SLOTS + 1];     // C, k = inflated 2 ln(255 o) (or -1: no pixel can reach alpha >= 1/255)
+  float4 geo0[EMIT_SLOTS + 1];     // x, y, A', B' (the conic scaled for exp2, sign flipped: see emit_stage_owner)
+  float2 geo1[EMIT_SLOTS + 1];     // C', k = inflated log2(255 o) (or -1: no pixel can reach alpha >= 1/255)
   uint32_t mark[EMIT_SLOTS];       // 1 << 10 | owner, at the owner's first slot (0 = no owner starts here)
   uint32_t wave_max[4];
 };
 constexpr uint32_t EMIT_OWNER_MASK = 1023u;
 
 __device__ __forceinline__ void emit_stage_owner(EmitLds& L, int k, uint32_t idx, const float4& e0, const float4& e1) {
-  // e0, e1: x y A B | C opacity rect_min rect_max, picked from the Gaussian's record
+  // e0, e1: x y A2 B2 | C2 opacity rect_min rect_max, picked from the Gaussian's record.  The quadrant test runs on
+  // q(d) = -(A2 dx^2 + B2 dx dy + C2 dy^2) = -log2 of the Gaussian's falloff: alpha >= 1/255  <=>  q <= log2(255 o).
   const uint32_t rmin = __float_as_uint(e1.z), rmax = __float_as_uint(e1.w);
   L.idx[k] = idx;
   L.bin[k] = make_uint2(rmin, (rmax & 0xFFFFu) - (rmin & 0xFFFFu));
   const float op = e1.y;
-  L.geo0[k] = e0;
-  L.geo1[k] = make_float2(e1.x, (op * 255.0f > 1.0f) ? 2.0f * __logf(255.0f * op) * 1.0001f + 1e-3f : -1.0f);
+  L.geo0[k] = make_float4(e0.x, e0.y, -e0.z, -0.5f * e0.w);    // x, y, A' = -A2, B' = -B2 / 2  (q = A' dx^2 + 2 B' dx dy + C' dy^2)
+  L.geo1[k] = make_float2(-e1.x, (op * 255.0f > 1.0f) ? __builtin_amdgcn_logf(255.0f * op) * 1.0001f + 1e-3f : -1.0f);
 }
 // owner k's first slot is `start`; its mark goes to the slot's position inside the sub-batch [s0, s0 + 512) (owner 0 may
 // start before s0: position 0; an owner that starts behind the sub-batch -- the next sub-batch's first -- leaves no mark)
@@ -298,10 +299,11 @@ __global__ void __launch_bounds__(256) duplicate_with_keys_kernel(
     if (k < n_own) {
       emit_mark_owner(L.mark, k, start, s0, 1u);
       const uint32_t idx = order[g_lo + k];
-      const float4* r = reinterpret_cast<const float4*>(rec + (size_t)idx * REC_DWORDS);   // ONE line per owner (gs_layout.h)
-      const float4 q0 = r[0], q2 = r[2], q3 = r[3];
-      const float op = reinterpret_cast<const float*>(r)[REC_O];
-      emit_stage_owner(L, k, idx, make_float4(q0.x, q0.y, q2.y, q2.z), make_float4(q2.w, op, q3.y, q3.z));
+      const float* r = rec + (size_t)idx * REC_DWORDS;   // ONE line per owner, 32 bytes of it in three loads (gs_layout.h)
+      const float4 q0 = *reinterpret_cast<const float4*>(r);                   // x y A2 B2
+      const float2 q1 = *reinterpret_cast<const float2*>(r + REC_C2);          // C2 opacity
+      const float2 q2 = *reinterpret_cast<const float2*>(r + REC_RECT_MIN);    // rect_min rect_max
+      emit_stage_owner(L, k, idx, q0, make_float4(q1.x, q1.y, q2.x, q2.y));
     }
   }
   __syncthreads();

@@ -20,20 +20,20 @@ constexpr int NUM_CHANNELS = 3;  // cuda_rasterizer/config.h:15
 
 constexpr float LOG2E = 1.4426950408889634f;
 
-// Per-Gaussian render record, 16 dwords = 64 B, 64-B aligned.
+// Per-Gaussian record, 16 dwords = 64 B, 64-B aligned -- the ONLY per-Gaussian record of the pipeline.
 //  [0] x  [1] y            pixel-space mean           (reference: GeometryState::means2D)
 //  [2] A2 [3] B2 [4] C2    conic pre-scaled for exp2: A2=-0.5*log2e*A, B2=-log2e*B, C2=-0.5*log2e*C
 //  [5] opacity             (reference: conic_opacity.w)
 //  [6..8] r g b            colour (colors_precomp, or SH->RGB result)
-//  [9..11] A B C           conic as the reference stores it (conic_opacity.xyz)
-//  [12] depth              view-space z (GeometryState::depths)
-//  [13] rect_min  [14] rect_max   tile rectangle, x | y << 16 each (bit patterns)     [15] reserved
-// The tile kernels read [0..8]; the instance emitter gathers x, y, opacity, the conic [9..11] and the rectangle of every owner
-// from the SAME record (a random gather pulls the whole 128-byte line whatever it reads, tools/ubench_gather.hip), so there
-// is no second per-Gaussian record: until round 3 a 32-byte "emit record" duplicated those fields for the emitter and the
-// per-Gaussian backward -- a sixth of preprocess_fwd_kernel's traffic.
+//  [9] depth               view-space z (GeometryState::depths)
+//  [10] rect_min  [11] rect_max   tile rectangle, x | y << 16 each (bit patterns)
+//  [12..14] A B C          conic as the reference stores it (conic_opacity.xyz; debug unpackers only)   [15] reserved
+// The tile kernels read [0..8].  The instance emitter gathers [0..5] and [10..11] of every owner -- the same 32 bytes a
+// separate "emit record" held until round 3, in three loads (16 + 8 + 8 bytes) from this record: a random gather pulls the
+// whole 128-byte line whatever it reads (tools/ubench_gather.hip), so the second record bought the emitter nothing and cost
+// preprocess_fwd_kernel a sixth of its traffic.  The emitter's quadrant test runs on the scaled conic (threshold log2(255 o)).
 constexpr int REC_DWORDS = 16;
-enum RecField { REC_X = 0, REC_Y, REC_A2, REC_B2, REC_C2, REC_O, REC_R, REC_G, REC_B, REC_CA, REC_CB, REC_CC, REC_DEPTH, REC_RECT_MIN, REC_RECT_MAX };
+enum RecField { REC_X = 0, REC_Y, REC_A2, REC_B2, REC_C2, REC_O, REC_R, REC_G, REC_B, REC_DEPTH, REC_RECT_MIN, REC_RECT_MAX, REC_CA, REC_CB, REC_CC };
 
 // Per-Gaussian bin record (uint4): depth bits, rect_min (x | y<<16), rect_max (x | y<<16), tiles_touched.
 struct BinInfo { uint32_t depth_bits, rect_min, rect_max, tiles_touched; };

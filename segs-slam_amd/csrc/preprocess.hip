@@ -277,8 +277,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       // A2/B2/C2: conic pre-scaled so the tile kernels evaluate alpha = o * exp2(A2 dx^2 + B2 dx dy + C2 dy^2)
       r4[0] = make_float4(g.px, g.py, (-0.5f * LOG2E) * g.conic.x, (-LOG2E) * g.conic.y);
       r4[1] = make_float4((-0.5f * LOG2E) * g.conic.z, op, col.x, col.y);
-      r4[2] = make_float4(col.z, g.conic.x, g.conic.y, g.conic.z);
-      r4[3] = make_float4(g.depth, __uint_as_float(b.rect_min), __uint_as_float(b.rect_max), 0.f);   // the emitter's rectangle
+      r4[2] = make_float4(col.z, g.depth, __uint_as_float(b.rect_min), __uint_as_float(b.rect_max));   // [10..11]: the emitter's rectangle
+      r4[3] = make_float4(g.conic.x, g.conic.y, g.conic.z, 0.f);
     }
     radii[idx] = g.radius;
     // BinInfo feeds make_depth_keys_kernel and the parity-test unpackers of the reference-shaped path; the resident path

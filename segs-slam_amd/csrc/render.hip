@@ -31,8 +31,6 @@
 
 namespace segs {
 
-struct RecS { float x, y, a2, b2, c2, o, r, g, b, ca, cb, cc; };
-
 // XCD-aware workgroup -> tile mapping.  Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so with
 // the identity mapping horizontally adjacent tiles -- which share most of their Gaussians -- land on 8 different L2s and
 // every record is fetched up to 8 times.  Here each group of 64 consecutive tiles is cut into 8 runs of 8 adjacent tiles,
@@ -44,16 +42,6 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t wg, uint32_t num_tiles) {
   return (local >> 3) * 64u + xcd * 8u + (local & 7u);
 }
 
-__device__ __forceinline__ RecS load_rec(const float* __restrict__ rec, uint32_t id) {
-  const float4* p = reinterpret_cast<const float4*>(rec + (size_t)id * REC_DWORDS);
-  const float4 q0 = p[0], q1 = p[1], q2 = p[2];
-  RecS r;
-  r.x = q0.x; r.y = q0.y; r.a2 = q0.z; r.b2 = q0.w;
-  r.c2 = q1.x; r.o = q1.y; r.r = q1.z; r.g = q1.w;
-  r.b = q2.x; r.ca = q2.y; r.cb = q2.z; r.cc = q2.w;
-  return r;
-}
-
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int lane) {
@@ -61,26 +49,6 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int lane) {
 }
 
 
-// Per-lane copy of one record (the lane's own list entry); q2.x = blue, q2.yzw = conic (backward only).
-struct LaneRec { float4 q0, q1, q2; };
-__device__ __forceinline__ LaneRec load_lane_rec_fwd(const float* __restrict__ rec, uint32_t v, uint32_t qbit) {
-  LaneRec r;
-  r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0;
-  if ((v & qbit) != 0u) {
-    const float4* p = reinterpret_cast<const float4*>(rec + (size_t)(v & ID_MASK) * REC_DWORDS);
-    r.q0 = p[0]; r.q1 = p[1]; r.q2.x = reinterpret_cast<const float*>(p)[8];
-  }
-  return r;
-}
-__device__ __forceinline__ LaneRec load_lane_rec_bwd(const float* __restrict__ rec, uint32_t v, uint32_t qbit) {
-  LaneRec r;
-  r.q0 = make_float4(0.f, 0.f, 0.f, 0.f); r.q1 = r.q0; r.q2 = r.q0;
-  if ((v & qbit) != 0u) {
-    const float4* p = reinterpret_cast<const float4*>(rec + (size_t)(v & ID_MASK) * REC_DWORDS);
-    r.q0 = p[0]; r.q1 = p[1]; r.q2 = p[2];
-  }
-  return r;
-}
 __device__ __forceinline__ float rl(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
