@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include "../../include/segs_neural.h"
 #include "../../include/segs_raster.h"
 #include "kernels.h"
@@ -224,10 +225,10 @@ __device__ __forceinline__ void stage_tables(float* __restrict__ img, Small& S, 
   const float4* src = reinterpret_cast<const float4*>(g_img);
   float4* dst = reinterpret_cast<float4*>(img);
 #pragma unroll 4
-  for (int e = threadIdx.x; e < n_img * 16; e += 256) dst[e] = src[e];
+  for (int e = threadIdx.x; e < n_img * 16; e += blockDim.x) dst[e] = src[e];
   const float4* s2 = reinterpret_cast<const float4*>(g_small);
   float4* d2 = reinterpret_cast<float4*>(&S);
-  for (int e = threadIdx.x; e < (int)(sizeof(Small) / 16); e += 256) d2[e] = s2[e];
+  for (int e = threadIdx.x; e < (int)(sizeof(Small) / 16); e += blockDim.x) d2[e] = s2[e];
   __syncthreads();
 }
 
@@ -532,6 +533,13 @@ constexpr int BWD_GRID = 256;                // one workgroup per CU; also the n
 static_assert(BWD_GRID == WG_WAVES, "the fused backward's partial tiles reuse the per-wave slots of the reduce kernel");
 constexpr int N_SMALL = 20;                  // per-lane scalar accumulators: 5 + 3 bias sums, 3 x 4 tail columns
 
+__device__ __forceinline__ void get_tile(const float* buf, int col, int h, f32x16& v) {   // what put_tile of the same lane wrote
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const float4 q = *reinterpret_cast<const float4*>(buf + col * TS + 8 * g + 4 * h);
+    v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+  }
+}
 __device__ __forceinline__ void put_tile(float* buf, int col, int h, const f32x16& v) {
 #pragma unroll
   for (int g = 0; g < 4; g++)    // registers 4g..4g+3 are units 8g + 4h .. + 3
@@ -539,6 +547,7 @@ __device__ __forceinline__ void put_tile(float* buf, int col, int h, const f32x1
 }
 // acc[i][j] += sum_a A[a][i] B[a][j] over the slab's 32 anchors; asum += this lane's column of A (bias gradient of unit i,
 // half of the anchors per lane half)
+template <int GROUP = 16>   // steps whose operand loads may be in flight together (the gradient wave of the pair kernel has no registers for 16)
 __device__ __forceinline__ void wgrad_chain(const float* bufA, const float* bufB, int lane, f32x16& acc,
                                             float& asum) {
   const float* pa = bufA + (lane >> 5) * TS + (lane & 31);
@@ -548,10 +557,12 @@ __device__ __forceinline__ void wgrad_chain(const float* bufA, const float* bufB
     const float av = pa[2 * s * TS], bv = pb[2 * s * TS];
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     asum += av;
+    if (GROUP < 16 && (s + 1) % GROUP == 0) __builtin_amdgcn_sched_barrier(0);
   }
 }
 // the same for a first layer: B = the 32 features; the four tail inputs (view xyz, dist) are too few for a tile of their
 // own and are accumulated on the VALU from the A values that are in registers anyway
+template <int TSTRIDE = 4, int GROUP = 16>   // floats between the tail rows of consecutive anchors; see wgrad_chain
 __device__ __forceinline__ void wgrad_chain_tail(const float* bufA, const float* bufB,
                                                  const float* bufT, int lane, f32x16& acc, float& asum, float* tl) {
   const int half = lane >> 5;
@@ -560,10 +571,11 @@ __device__ __forceinline__ void wgrad_chain_tail(const float* bufA, const float*
 #pragma unroll
   for (int s = 0; s < 16; s++) {
     const float av = pa[2 * s * TS], bv = pb[2 * s * TS];
-    const float4 t = *reinterpret_cast<const float4*>(bufT + (2 * s + half) * 4);
+    const float4 t = *reinterpret_cast<const float4*>(bufT + (2 * s + half) * TSTRIDE);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     asum += av;
     tl[0] += av * t.x; tl[1] += av * t.y; tl[2] += av * t.z; tl[3] += av * t.w;
+    if (GROUP < 16 && (s + 1) % GROUP == 0) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -934,6 +946,328 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
   }
 }
 
+// ---- the plain model's backward: chain waves and weight-gradient waves ------------------------------------------------
+// The one-kernel form above keeps 128 accumulator registers next to the chain's own state in ONE wave: nothing else fits on its
+// SIMD, the matrix pipe idles while that wave does element-wise work or waits for memory (34 % busy at 300 k anchors), and a
+// third of its vector instructions are register copies between the two halves of the 512-register file.  Here a workgroup is
+// four PAIRS of waves, a pair per SIMD:
+//   chain wave  (waves 0-3): forward recompute, element-wise backward, dH and dX chains -- 262 MFMAs per slab, no accumulators;
+//   wgrad wave  (waves 4-7): the eight weight-gradient products of the slab -- 128 MFMAs, the 128 accumulators, nothing else.
+// The chain wave hands every operand over as a transposition tile in LDS (the tiles existed already); a workgroup barrier per
+// product ("job") orders the hand-over: the chain wave writes tile D[j & 1] of job j and passes barrier j, the wgrad wave runs
+// job j after barrier j and arrives at barrier j + 1 when it is done -- so job j's MFMAs run under the chain wave's work on job
+// j + 1.  Single-buffered tiles are written where the partner cannot be reading them: H of an MLP after the barrier of the
+// previous MLP's first-layer job (which reads D, X, T), X and T of a slab after the slab's first barrier (the previous slab's
+// last job is over then).  All eight waves of a workgroup run the same number of rounds, so the barriers match.
+constexpr int PAIR_LDS = 4 * T_TILE + 32 * 4;   // X | H | D0 | D1 | tail(view xyz, dist), floats per pair of waves
+constexpr int PAIR_STAGE = 8 * 1024 + N_SMALL * 64;   // end of kernel: a wgrad wave's eight tiles and its scalar sums
+
+__global__ void __launch_bounds__(512, 1) neural_bwd_pair_kernel(
+    Layout L, const uint32_t* __restrict__ count, const uint32_t* __restrict__ vis, const float* __restrict__ anchor,
+    const float* __restrict__ offset, const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
+    const float* __restrict__ g_img, const Small* __restrict__ g_small, const float* __restrict__ campos,
+    const float* __restrict__ g_means, const float* __restrict__ g_colors, const float* __restrict__ g_opacity,
+    const float* __restrict__ g_scales, const float* __restrict__ g_rot, float* __restrict__ d_anchor,
+    float* __restrict__ d_offset, float* __restrict__ d_feat, float* __restrict__ d_scaling_log,
+    float* __restrict__ partial, float reg_weight, float* __restrict__ reg_sum) {
+  extern __shared__ __align__(16) float lds_dyn[];
+  float* img = lds_dyn;
+  Small& S = *reinterpret_cast<Small*>(lds_dyn + N_IMG_BWD * 64);
+  const uint32_t n = *count;
+  if (blockIdx.x * 128u >= n) return;
+  stage_tables(img, S, N_IMG_BWD, g_img, g_small);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int pair = wv & 3;
+  const bool chain_role = wv < 4;   // wave-uniform
+  const int col = lane & 31, h = lane >> 5;
+  float* const bufX = lds_dyn + N_IMG_BWD * 64 + sizeof(Small) / 4 + pair * PAIR_LDS;
+  float* const bufH = bufX + T_TILE;
+  float* const bufD0 = bufH + T_TILE;
+  float* const bufD1 = bufD0 + T_TILE;
+  float* const bufT = bufD1 + T_TILE;
+  const uint32_t per_round = gridDim.x * 128u;
+  const uint32_t rounds = (n - blockIdx.x * 128u + per_round - 1u) / per_round;   // of this workgroup: the same for its eight waves
+  float* const stage = lds_dyn;   // [4 wgrad waves][PAIR_STAGE], after the last round
+
+  if (chain_role) {
+    // Memory round trips are what a chain wave waits for.  The next slab's anchor index is requested during tile 1 (one register);
+    // opacity and colour gradients at the top of the slab next to the anchor's own data; a covariance tile's five fields at the top
+    // of its iteration, in front of the MFMA chains; the rows the slab's results are added to with the last tile.  (Requesting the
+    // next slab's anchor data or a covariance tile's inputs a tile ahead needs 40 / 32 registers more than there are: the spills
+    // cost more than the round trips -- 0.24 -> 0.30-0.37 ms, profiles/r03_neural_bwd_pair_notes.txt.)
+    auto slab_lane = [&](uint32_t rd) { return (rd * gridDim.x + blockIdx.x) * 128u + (uint32_t)pair * 32u + (uint32_t)col; };
+    uint32_t a_nx = vis[min(slab_lane(0), n - 1u)];
+    for (uint32_t rd = 0; rd < rounds; rd++) {
+      const uint32_t t = slab_lane(rd);
+      const bool valid = t < n;   // a pair's last round may be empty: it runs on a copy of the last anchor and stores nothing
+      const uint32_t a = a_nx;
+      AnchorLane st;
+      anchor_lane<false>(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
+      const uint32_t c0 = a * NO + 5 * h;   // 32-bit element offsets (the entry points bound A): one SGPR base + one VGPR offset per access
+      float in_op[5], in_col[15];
+      ldn<5>(g_opacity + c0, in_op);
+      ldn<15>(g_colors + c0 * 3, in_col);
+      float in_sc[6], in_mu[6], in_off[6], in_rot[8], acc_off[6];   // the (up to) two candidates of the current covariance tile
+      float4* const dfo = reinterpret_cast<float4*>(d_feat + a * FD);
+      float4 acc_feat[4];
+      float acc_scl[6], acc_anc[3];
+      f32x16 dx;
+#pragma unroll
+      for (int r = 0; r < 16; r++) dx[r] = 0.f;
+      float dtail[4] = {0.f, 0.f, 0.f, 0.f};
+      uint32_t keep = 0;   // bit r: candidate 5h + r has neural opacity > 0 (the reference's mask, :279)
+      // scaling regulariser of the mapper loss, reg_weight * mean_P(prod(scaling)) (src/gaussian_mapper.cpp:926-928):
+      // every kept candidate adds reg_weight / P * prod / s_c to dL/dscaling_c
+      const float reg_w = reg_weight != 0.f ? reg_weight / (float)max(count[1], 1u) : 0.f;
+      float reg_acc = 0.f;
+      float dgs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, danc[3] = {0.f, 0.f, 0.f};
+      f32x16 hp, dh;
+      int job = 0;   // jobs handed to the wgrad wave in this slab: t0 f0 t1 f2 t2 t3 t4 f1
+#pragma unroll 1
+      for (int tile = 0; tile < N_TILES; tile++) {
+        const int m = tile_mlp(tile);
+        if (tile >= 2) {
+#pragma unroll
+          for (int cl = 0; cl < 2; cl++) {
+            const int cc = 2 * (tile - 2) + cl;
+            if (cc < 5 && ((keep >> cc) & 1u)) {   // masked-out candidates are never read
+              ldn<3>(g_scales + (c0 + cc) * 3, in_sc + 3 * cl);
+              ldn<3>(g_means + (c0 + cc) * 3, in_mu + 3 * cl);
+              ldn<3>(offset + (c0 + cc) * 3, in_off + 3 * cl);
+              ldn<4>(g_rot + (c0 + cc) * 4, in_rot + 4 * cl);
+              ldn<3>(d_offset + (c0 + cc) * 3, acc_off + 3 * cl);
+            }
+          }
+        }
+        if (tile == 1) a_nx = vis[min(slab_lane(rd + 1), n - 1u)];
+        if (tile == N_TILES - 1) {
+#pragma unroll
+          for (int g = 0; g < 4; g++) acc_feat[g] = dfo[2 * g + h];
+          ldn<6>(d_scaling_log + a * 6, acc_scl);
+          ldn<3>(d_anchor + a * 3, acc_anc);
+        }
+        if (tile <= 2) {
+          hp = layer1(img, S, m, lane, h, st.xo);
+#pragma unroll
+          for (int r = 0; r < 16; r++) dh[r] = 0.f;
+          f32x16 hr;
+#pragma unroll
+          for (int r = 0; r < 16; r++) hr[r] = fmaxf(hp[r], 0.f);
+          put_tile(bufH, col, h, hr);   // (the partner is in a first-layer job or idle: it reads D, X, T)
+        }
+        f32x16 o = layer2(img, S, tile, lane, h, hp);
+        // ---- element-wise: outputs -> dL/d(output pre-activation), in place (zero for the padding lanes of the last slab:
+        // they carry a copy of the last anchor and must not reach the weight gradients)
+        if (tile == 0) {
+          float d[5];
+#pragma unroll
+          for (int r = 0; r < 5; r++) {
+            const float op = fast_tanh(o[r]);
+            d[r] = 0.f;
+            if (op > 0.f) { keep |= 1u << r; d[r] = in_op[r] * (1.f - op * op); }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[r] = (r < 5 && valid) ? d[r < 5 ? r : 0] : 0.f;
+        } else if (tile == 1) {
+          float d[15];
+#pragma unroll
+          for (int r = 0; r < 15; r++) {
+            const float colv = sigmoidf(o[r]);
+            d[r] = ((keep >> (r / 3)) & 1u) ? in_col[r] * colv * (1.f - colv) : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[r] = (r < 15 && valid) ? d[r < 15 ? r : 0] : 0.f;
+        } else {
+#pragma unroll
+          for (int cl = 0; cl < 2; cl++) {
+            const int cc = 2 * (tile - 2) + cl;
+            const bool on = cc < 5 && ((keep >> cc) & 1u);
+            float dsr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float doff[3] = {0.f, 0.f, 0.f};
+            if (on) {
+              const float sr3 = o[7 * cl + 3], sr4 = o[7 * cl + 4], sr5 = o[7 * cl + 5], sr6 = o[7 * cl + 6];
+              float gsc[3] = {in_sc[3 * cl], in_sc[3 * cl + 1], in_sc[3 * cl + 2]};
+              const float gm[3] = {in_mu[3 * cl], in_mu[3 * cl + 1], in_mu[3 * cl + 2]};
+              const float off[3] = {in_off[3 * cl], in_off[3 * cl + 1], in_off[3 * cl + 2]};
+              float sg[3];
+#pragma unroll
+              for (int c = 0; c < 3; c++) sg[c] = sigmoidf(o[7 * cl + c]);
+              if (reg_w != 0.f) {
+                const float s0 = st.gs[3] * sg[0], s1 = st.gs[4] * sg[1], s2 = st.gs[5] * sg[2];
+                gsc[0] += reg_w * (s1 * s2); gsc[1] += reg_w * (s0 * s2); gsc[2] += reg_w * (s0 * s1);
+                reg_acc += s0 * s1 * s2;
+              }
+#pragma unroll
+              for (int c = 0; c < 3; c++) {
+                dgs[3 + c] += gsc[c] * sg[c];
+                dsr[c] = gsc[c] * st.gs[3 + c] * sg[c] * (1.f - sg[c]);
+                danc[c] += gm[c];
+                doff[c] = gm[c] * st.gs[c];
+                dgs[c] += gm[c] * off[c];
+              }
+              const float4 gr = make_float4(in_rot[4 * cl], in_rot[4 * cl + 1], in_rot[4 * cl + 2], in_rot[4 * cl + 3]);
+              const float nr = sqrtf(sr3 * sr3 + sr4 * sr4 + sr5 * sr5 + sr6 * sr6);
+              if (nr >= 1e-12f) {   // r = v / |v|:  dv = (g - r (r.g)) / |v|
+                const float inv = 1.0f / nr;
+                const float r0 = sr3 * inv, r1 = sr4 * inv, r2 = sr5 * inv, r3 = sr6 * inv;
+                const float dot = r0 * gr.x + r1 * gr.y + r2 * gr.z + r3 * gr.w;
+                dsr[3] = (gr.x - r0 * dot) * inv; dsr[4] = (gr.y - r1 * dot) * inv;
+                dsr[5] = (gr.z - r2 * dot) * inv; dsr[6] = (gr.w - r3 * dot) * inv;
+              } else {              // clamp_min(|v|, eps) active: r = v / eps
+                dsr[3] = gr.x * 1e12f; dsr[4] = gr.y * 1e12f; dsr[5] = gr.z * 1e12f; dsr[6] = gr.w * 1e12f;
+              }
+            }
+            if (valid && on) {   // masked-out candidates add nothing
+              const float cur[3] = {acc_off[3 * cl] + doff[0], acc_off[3 * cl + 1] + doff[1], acc_off[3 * cl + 2] + doff[2]};
+              stn<3>(d_offset + (c0 + cc) * 3, cur);
+            }
+#pragma unroll
+            for (int q = 0; q < 7; q++) o[7 * cl + q] = valid ? dsr[q] : 0.f;
+          }
+          o[14] = 0.f; o[15] = 0.f;
+        }
+        // ---- job "t": dOUT tile x H of the MLP, the partner's
+        put_tile((job & 1) ? bufD1 : bufD0, col, h, o);
+        __syncthreads();
+        job++;
+        if (tile == 0) {
+          // X tile: unit 16 h + s holds input 2 s + h (this half's 16 features in one contiguous run); tail as one float4 per
+          // anchor.  Written here: the partner has finished the previous slab's last job, which read them.
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+            *reinterpret_cast<float4*>(bufX + col * TS + 16 * h + 4 * g) = make_float4(st.xo[4 * g], st.xo[4 * g + 1], st.xo[4 * g + 2], st.xo[4 * g + 3]);
+          if (h == 0) *reinterpret_cast<float4*>(bufT + col * 4) = make_float4(st.view[0], st.view[1], st.view[2], st.dist);
+        }
+        // ---- dH += W2^T dOUT for this tile: step s contracts the tile rows held in register s of the two lane halves, and only
+        // registers 0..4 | 0..14 | 0..13 | 0..13 | 0..6 of the five tiles hold output units (out_row): 55 MFMAs instead of 80
+        {
+          const float* im = img + (I_DH + tile * 16) * 64 + lane;
+          const int steps = tile == 0 ? 5 : (tile == 1 ? 15 : (tile == 4 ? 7 : 14));
+#pragma unroll
+          for (int s = 0; s < 16; s++)
+            if (s < 5 || s < steps) dh = __builtin_amdgcn_mfma_f32_32x32x2f32(im[s * 64], o[s], dh, 0, 0, 0);
+        }
+        if (tile != 2 && tile != 3) {
+          // end of MLP m: relu mask, job "f" (dHpre x (features | tail)) for the partner, then dX on the matrix cores and the
+          // view/dist tail on the VALU
+#pragma unroll
+          for (int r = 0; r < 16; r++) dh[r] = hp[r] > 0.f ? dh[r] : 0.f;
+          put_tile((job & 1) ? bufD1 : bufD0, col, h, dh);
+          __syncthreads();
+          job++;
+          const float* im = img + (I_DX + m * 16) * 64 + lane;
+#pragma unroll
+          for (int s = 0; s < 16; s++) dx = __builtin_amdgcn_mfma_f32_32x32x2f32(im[s * 64], dh[s], dx, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const float4 w = *reinterpret_cast<const float4*>(S.w1tail[m][rho(r, h)]);
+            dtail[0] += w.x * dh[r]; dtail[1] += w.y * dh[r]; dtail[2] += w.z * dh[r]; dtail[3] += w.w * dh[r];
+          }
+        }
+      }
+      if (reg_sum != nullptr && reg_w != 0.f) {   // sum of prod(scaling) over the kept candidates, for the loss value
+        reg_acc = valid ? reg_acc : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) reg_acc += __shfl_xor(reg_acc, off, 64);
+        if (lane == 0 && reg_acc != 0.f) atomicAdd(reg_sum, reg_acc);
+      }
+      // ---- combine the lane halves
+#pragma unroll
+      for (int c = 0; c < 6; c++) dgs[c] += other_half(dgs[c]);
+#pragma unroll
+      for (int c = 0; c < 3; c++) danc[c] += other_half(danc[c]);
+#pragma unroll
+      for (int c = 0; c < 4; c++) dtail[c] += other_half(dtail[c]);
+      if (valid && h == 0) {
+        float v[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) v[c] = acc_scl[c] + dgs[c] * st.gs[c];   // through exp()
+        stn<6>(d_scaling_log + a * 6, v);
+      }
+      if (valid) {   // dL/dfeat: each half adds its own 16 features: float4 group 2g + h is rows rho(4g + q, h), this half's registers 4g + q
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          float4 v = acc_feat[g];
+          v.x += dx[4 * g]; v.y += dx[4 * g + 1]; v.z += dx[4 * g + 2]; v.w += dx[4 * g + 3];
+          dfo[2 * g + h] = v;
+        }
+      }
+      // view = ob / |ob|, dist = |ob|:  d ob = (dview - view (view . dview)) / dist + ddist * view
+      if (valid && h == 0) {
+        const float vx = st.view[0], vy = st.view[1], vz = st.view[2];
+        const float dot = vx * dtail[0] + vy * dtail[1] + vz * dtail[2];
+        const float v[3] = {acc_anc[0] + danc[0] + (dtail[0] - vx * dot) * st.inv_dist + dtail[3] * vx,
+                            acc_anc[1] + danc[1] + (dtail[1] - vy * dot) * st.inv_dist + dtail[3] * vy,
+                            acc_anc[2] + danc[2] + (dtail[2] - vz * dot) * st.inv_dist + dtail[3] * vz};
+        stn<3>(d_anchor + a * 3, v);
+      }
+    }
+    __syncthreads();   // every wave is done with the operand images and the tiles
+  } else {
+    // weight-gradient accumulators: second layers per output tile, first layers per MLP (feature columns)
+    f32x16 aW2_0, aW2_1, aW2_2, aW2_3, aW2_4, aW1_0, aW1_1, aW1_2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      aW2_0[r] = 0.f; aW2_1[r] = 0.f; aW2_2[r] = 0.f; aW2_3[r] = 0.f; aW2_4[r] = 0.f; aW1_0[r] = 0.f; aW1_1[r] = 0.f; aW1_2[r] = 0.f;
+    }
+    float sm[N_SMALL];    // [0..4] bias sums of the output tiles, [5..7] of the hidden layers, [8 + 4m + c] tail column c of MLP m
+#pragma unroll
+    for (int q = 0; q < N_SMALL; q++) sm[q] = 0.f;
+    for (uint32_t rd = 0; rd < rounds; rd++) {
+      __syncthreads(); wgrad_chain(bufD0, bufH, lane, aW2_0, sm[0]);                          // t0
+      __syncthreads(); wgrad_chain_tail(bufD1, bufX, bufT, lane, aW1_0, sm[5], &sm[8]);       // f0
+      __syncthreads(); wgrad_chain(bufD0, bufH, lane, aW2_1, sm[1]);                          // t1
+      __syncthreads(); wgrad_chain_tail(bufD1, bufX, bufT, lane, aW1_2, sm[7], &sm[16]);      // f2
+      __syncthreads(); wgrad_chain(bufD0, bufH, lane, aW2_2, sm[2]);                          // t2
+      __syncthreads(); wgrad_chain(bufD1, bufH, lane, aW2_3, sm[3]);                          // t3
+      __syncthreads(); wgrad_chain(bufD0, bufH, lane, aW2_4, sm[4]);                          // t4
+      __syncthreads(); wgrad_chain_tail(bufD1, bufX, bufT, lane, aW1_1, sm[6], &sm[12]);      // f1
+    }
+    __syncthreads();   // every wave is done with the operand images and the tiles
+    float* const mine = stage + pair * PAIR_STAGE;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      mine[0 * 1024 + r * 64 + lane] = aW2_0[r]; mine[1 * 1024 + r * 64 + lane] = aW2_1[r]; mine[2 * 1024 + r * 64 + lane] = aW2_2[r];
+      mine[3 * 1024 + r * 64 + lane] = aW2_3[r]; mine[4 * 1024 + r * 64 + lane] = aW2_4[r]; mine[5 * 1024 + r * 64 + lane] = aW1_0[r];
+      mine[6 * 1024 + r * 64 + lane] = aW1_1[r]; mine[7 * 1024 + r * 64 + lane] = aW1_2[r];
+    }
+#pragma unroll
+    for (int q = 0; q < N_SMALL; q++) mine[8 * 1024 + q * 64 + lane] = sm[q];
+  }
+  __syncthreads();
+  // ---- the workgroup's weight-gradient partials: the four wgrad waves' accumulators summed in a fixed order, written in
+  // wgrad_reduce_kernel's partial-tile layout, slot = workgroup
+  const int tid = threadIdx.x;
+  auto slot = [&](int job) { return partial + ((size_t)job * WG_WAVES + blockIdx.x) * WG_TILE; };
+  for (int e8 = tid; e8 < 8 * 1024; e8 += 512) {
+    const int k = e8 >> 10, e = e8 & 1023;
+    const float sum = (stage[e8] + stage[PAIR_STAGE + e8]) + (stage[2 * PAIR_STAGE + e8] + stage[3 * PAIR_STAGE + e8]);
+    const int r = e >> 6, l = e & 63, i = rho(r, l >> 5), j = l & 31;   // D[i][j]
+    if (k < 5) {            // second layer, tile k: i = tile row -> output unit, j = hidden unit (the Linear's input)
+      const int o = out_row(k, (i >> 2) & 1, (i & 3) + 4 * (i >> 3));
+      if (o >= 0) slot(3 + tile_mlp(k))[(((o >> 5)) * 32 + j) * 32 + (o & 31)] = sum;
+    } else {                // first layer of MLP k - 5: i = hidden unit, j = feature position 16 (input & 1) + (input >> 1)
+      const int input = 2 * (j & 15) + (j >> 4);
+      slot(k - 5)[(size_t)input * 32 + i] = sum;
+    }
+  }
+  for (int e = tid; e < N_SMALL * 32; e += 512) {
+    const int q = e >> 5, u = e & 31;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) sum += stage[w * PAIR_STAGE + 8 * 1024 + q * 64 + u] + stage[w * PAIR_STAGE + 8 * 1024 + q * 64 + 32 + u];   // both lane halves
+    if (q < 5) {              // bias of output tile q: u = tile row
+      const int o = out_row(q, (u >> 2) & 1, (u & 3) + 4 * (u >> 3));
+      if (o >= 0) slot(3 + tile_mlp(q))[((1 * 3 + (o >> 5)) * 32 + 31) * 32 + (o & 31)] = sum;
+    } else if (q < 8) {       // bias of the hidden layer of MLP q - 5: u = hidden unit
+      slot(q - 5)[((1 * 3 + 0) * 32 + 31) * 32 + u] = sum;
+    } else {                  // tail input 32 + c of MLP (q - 8) / 4
+      const int mm = (q - 8) >> 2, c = (q - 8) & 3;
+      slot(mm)[((1 * 3 + 0) * 32 + c) * 32 + u] = sum;
+    }
+  }
+}
+
 // ---- weight gradients ---------------------------------------------------------------------------------------------
 struct WJob {
   int a_off, M;       // activation field of the scratch row (the Linear's input), M columns
@@ -1190,21 +1524,32 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   Temp T;
   temp_carve(A, L.total, L.bank, temp, &T);
   constexpr size_t bwd_lds = (N_IMG_BWD * 64 + 4 * WAVE_LDS) * sizeof(float) + sizeof(Small);   // > 64 KB: needs the opt-in below
-  static_assert(bwd_lds <= 160 * 1024, "one workgroup per CU");
-  static const hipError_t attr_rc0 = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel<false>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
-  static const hipError_t attr_rc1 = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_bwd_kernel<true>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds);
-  if (attr_rc0 != hipSuccess) return segs::set_hip_error(attr_rc0, __func__);
-  if (attr_rc1 != hipSuccess) return segs::set_hip_error(attr_rc1, __func__);
+  constexpr size_t pair_run = (N_IMG_BWD * 64 + 4 * PAIR_LDS) * sizeof(float) + sizeof(Small), pair_end = (size_t)4 * PAIR_STAGE * sizeof(float);
+  constexpr size_t pair_lds = pair_run > pair_end ? pair_run : pair_end;
+  static_assert(bwd_lds <= 160 * 1024 && pair_lds <= 160 * 1024, "one workgroup per CU");
+  auto allow_lds = [](const void* kernel, size_t bytes) { return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
+  static const hipError_t attr_rc[3] = {allow_lds(reinterpret_cast<const void*>(neural_bwd_kernel<false>), bwd_lds),
+                                        allow_lds(reinterpret_cast<const void*>(neural_bwd_kernel<true>), bwd_lds),
+                                        allow_lds(reinterpret_cast<const void*>(neural_bwd_pair_kernel), pair_lds)};
+  for (const hipError_t rc_attr : attr_rc)
+    if (rc_attr != hipSuccess) return segs::set_hip_error(rc_attr, __func__);
   // the regulariser sum was cleared by the forward (pack_tables_kernel) and is cleared again by reg_finish_kernel; it is
   // only accumulated when somebody reads it
   float* reg_sum = scaling_reg_out ? T.gsum + L.total + 8 : nullptr;
-  // the feature bank's extra state (32 features kept for its mixing weights) costs registers the plain model does not need
-  (L.bank ? neural_bwd_kernel<true> : neural_bwd_kernel<false>)<<<BWD_GRID, 256, bwd_lds, st>>>(
-      L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small, camera_center, dL_dmeans3D,
-      dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor, dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, T.partial,
-      scaling_reg_weight, reg_sum);
+  // Plain model: chain waves + weight-gradient waves (neural_bwd_pair_kernel).  The feature bank's epilogue keeps the 32 features
+  // and works through the scratch rows: the one-kernel form.  SEGS_NEURAL_BWD_ONE_ROLE=1 runs the plain model through that form
+  // too (the A/B of profiles/).
+  static const bool one_role = [] { const char* e = getenv("SEGS_NEURAL_BWD_ONE_ROLE"); return e && e[0] == '1'; }();
+  if (!L.bank && !one_role)
+    neural_bwd_pair_kernel<<<BWD_GRID, 512, pair_lds, st>>>(
+        L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small, camera_center, dL_dmeans3D,
+        dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor, dL_doffset, dL_dfeat, dL_dscaling_log, T.partial,
+        scaling_reg_weight, reg_sum);
+  else
+    (L.bank ? neural_bwd_kernel<true> : neural_bwd_kernel<false>)<<<BWD_GRID, 256, bwd_lds, st>>>(
+        L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small, camera_center, dL_dmeans3D,
+        dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor, dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, T.partial,
+        scaling_reg_weight, reg_sum);
   if (scaling_reg_out && L.app == 0) reg_finish_kernel<<<1, 1, 0, st>>>(T.count, reg_sum, scaling_reg_weight, scaling_reg_out);
   const WJobs J = make_jobs(L);
   if (L.bank) wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), 64, 0, st>>>(J, T.count, T.rows, T.partial);   // the feature bank's two small Linears

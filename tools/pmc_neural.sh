@@ -1,11 +1,35 @@
 #!/bin/bash
-# One SQ counter pass over the config-5-sized anchor-level step (through gpurun): tools/pmc_neural.sh TAG
+# SQ counters of the neural-Gaussian kernels in the anchor-level step at config 5's size (run through gpurun from the repo root):
+#   tools/pmc_neural.sh TAG        -> gpurun_out/TAG_pmc_neural_{pair,one_role}.json
+# Each counter set is its own rocprofv3 pass (--kernel-trace --pmc only).
 set -eo pipefail
-TAG=${1:-rXX}
 export TMPDIR=/tmp
+TAG=${1:-rXX}
 OUT=gpurun_out
-rm -rf $OUT/${TAG}_pmcn
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/${TAG}_pmcn -o run -- python3 bench.py --mode scaffold --workload c2 --anchors 300000 --appearance-dim 16 --no-feat-bank --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmcn.log
-python3 tools/pmc_summary.py $OUT/${TAG}_pmc_neural.json $OUT/${TAG}_pmcn > $OUT/${TAG}_pmc_neural.md
-rm -rf $OUT/${TAG}_pmcn
-grep "neural" $OUT/${TAG}_pmc_neural.md
+mkdir -p $OUT
+CMD="bench.py --mode scaffold --workload c2 --anchors 300000 --appearance-dim 16 --no-feat-bank --steps 4 --warmup 1 --no-cpu-baseline --no-extras"
+SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+      "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES"
+      "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_IFETCH SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM"
+      "FETCH_SIZE" "WRITE_SIZE")
+for mode in pair one_role; do
+  if [ $mode = one_role ]; then export SEGS_NEURAL_BWD_ONE_ROLE=1; else unset SEGS_NEURAL_BWD_ONE_ROLE; fi
+  dirs=""
+  for i in "${!SETS[@]}"; do
+    d=$OUT/${TAG}_pmcn_${mode}_$i
+    rm -rf $d
+    rocprofv3 --kernel-trace --pmc ${SETS[$i]} --output-format csv -d $d -o run -- python3 $CMD > /dev/null 2> $OUT/${TAG}_pmcn_${mode}_$i.log || { echo "pass $i ($mode) failed"; tail -5 $OUT/${TAG}_pmcn_${mode}_$i.log; }
+    dirs="$dirs $d"
+    echo "pass $mode $i done"
+  done
+  python3 tools/pmc_summary.py $OUT/${TAG}_pmc_neural_${mode}.json $dirs > /dev/null
+  rm -rf $dirs
+done
+python3 - <<PY
+import json
+for mode in ("pair", "one_role"):
+    d = json.load(open("$OUT/${TAG}_pmc_neural_%s.json" % mode))
+    for k, e in d.items():
+        if "neural" in k:
+            print(mode, k, {c: round(v) for c, v in e.items()})
+PY
