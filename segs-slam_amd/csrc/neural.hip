@@ -435,33 +435,37 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
   const uint32_t n = *count;
   if (blockIdx.x * 128u >= n) return;
   if (threadIdx.x == 0) blk_kept = 0u;
-  stage_tables(img, S, N_IMG_FWD, g_img, g_small);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
   uint32_t kept_total = 0;
   // Software pipeline over the wave's slabs: the anchors (index, features, position, scaling, the five offsets of this lane
   // half) of slab k + 1 are requested before slab k is computed, so no slab waits for its own loads (each used to pay about
   // seven dependent round trips: index -> anchor data, then one per candidate for the offsets).
+  // The anchor INDEX runs two slabs ahead: the data request of slab k + 1 then starts from an index that arrived a slab ago, not
+  // from one it has to wait for (index -> data was one exposed round trip per slab, behind the previous slab's stores).
   const uint32_t stride = gridDim.x * 128u;
-  uint32_t a_nx;
+  auto index_of = [&](uint32_t g) { const uint32_t t = g + col; return vis[t < n ? t : n - 1]; };
   RawAnchor raw_nx;
   float off_nx[15];
-  auto request = [&](uint32_t g) {
-    const uint32_t t = g + col;
-    a_nx = vis[t < n ? t : n - 1];
-    load_raw(a_nx, anchor, anchor_feat, scaling_log, raw_nx);
-    ldn<15>(offset + (a_nx * NO + 5 * h) * 3, off_nx);
+  auto request = [&](uint32_t a_of) {
+    load_raw(a_of, anchor, anchor_feat, scaling_log, raw_nx);
+    ldn<15>(offset + (a_of * NO + 5 * h) * 3, off_nx);
   };
-  request((blockIdx.x * 4u + wv) * 32u);
-  for (uint32_t g0 = (blockIdx.x * 4u + wv) * 32u; g0 < n; g0 += stride) {
+  const uint32_t g_first = (blockIdx.x * 4u + wv) * 32u;
+  stage_tables(img, S, N_IMG_FWD, g_img, g_small);   // (requesting the first slab in front of this copy changed nothing measurable)
+  uint32_t a_cur = index_of(g_first), a_next = index_of(g_first + stride);
+  request(a_cur);
+  for (uint32_t g0 = g_first; g0 < n; g0 += stride) {
     const uint32_t t = g0 + col;
     const bool valid = t < n;
-    const uint32_t a = a_nx;
+    const uint32_t a = a_cur;
     const RawAnchor raw = raw_nx;
     float off_q[15];   // offsets of the candidates still to come, the next covariance tile's two in front
 #pragma unroll
     for (int q = 0; q < 15; q++) off_q[q] = off_nx[q];
-    if (g0 + stride < n) request(g0 + stride);
+    if (g0 + stride < n) request(a_next);
+    a_cur = a_next;
+    a_next = index_of(g0 + 2u * stride);
     AnchorLane st;
     if (L.bank) anchor_lane_raw<true>(S, h, raw, campos, st);
     else anchor_lane_raw<false>(S, h, raw, campos, st);
@@ -975,11 +979,12 @@ __global__ void __launch_bounds__(512, 1) neural_bwd_pair_kernel(
   Small& S = *reinterpret_cast<Small*>(lds_dyn + N_IMG_BWD * 64);
   const uint32_t n = *count;
   if (blockIdx.x * 128u >= n) return;
-  stage_tables(img, S, N_IMG_BWD, g_img, g_small);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int pair = wv & 3;
+  const int pair = wv & 3;          // waves w and w + 4 of a workgroup share SIMD w (measured: the even/odd pairing is 9 % slower)
   const bool chain_role = wv < 4;   // wave-uniform
   const int col = lane & 31, h = lane >> 5;
+  const uint32_t a_first = vis[min((blockIdx.x * 4u + (uint32_t)pair) * 32u + (uint32_t)col, n - 1u)];   // in flight under the copy of the tables
+  stage_tables(img, S, N_IMG_BWD, g_img, g_small);
   float* const bufX = lds_dyn + N_IMG_BWD * 64 + sizeof(Small) / 4 + pair * PAIR_LDS;
   float* const bufH = bufX + T_TILE;
   float* const bufD0 = bufH + T_TILE;
@@ -996,7 +1001,7 @@ __global__ void __launch_bounds__(512, 1) neural_bwd_pair_kernel(
     // next slab's anchor data or a covariance tile's inputs a tile ahead needs 40 / 32 registers more than there are: the spills
     // cost more than the round trips -- 0.24 -> 0.30-0.37 ms, profiles/r03_neural_bwd_pair_notes.txt.)
     auto slab_lane = [&](uint32_t rd) { return (rd * gridDim.x + blockIdx.x) * 128u + (uint32_t)pair * 32u + (uint32_t)col; };
-    uint32_t a_nx = vis[min(slab_lane(0), n - 1u)];
+    uint32_t a_nx = a_first;
     for (uint32_t rd = 0; rd < rounds; rd++) {
       const uint32_t t = slab_lane(rd);
       const bool valid = t < n;   // a pair's last round may be empty: it runs on a copy of the last anchor and stores nothing

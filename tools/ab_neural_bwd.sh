@@ -12,7 +12,7 @@ run() {
   (cd "$ROOT" && python - <<'PY'
 import json, torch, bench
 r = bench.mapper_step_block(torch.device("cuda:0"), steps=40, warmup=10)
-print("  ms/step", round(r["ms_per_step"], 4), "p50", r["step_ms"]["p50"], {k: v for k, v in r["phase_ms"].items() if "neural" in k})
+print("  ms/step", round(r["ms_per_step"], 4), "p50", round(r["step_ms"]["p50"], 4), {k: v for k, v in r["phase_ms"].items() if "neural" in k})
 PY
   )
 }
