@@ -230,8 +230,9 @@ def test_model_io_round_trip(tmp_path):
         model_io.load_model(p, str(tmp_path / "mlp"), ng.ModelDims(appearance_dim=16), dev)
 
 
-def test_second_slab_of_persistent_workgroups_is_consistent():
-    """A = 140 001 anchors exceed the forward's 1024 workgroups x 128 anchors (and the backward's 256), so the persistent
+@pytest.mark.parametrize("case", [0, 1])   # 0: feature bank (one-kernel backward), 1: plain model (chain + weight-gradient wave pairs)
+def test_second_slab_of_persistent_workgroups_is_consistent(case):
+    """A = 140 001 anchors exceed the forward's 512 workgroups x 128 anchors (and the backward's 256), so the persistent
     workgroups loop over further slabs.  Checked
     by consistency (no float64 reference at this size): the same anchors processed as two smaller models give bit-identical
     per-anchor outputs and gradients (the arithmetic of an anchor does not depend on the wave that carries it) and MLP weight
@@ -239,8 +240,8 @@ def test_second_slab_of_persistent_workgroups_is_consistent():
     from segs_slam_amd import neural_gaussians as ng
     dev = torch.device("cuda:0")
     A, A1 = 140001, 70000
-    rd = neural_ref.NeuralDims(**CASES[0])
-    md = ng.ModelDims(**CASES[0])
+    rd = neural_ref.NeuralDims(**CASES[case])
+    md = ng.ModelDims(**CASES[case])
     anchor, offset, feat, scaling_log, mlp = neural_ref.random_model(rd, A, 77)
     campos = torch.tensor([0.1, -0.2, -0.5], device=dev)
     pose7 = torch.tensor([0.3, -0.1, 0.2, 0.9, 0.1, -0.3, 0.2], device=dev)
@@ -266,6 +267,53 @@ def test_second_slab_of_persistent_workgroups_is_consistent():
         assert torch.equal(big.grad(name), torch.cat([s1.grad(name), s2.grad(name)], dim=0)), name
     ref = s1.mlp_grads + s2.mlp_grads
     assert float((big.mlp_grads - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+_ONE_ROLE_SCRIPT = """
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from oracle import neural_ref
+from segs_slam_amd import neural_gaussians as ng
+dev = torch.device("cuda:0")
+kw = {kw!r}
+rd, md = neural_ref.NeuralDims(**kw), ng.ModelDims(**kw)
+A = {A}
+anchor, offset, feat, scaling_log, mlp = neural_ref.random_model(rd, A, 91)
+m = ng.ScaffoldModel(A, md, dev)
+m.load(anchor, offset, feat, scaling_log, mlp)
+g = torch.Generator().manual_seed(5)
+radii = torch.where(torch.rand(A, generator=g) < 0.8, torch.tensor(3), torch.tensor(0)).to(torch.int32).to(dev)
+grads = [torch.randn(A * 10, n, generator=g).to(dev) for n in (3, 3, 1, 3, 4)]
+gen = ng.NeuralGaussians(m)
+gen.forward(torch.tensor([0.1, -0.2, -0.5], device=dev), torch.tensor([0.3, -0.1, 0.2, 0.9, 0.1, -0.3, 0.2], device=dev), radii)
+gen.backward(*grads, scaling_reg_weight=0.01)
+torch.cuda.synchronize()
+np.save({out!r}, m.grads.cpu().numpy())
+"""
+
+
+def test_wave_pair_backward_equals_the_one_kernel_backward(tmp_path):
+    """The plain model's backward runs as pairs of chain / weight-gradient waves (neural_bwd_pair_kernel); the one-kernel form
+    it replaced is still in the library behind SEGS_NEURAL_BWD_ONE_ROLE=1 (the switch is read once per process, hence the two
+    child processes).  The arithmetic of an anchor is the same in both: per-anchor gradients must be bit-identical."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for one_role in ("0", "1"):
+        out = str(tmp_path / f"grads_{one_role}.npy")
+        env = dict(os.environ, SEGS_NEURAL_BWD_ONE_ROLE=one_role)
+        subprocess.run([sys.executable, "-c", _ONE_ROLE_SCRIPT.format(root=root, kw=CASES[1], A=40001, out=out)], check=True, env=env,
+                       timeout=300)
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    n_anchor = 40001 * (3 + 30 + 32 + 6)   # the four per-anchor segments of the bucket; the MLP block follows
+    assert np.array_equal(outs[0][:n_anchor], outs[1][:n_anchor])
+    # the visible-anchor list is compacted with one atomic per 2048 anchors, so its block order -- and with it the order in which
+    # the MLP weight gradients are summed -- differs from run to run: same bound as the split-model test above
+    a, b = outs[0][n_anchor:], outs[1][n_anchor:]
+    assert np.abs(a).max() > 0 and np.abs(a - b).max() <= 1e-5 * np.abs(a).max()
 
 
 def test_scaffold_step_alternates_pyramid_levels_on_one_step_object():
