@@ -236,6 +236,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
   load_rows3(means3D, scales, colors, P, lds, p, sc, col);
 
   uint32_t touched = 0, dbits_mine = 0;
+  float4 rq0 = make_float4(0, 0, 0, 0), rq1 = rq0, rq2 = rq0, rq3 = rq0;   // this Gaussian's record, stored below
+  bool has_record = false;
   if (idx < P) {
     Projected g = project_gaussian(p, sc, mod, rot, cov3D_precomp ? cov3D_precomp + (size_t)6 * idx : nullptr,
                                    viewmatrix, projmatrix, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy);
@@ -273,12 +275,12 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
         col = sh::to_rgb(idx, D, M, p, cam_pos, shs, &cb);
         clamped[idx] = cb;
       }
-      float4* r4 = reinterpret_cast<float4*>(rec + (size_t)idx * REC_DWORDS);
       // A2/B2/C2: conic pre-scaled so the tile kernels evaluate alpha = o * exp2(A2 dx^2 + B2 dx dy + C2 dy^2)
-      r4[0] = make_float4(g.px, g.py, (-0.5f * LOG2E) * g.conic.x, (-LOG2E) * g.conic.y);
-      r4[1] = make_float4((-0.5f * LOG2E) * g.conic.z, op, col.x, col.y);
-      r4[2] = make_float4(col.z, g.depth, __uint_as_float(b.rect_min), __uint_as_float(b.rect_max));   // [10..11]: the emitter's rectangle
-      r4[3] = make_float4(g.conic.x, g.conic.y, g.conic.z, 0.f);
+      rq0 = make_float4(g.px, g.py, (-0.5f * LOG2E) * g.conic.x, (-LOG2E) * g.conic.y);
+      rq1 = make_float4((-0.5f * LOG2E) * g.conic.z, op, col.x, col.y);
+      rq2 = make_float4(col.z, g.depth, __uint_as_float(b.rect_min), __uint_as_float(b.rect_max));   // [10..11]: the emitter's rectangle
+      rq3 = make_float4(g.conic.x, g.conic.y, g.conic.z, 0.f);
+      has_record = true;
     }
     radii[idx] = g.radius;
     // BinInfo feeds make_depth_keys_kernel and the parity-test unpackers of the reference-shaped path; the resident path
@@ -293,6 +295,31 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(
       depth_keys[idx] = b.tiles_touched ? b.depth_bits : 0xFFFFFFFFu;
       (void)depth_vals;   // the sort's first pass takes the index itself as the value (no iota array)
       if (depth_overflow && b.tiles_touched && (b.depth_bits - DEPTH_KEY_MIN) >= ((1u << DEPTH_KEY_BITS) - 1u)) *depth_overflow = 1u;
+    }
+  }
+  // The records leave through a per-wave LDS transpose: a lane storing its own 64 bytes as four float4 makes every store
+  // instruction touch 64 different lines, a quarter of each; transposed, an instruction writes sixteen whole records (1 KB
+  // contiguous), 32 records of the wave at a time in the (by now free) staging buffer of the input sweeps.
+  {
+    const int lane = threadIdx.x & 63;
+    float* const wl = lds + (threadIdx.x >> 6) * 576;   // 32 records x 16 dwords of this wave (576 = 2304 / 4)
+    const uint64_t recs = __ballot(has_record);
+    const size_t wave_first = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if ((lane >> 5) == half) {
+        float4* mine = reinterpret_cast<float4*>(wl + (lane & 31) * REC_DWORDS);
+        mine[0] = rq0; mine[1] = rq1; mine[2] = rq2; mine[3] = rq3;
+      }
+      asm volatile("" ::: "memory");   // (a wave's LDS instructions complete in order)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int r = 16 * j + (lane >> 2);        // record of this half the lane carries a quarter of
+        const int owner = 32 * half + r;
+        if ((recs >> owner) & 1ull)
+          reinterpret_cast<float4*>(rec + (wave_first + owner) * REC_DWORDS)[lane & 3] = reinterpret_cast<const float4*>(wl + r * REC_DWORDS)[lane & 3];
+      }
+      asm volatile("" ::: "memory");
     }
   }
   if (ranges)
