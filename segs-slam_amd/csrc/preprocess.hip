@@ -445,14 +445,38 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(
     //   dL/dmean2D.x = -(A Mx + B My) W/2,  .y = -(C My + B Mx) H/2,  dL/dconic = -(Mxx, Mxy, Myy)/2
     // with (A, B, C) the conic, formed below from this kernel's own 2D covariance (round 2 gathered it -- and the opacity, which
     // the tile kernel now divides out itself -- from the 32-byte emit record: 9 % of this kernel's traffic).
-    if (binned) {
-      float4* row = reinterpret_cast<float4*>(gacc + (size_t)idx * GACC_DWORDS);
-      a0 = row[0]; a1 = row[1];
-      dcol2 = gacc[(size_t)idx * GACC_DWORDS + 8];
-      if (clean_gacc) {   // only binned Gaussians' rows can have been touched by the tile kernel
-        row[0] = make_float4(0.f, 0.f, 0.f, 0.f); row[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        gacc[(size_t)idx * GACC_DWORDS + 8] = 0.f;
+    // The rows arrive (and are cleared) through a per-wave LDS transpose, like K1's records: a lane reading its own row as
+    // two float4 and a dword makes each load touch 64 lines; transposed, an instruction moves sixteen whole rows.
+    {
+      __shared__ __attribute__((aligned(16))) float gl[4][32 * GACC_DWORDS];
+      const int lane = threadIdx.x & 63;
+      float* const wl = gl[threadIdx.x >> 6];
+      const uint64_t rows = __ballot(binned);   // only binned Gaussians' rows can have been touched by the tile kernel
+      const size_t wave_first = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63);
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        float4 q[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int r = 16 * j + (lane >> 2), owner = 32 * half + r;
+          q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (((rows >> owner) & 1ull) && (lane & 3) < 3) {
+            float4* src = reinterpret_cast<float4*>(gacc + (wave_first + owner) * GACC_DWORDS) + (lane & 3);
+            q[j] = *src;
+            if (clean_gacc) *src = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) reinterpret_cast<float4*>(wl + (16 * j + (lane >> 2)) * GACC_DWORDS)[lane & 3] = q[j];
+        asm volatile("" ::: "memory");   // (a wave's LDS instructions complete in order)
+        if ((lane >> 5) == half) {
+          const float4* mine = reinterpret_cast<const float4*>(wl + (lane & 31) * GACC_DWORDS);
+          a0 = mine[0]; a1 = mine[1]; dcol2 = wl[(lane & 31) * GACC_DWORDS + 8];
+        }
+        asm volatile("" ::: "memory");
       }
+    }
+    if (binned) {
       G.xx = -0.5f * a0.z; G.xy = -0.5f * a0.w; G.yy = -0.5f * a1.x;
       dop = a1.y;
       dcol0 = a1.z; dcol1 = a1.w;
