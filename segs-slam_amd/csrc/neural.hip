@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 #include <cstdlib>
 #include "../../include/segs_neural.h"
 #include "../../include/segs_raster.h"
@@ -376,7 +377,20 @@ __device__ __forceinline__ f32x16 layer2(const float* __restrict__ img, const Sm
   return d;
 }
 
-constexpr int NEURAL_GRID = 512;   // persistent forward workgroups (2 per CU; 4 per CU was slower: 112 -> 141 us at 300 k anchors), each loops over 128-anchor slabs
+// Persistent forward workgroups: one of eight waves per CU (two waves per SIMD; four per SIMD was slower: 112 -> 141 us at 300 k
+// anchors), each wave loops over 32-anchor slabs.  Eight waves share one copy of the tables and leave room for a 12.6-KB output
+// staging area per wave (below).
+constexpr int NEURAL_GRID = 256;
+constexpr int FWD_WAVES = 8;
+// Output staging of one wave: the outputs of a slab -- 32 anchors x (rotations 40 | scales 30 | means 30) floats, or x 10
+// opacities, or x 30 colour values -- go to LDS in the layout of the output arrays and leave as contiguous runs: lanes write
+// consecutive 8- or 16-byte elements of consecutive anchors' runs, so a store instruction covers whole lines.  Stored straight from
+// the registers (12-16 bytes per lane, 60-120 bytes apart) every store instruction touched 64 lines, and the 24 of them per slab
+// were what the kernel waited for: 97 us at 300 k anchors, 60 us with the stores compiled out.
+constexpr int STG_ROW = 100;                       // floats per anchor of the covariance phase: rotations 0..39 | scales 40..69 | means 70..99
+constexpr int STG_WAVE = 32 * STG_ROW + 32;        // + the slab's anchor indices
+constexpr size_t FWD_LDS = (N_IMG_FWD * 64 + FWD_WAVES * STG_WAVE) * sizeof(float) + sizeof(Small);
+static_assert(FWD_LDS <= 160 * 1024, "one forward workgroup per CU");
 
 // 2048 anchors per workgroup (eight rounds of 256) and ONE returning atomic on the list's count per workgroup: the count is a
 // single word, which takes about 12 ns per returning atomic whatever the parallelism -- with one per 256 anchors this kernel
@@ -422,7 +436,7 @@ __global__ void __launch_bounds__(256) compact_visible_kernel(int A, const int* 
   }
 }
 
-__global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
+__global__ void __launch_bounds__(FWD_WAVES * 64, 1) neural_fwd_kernel(
     Layout L, const uint32_t* __restrict__ count, const uint32_t* __restrict__ vis, const float* __restrict__ anchor,
     const float* __restrict__ offset, const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
     const float* __restrict__ g_img, const Small* __restrict__ g_small, const float* __restrict__ campos,
@@ -433,7 +447,7 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
   Small& S = *reinterpret_cast<Small*>(lds_dyn + N_IMG_FWD * 64);
   __shared__ uint32_t blk_kept;
   const uint32_t n = *count;
-  if (blockIdx.x * 128u >= n) return;
+  if (blockIdx.x * (FWD_WAVES * 32u) >= n) return;
   if (threadIdx.x == 0) blk_kept = 0u;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
@@ -443,7 +457,9 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
   // seven dependent round trips: index -> anchor data, then one per candidate for the offsets).
   // The anchor INDEX runs two slabs ahead: the data request of slab k + 1 then starts from an index that arrived a slab ago, not
   // from one it has to wait for (index -> data was one exposed round trip per slab, behind the previous slab's stores).
-  const uint32_t stride = gridDim.x * 128u;
+  const uint32_t stride = gridDim.x * (FWD_WAVES * 32u);
+  float* const stg = lds_dyn + N_IMG_FWD * 64 + sizeof(Small) / 4 + wv * STG_WAVE;
+  uint32_t* const stg_a = reinterpret_cast<uint32_t*>(stg + 32 * STG_ROW);
   auto index_of = [&](uint32_t g) { const uint32_t t = g + col; return vis[t < n ? t : n - 1]; };
   RawAnchor raw_nx;
   float off_nx[15];
@@ -451,7 +467,7 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
     load_raw(a_of, anchor, anchor_feat, scaling_log, raw_nx);
     ldn<15>(offset + (a_of * NO + 5 * h) * 3, off_nx);
   };
-  const uint32_t g_first = (blockIdx.x * 4u + wv) * 32u;
+  const uint32_t g_first = (blockIdx.x * (uint32_t)FWD_WAVES + wv) * 32u;
   stage_tables(img, S, N_IMG_FWD, g_img, g_small);   // (requesting the first slab in front of this copy changed nothing measurable)
   uint32_t a_cur = index_of(g_first), a_next = index_of(g_first + stride);
   request(a_cur);
@@ -469,45 +485,89 @@ __global__ void __launch_bounds__(256, 2) neural_fwd_kernel(
     AnchorLane st;
     if (L.bank) anchor_lane_raw<true>(S, h, raw, campos, st);
     else anchor_lane_raw<false>(S, h, raw, campos, st);
-    const uint32_t c0 = a * NO + 5 * h;     // first candidate of this lane half (32-bit element offsets: the entry points bound A)
     f32x16 hp;
     uint32_t kept = 0;   // candidates of this lane with neural opacity > 0: P of the reference's compacted tensors
+    const uint32_t nv = min(32u, n - g0);   // anchors of this slab (wave-uniform): slots nv .. 31 are copies of the last anchor and store nothing
+    if (h == 0) stg_a[col] = a;
+    // runs of RUN elements (float2, or float4 for the rotations) per anchor, staged at stg + slot * ROW + OFF, to dst + anchor * RUN
+    // (all of a field's LDS reads are issued before its first store: a rolled loop pays an LDS round trip per iteration)
+    auto flush2 = [&](float* __restrict__ dst, int row, int off, auto run_c /* float2 per anchor */) {
+      constexpr uint32_t run = decltype(run_c)::value, ITER = (32u * run + 63u) / 64u;
+      float2 v[ITER];
+      uint32_t at[ITER];
+#pragma unroll
+      for (uint32_t i = 0; i < ITER; i++) {
+        const uint32_t e = lane + 64u * i, s = min(e / run, 31u), k = e - (e / run) * run;
+        v[i] = *reinterpret_cast<const float2*>(stg + s * row + off + 2 * k);
+        at[i] = stg_a[s] * run + k;
+      }
+#pragma unroll
+      for (uint32_t i = 0; i < ITER; i++)
+        if (lane + 64u * i < nv * run) reinterpret_cast<float2*>(dst)[at[i]] = v[i];
+    };
+    using R5 = std::integral_constant<uint32_t, 5u>;
+    using R15 = std::integral_constant<uint32_t, 15u>;
 #pragma unroll 1
     for (int tile = 0; tile < N_TILES; tile++) {
       if (tile <= 2) hp = layer1(img, S, tile_mlp(tile), lane, h, st.xo);
       const f32x16 o = layer2(img, S, tile, lane, h, hp);
-      if (!valid) continue;
       if (tile == 0) {
-        float op[5];
+        if (valid) {
 #pragma unroll
-        for (int r = 0; r < 5; r++) { op[r] = fast_tanh(o[r]); kept += op[r] > 0.f ? 1u : 0u; }
-        stn<5>(neural_opacity + c0, op);
-        stn<5>(opacity + c0, op);
+          for (int r = 0; r < 5; r++) { const float op = fast_tanh(o[r]); kept += op > 0.f ? 1u : 0u; stg[col * 10 + 5 * h + r] = op; }
+        }
+        asm volatile("" ::: "memory");   // (a wave's LDS instructions complete in order)
+        flush2(neural_opacity, 10, 0, R5());
+        flush2(opacity, 10, 0, R5());
+        asm volatile("" ::: "memory");
       } else if (tile == 1) {
-        float cv[15];
+        if (valid) {
 #pragma unroll
-        for (int r = 0; r < 15; r++) cv[r] = sigmoidf(o[r]);
-        stn<15>(colors + c0 * 3, cv);
+          for (int r = 0; r < 15; r++) stg[col * 30 + 15 * h + r] = sigmoidf(o[r]);
+        }
+        asm volatile("" ::: "memory");
+        flush2(colors, 30, 0, R15());
+        asm volatile("" ::: "memory");
       } else {
+        if (valid) {
 #pragma unroll
-        for (int cl = 0; cl < 2; cl++) {
-          const int cc = 2 * (tile - 2) + cl;
-          if (cc < 5) {
-            const float q0 = o[7 * cl + 3], q1 = o[7 * cl + 4], q2 = o[7 * cl + 5], q3 = o[7 * cl + 6];
-            float sc[3], mu[3];
+          for (int cl = 0; cl < 2; cl++) {
+            const int cc = 2 * (tile - 2) + cl;
+            if (cc < 5) {
+              const float q0 = o[7 * cl + 3], q1 = o[7 * cl + 4], q2 = o[7 * cl + 5], q3 = o[7 * cl + 6];
+              float* const row = stg + col * STG_ROW;
+              const int k = 5 * h + cc;   // candidate
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-              sc[c] = st.gs[3 + c] * sigmoidf(o[7 * cl + c]);   // :327-328
-              mu[c] = st.anc[c] + off_q[3 * cl + c] * st.gs[c];  // :331-332
+              for (int c = 0; c < 3; c++) {
+                row[40 + 3 * k + c] = st.gs[3 + c] * sigmoidf(o[7 * cl + c]);   // :327-328
+                row[70 + 3 * k + c] = st.anc[c] + off_q[3 * cl + c] * st.gs[c];  // :331-332
+              }
+              const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);  // F::normalize
+              *reinterpret_cast<float4*>(row + 4 * k) = make_float4(q0 / nrm, q1 / nrm, q2 / nrm, q3 / nrm);
             }
-            stn<3>(scales + (c0 + cc) * 3, sc);
-            const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);  // F::normalize
-            reinterpret_cast<float4*>(rotations)[c0 + cc] = make_float4(q0 / nrm, q1 / nrm, q2 / nrm, q3 / nrm);
-            stn<3>(means3D + (c0 + cc) * 3, mu);
           }
         }
 #pragma unroll
         for (int q = 0; q < 9; q++) off_q[q] = off_q[q + 6];   // the tile loop is rolled: register arrays take no runtime index
+        if (tile == N_TILES - 1) {
+          asm volatile("" ::: "memory");
+          {   // rotations: ten float4 per anchor
+            float4 v[5];
+            uint32_t at[5];
+#pragma unroll
+            for (uint32_t i = 0; i < 5; i++) {
+              const uint32_t e = lane + 64u * i, s = e / 10u, k = e - s * 10u;
+              v[i] = *reinterpret_cast<const float4*>(stg + s * STG_ROW + 4 * k);
+              at[i] = stg_a[s] * 10u + k;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 5; i++)
+              if (lane + 64u * i < nv * 10u) reinterpret_cast<float4*>(rotations)[at[i]] = v[i];
+          }
+          flush2(scales, STG_ROW, 40, R15());
+          flush2(means3D, STG_ROW, 70, R15());
+          asm volatile("" ::: "memory");
+        }
       }
     }
     kept_total += valid ? kept : 0u;
@@ -1503,7 +1563,9 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
   pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small, T.count, T.gsum + L.total + 8);
   const int nb = (A + 256 * CV_ROUNDS - 1) / (256 * CV_ROUNDS);
   compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity);
-  neural_fwd_kernel<<<NEURAL_GRID, 256, N_IMG_FWD * 64 * sizeof(float) + sizeof(Small), st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
+  static const hipError_t fwd_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS);
+  if (fwd_attr != hipSuccess) return segs::set_hip_error(fwd_attr, __func__);
+  neural_fwd_kernel<<<NEURAL_GRID, FWD_WAVES * 64, FWD_LDS, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
                                         camera_center, means3D, colors, opacity, scales, rotations, neural_opacity, T.count + 1);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
