@@ -351,7 +351,8 @@ def main():
                                     "step ends; the line's ms_per_step is the host clock over all K steps)"}
         if world == 1 and args.mode == "raster" and not args.no_extras:
             extras = [("render_only_ms", lambda: render_only(eng, (bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy))),
-                      ("mapper_step", lambda: mapper_step_block(dev)), ("config3", lambda: config3_block(dev))]
+                      ("mapper_step", lambda: mapper_step_block(dev)), ("replica_step", lambda: replica_step_block(dev)),
+                      ("config3", lambda: config3_block(dev))]
             for key, fn in extras:
                 try:
                     out[key] = fn()
@@ -436,6 +437,57 @@ def mapper_step_block(dev, steps: int = 50, warmup: int = 10):
             "phase_ms": {k: round(v, 4) for k, v in phases.items()},
             "render_only_ms": _percentiles([rev[i].elapsed_time(rev[i + 1]) for i in range(20)]),
             "dropped_steps": tstep.dropped_steps()}
+
+
+def replica_step_block(dev, anchors: int = 50_000, steps: int = 50, warmup: int = 10, iteration: int = 10_000,
+                       variants=(("fused", True), ("autograd_mirror", False))):
+    """The Replica mapper iteration with its frequency regulariser ON, untimed-region block: the step
+    cfg/gaussian_mapper/RGB-D/Replica/office0.yaml describes (mapper_config.make_mapper_step: feature bank, appearance_dim 32,
+    scaling regulariser, row mask, multi_scale_loss over 3 scales with lambda 0.01 between iterations 5 000 and 25 500,
+    densification statistics every iteration) at an iteration inside that window, 1200x680, `anchors` x 10 offsets (BASELINE
+    config 2's ~500 k Gaussians).  Timed twice: with the fused frequency path (csrc/freq_loss.hip + cached |FFT(gt)| + one
+    rfft2 / irfft2 per scale) and with the torch.fft + autograd mirror of the reference's op chain it replaces."""
+    import numpy as np
+    import torch
+    from segs_slam_amd import mapper_config as mc, neural_gaussians as ng, scenes
+    cfg = mc.load_committed_config("cfg/gaussian_mapper/RGB-D/Replica/office0.yaml")
+    cam = scenes.make_config_camera("c2")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    gt = torch.rand(3, cam.height, cam.width, device=dev)
+    out = {"workload": f"Replica office0 mapper step (cfg values of cfg/gaussian_mapper/RGB-D/Replica/office0.yaml), iteration {iteration}+: "
+                       f"{anchors} anchors x 10 offsets, {cam.width}x{cam.height}, feature bank on, appearance_dim {cfg.model.appearance_dim}, "
+                       f"multi_scale_loss scales {list(cfg.scales)} lambda {cfg.lambda_frequency_high}, training_statis every iteration",
+           "steps": steps, "warmup": warmup}
+    for label, fused in variants:
+        model = ng.synthetic_model(anchors, cfg.model, cam, dev, seed=0)
+        tstep = mc.make_mapper_step(cfg, model, cam.width, cam.height)
+        assert tstep.freq_reg is not None
+        tstep.freq_reg["fused"] = fused
+        tstep.keyframe_for = lambda step, n: 0
+        # between two adjust_anchor iterations of the cfg's schedule (every 100 from 1 500): the timed steps hold none
+        tstep.iteration = iteration
+        assert (iteration + warmup + steps + 20) // cfg.densify.update_interval == iteration // cfg.densify.update_interval
+        for _ in range(warmup):
+            tstep.training_once([kf], [gt])
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(steps):
+            tstep.training_once([kf], [gt])
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        low_on, high_on = tstep._freq_active()
+        phases = tstep.profile_phases(kf, gt, 20)
+        tstep.engine.check()
+        out[label] = {"iters_per_s": steps / wall, "ms_per_step": wall / steps * 1e3,
+                      "step_ms": _percentiles([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]),
+                      "phase_ms": {k: round(v, 4) for k, v in phases.items()}, "frequency_terms_on": {"low": low_on, "high": high_on},
+                      "dropped_steps": tstep.dropped_steps(), "instances_binned": tstep.engine.R}
+    return out
 
 
 def config3_block(dev, max_iters: int = 3000, target_anchors: int = 200_000, steady_iters: int = 200):

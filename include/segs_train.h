@@ -63,6 +63,59 @@ size_t segs_l1_ssim_temp_bytes(int H, int W);
 int segs_l1_ssim_loss(const float* img1, const float* img2, int H, int W, float lambda_dssim, float* loss_out,
                       float* dL_dimg1, char* temp, void* stream);
 
+/* ---- Frequency regulariser of the mapper loss (src/gaussian_mapper.cpp:930-945) ----------------------------------------
+ * loss_utils::multi_scale_loss / high_frequency_loss (include/loss_utils.h:126-165, 216-237):
+ *     freq = lambda_high * sum_s  s * mean( | |fft2(resize_s(image))| - |fft2(resize_s(gt))| | ),   s = 1, 1/2, 1/4
+ * (without Mapper.use_multi_resolution: the s = 1 term alone).  resize_s is torch's bilinear interpolate with
+ * align_corners = false and recompute_scale_factor = true, i.e. to floor(size * s) with scale = in / out.  The reference's
+ * frequency mask is a no-op for real image sizes and low_freq_loss has a zero gradient (pinned by
+ * tests/golden/loss_reference.npz), so this is the whole regulariser.
+ *
+ * The FFTs stay library calls of the caller (hipFFT through torch.fft / torch::fft, like the reference); these entry points
+ * are everything around them, one launch each for all scales ("levels"; at most SEGS_FREQ_MAX_LEVELS):
+ *   1. segs_freq_pyramid           image (C,H,W) -> level_out[l] (C,h_l,w_l) for every level smaller than the image (a level
+ *                                  of the image's own size is the image: its buffer is not written and may be NULL);
+ *   2. caller: spectrum[l] = rfft2(level l)  -- (C, h_l, w_l/2+1) interleaved complex64, unnormalised;
+ *   3. segs_freq_spectrum_loss     *freq_loss_out = sum_l level_weight[l] * sum_k m_k | |G_k| - target_magnitude[l][k] |
+ *                                  (m_k = 2 for the columns that stand for their mirror image too, else 1), added to
+ *                                  *loss_inout if non-NULL; spectrum[l] <- level_weight[l] * sign(|G|-|T|) * G/|G| in place.
+ *                                  level_weight[l] = lambda_high * s_l / (C h_l w_l);
+ *   4. caller: level_grad[l] = irfft2(spectrum[l], size (h_l,w_l)) WITHOUT the 1/(h w) normalisation (norm = "forward");
+ *   5. segs_freq_pyramid_backward_add   dL_dimage += sum_l resize_l^T(level_grad[l])   (plain add for a full-size level).
+ * target_magnitude[l] = |rfft2(resize_l(gt))| is constant per keyframe: segs_freq_pyramid + rfft2 + segs_spectrum_magnitude
+ * once, then cached by the host.  temp: segs_freq_temp_bytes(...) bytes. */
+#define SEGS_FREQ_MAX_LEVELS 4
+int segs_freq_pyramid(const float* image, int C, int H, int W, int nlevels, const int* level_h, const int* level_w,
+                      float* const* level_out, void* stream);
+int segs_spectrum_magnitude(const float* spectrum, size_t n_complex, float* magnitude, void* stream);
+size_t segs_freq_temp_bytes(int C, int nlevels, const int* level_h, const int* level_w);
+int segs_freq_spectrum_loss(int C, int nlevels, const int* level_h, const int* level_w, float* const* spectrum,
+                            const float* const* target_magnitude, const float* level_weight, float* freq_loss_out,
+                            float* loss_inout, char* temp, void* stream);
+int segs_freq_pyramid_backward_add(float* dL_dimage, int C, int H, int W, int nlevels, const int* level_h, const int* level_w,
+                                   const float* const* level_grad, void* stream);
+
+/* The whole regulariser in one call, transforms included ("plan": one per image size; owns its hipFFT plans and scratch).
+ * hipFFT is bound at run time by soname (the copy the process already carries, e.g. PyTorch-ROCm's, else the system one);
+ * SEGS_ERR_UNSUPPORTED if there is none.  scales: Mapper.scale_num values 1 / 2^i (src/gaussian_mapper.cpp:514-517), or {1}
+ * for high_frequency_loss alone.  When H and W are multiples of 4 and the scales are {1, 1/2, 1/4} the plan evaluates all
+ * three scales from ONE forward and ONE inverse full-size transform (alias folding, csrc/freq_loss.hip); otherwise one pair
+ * per scale as in steps 1-5 above.
+ *   segs_freq_target   target_out[segs_freq_target_floats(plan)] = |FFT| tables of a target image (once per keyframe)
+ *   segs_freq_loss     *freq_loss_out = the regulariser's value (also added to *loss_inout if non-NULL);
+ *                      dL_inout (3,H,W) += its gradient w.r.t. image.  Nothing waits for the device. */
+typedef struct segs_freq_plan segs_freq_plan;
+int segs_freq_plan_create(int H, int W, int nscales, const float* scales, float lambda_high, segs_freq_plan** out);
+void segs_freq_plan_destroy(segs_freq_plan* plan);
+int segs_freq_plan_levels(const segs_freq_plan* plan, int* level_h, int* level_w, int* folded);   /* returns the level count */
+size_t segs_freq_target_floats(const segs_freq_plan* plan);
+int segs_freq_target(segs_freq_plan* plan, const float* gt, float* target_out, void* stream);
+int segs_freq_loss(segs_freq_plan* plan, const float* image, const float* target, float* dL_inout, float* freq_loss_out,
+                   float* loss_inout, void* stream);
+/* tests: the coefficient spectra a segs_freq_loss call hands to its inverse transforms (level 0 of a folded plan holds all
+ * scales).  First call (out may be NULL): switch the plan to keeping copies; later calls: out[(3, h_l, w_l/2+1) complex64]. */
+int segs_freq_debug_coefficients(segs_freq_plan* plan, int level, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,3 +57,36 @@ extern "C" int ref_freq_losses(const float* img1, const float* img2, int H, int 
     return 1;
   }
 }
+
+// multi_scale_loss (include/loss_utils.h:216-237) piece by piece.  The function itself cannot run here -- it calls
+// high_frequency_loss with its default device, kCUDA (:234) -- so this driver issues the same two interpolate calls per scale
+// (:225-232: bilinear, align_corners = false, recompute_scale_factor = true) and hands their results to the REFERENCE's
+// high_frequency_loss with torch::kCPU, summing scale * loss like :234.  out[0] = the sum, out[1 + i] = the i-th scale's
+// high_frequency_loss; dL = autograd gradient of the sum w.r.t. gen_img.
+extern "C" int ref_multi_scale_loss(const float* gen, const float* target, int H, int W, const float* scales, int nscales,
+                                    float* out, float* dL) {
+  try {
+    namespace F = torch::nn::functional;
+    auto opts = torch::TensorOptions().dtype(torch::kFloat32);
+    torch::Tensor a = torch::from_blob(const_cast<float*>(gen), {3, H, W}, opts).clone().requires_grad_(true);
+    torch::Tensor b = torch::from_blob(const_cast<float*>(target), {3, H, W}, opts).clone();
+    torch::Tensor loss = torch::zeros({});
+    for (int i = 0; i < nscales; i++) {
+      const float scale = scales[i];
+      std::vector<double> sf = {static_cast<double>(scale), static_cast<double>(scale)};
+      auto io = F::InterpolateFuncOptions().scale_factor(sf).mode(torch::kBilinear).align_corners(false).recompute_scale_factor(true);
+      auto ga = F::interpolate(a.unsqueeze(0), io);
+      auto gb = F::interpolate(b.unsqueeze(0), io);
+      auto l = loss_utils::high_frequency_loss(ga.squeeze(0), gb.squeeze(0), 0.4, torch::kCPU);
+      out[1 + i] = l.item<float>();
+      loss = loss + scale * l;
+    }
+    loss.backward();
+    out[0] = loss.item<float>();
+    std::memcpy(dL, a.grad().contiguous().data_ptr<float>(), sizeof(float) * 3 * (size_t)H * W);
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "ref_multi_scale_loss: %s\n", e.what());
+    return 1;
+  }
+}

@@ -73,6 +73,18 @@ SYMBOLS = {
     "segs_search_neighborhood_depth": (_i, [_i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "segs_l1_ssim_temp_bytes": (_sz, [_i, _i]),
     "segs_l1_ssim_loss": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "segs_freq_pyramid": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "segs_spectrum_magnitude": (_i, [_vp, _sz, _vp, _vp]),
+    "segs_freq_temp_bytes": (_sz, [_i, _i, _vp, _vp]),
+    "segs_freq_spectrum_loss": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "segs_freq_pyramid_backward_add": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "segs_freq_plan_create": (_i, [_i, _i, _i, _vp, _f, _vp]),
+    "segs_freq_plan_destroy": (None, [_vp]),
+    "segs_freq_plan_levels": (_i, [_vp, _vp, _vp, _vp]),
+    "segs_freq_target_floats": (_sz, [_vp]),
+    "segs_freq_target": (_i, [_vp, _vp, _vp, _vp]),
+    "segs_freq_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "segs_freq_debug_coefficients": (_i, [_vp, _i, _vp, _vp]),
     "segs_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_int64, _f, _i, _vp]),
     "segs_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_int64, _f, _i, _vp, _vp]),
     "segs_adam_step_device": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, _vp, _i, _f, _i, _vp, _vp]),

@@ -88,7 +88,13 @@ class MapperConfig:
 
 
 def load_mapper_config(path: str, duplicates: str = "first") -> MapperConfig:
-    raw = read_opencv_yaml(path, duplicates)
+    return mapper_config_from_values(read_opencv_yaml(path, duplicates), path)
+
+
+def mapper_config_from_values(raw: Dict[str, Scalar], path: str = "<values>") -> MapperConfig:
+    """The typed configuration from a flat key -> value mapping: what read_opencv_yaml returns, or a committed extract of a
+    reference configuration file (tests/golden/mapper_cfgs.json) where the reference tree itself is absent (the GPU box)."""
+    raw = dict(raw)
 
     def num(key, cast):
         v = raw.get(key, 0)                     # absent node -> 0, like cv::FileNode
@@ -123,6 +129,19 @@ def load_mapper_config(path: str, duplicates: str = "first") -> MapperConfig:
                         high_frequency_regularization_start=I("Mapper.high_frequency_regularization_start"),
                         lambda_frequency_high=F("Mapper.lambda_frequency_high"), lambda_frequency_low=F("Mapper.lambda_frequency_low"),
                         use_coarse_anchor=B("Model.use_coarse_anchor"), raw=raw)
+
+
+def load_committed_config(rel_path: str) -> MapperConfig:
+    """A reference configuration by its path inside the reference tree (e.g. "cfg/gaussian_mapper/RGB-D/Replica/office0.yaml"),
+    from the committed value extract tests/golden/mapper_cfgs.json (made by tests/golden/make_cfg_golden.py)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "mapper_cfgs.json")) as f:
+        table = json.load(f)
+    if rel_path not in table:
+        raise KeyError(f"{rel_path} is not in tests/golden/mapper_cfgs.json (has: {sorted(table)})")
+    return mapper_config_from_values(table[rel_path], rel_path)
 
 
 def make_mapper_step(cfg: MapperConfig, model, width: int, height: int, spatial_lr_scale: float = 1.0, process_group=None,

@@ -317,7 +317,7 @@ class ScaffoldTrainerStep:
     def __init__(self, model: ScaffoldModel, width: int, height: int, opt: Optional[ScaffoldOptimizationParams] = None,
                  spatial_lr_scale: float = 1.0, process_group=None, scaling_reg_weight: float = 0.0):
         # scaling_reg_weight = 0.01 gives the mapper's loss (src/gaussian_mapper.cpp:926-928), 0 the trainer's (:89-90 of
-        # src/gaussian_trainer.cpp); the mapper's FFT regularisers (:930-945) are not built
+        # src/gaussian_trainer.cpp); the mapper's FFT regularisers (:930-945): enable_frequency_regularization()
         self.scaling_reg_weight = float(scaling_reg_weight)
         self.freq_reg = None             # see enable_frequency_regularization()
         self.model, self.opt = model, opt or ScaffoldOptimizationParams()
@@ -362,11 +362,36 @@ class ScaffoldTrainerStep:
         self.bg.fill_(1.0 if white else 0.0)
 
     def enable_frequency_regularization(self, lambda_high: float = 0.01, lambda_low: float = 0.0, scales=(1.0, 0.5, 0.25),
-                                        start: int = 5000, until: int = 25500, multi_resolution: bool = True):
-        """The mapper's FFT regularisers (src/gaussian_mapper.cpp:930-945, Mapper.* keys of the Replica cfg :140-146).  Their
-        gradient is taken with torch.fft + autograd (hipFFT library calls, as in the reference) and added to dL/dimage."""
+                                        start: int = 5000, until: int = 25500, multi_resolution: bool = True,
+                                        fused: bool = True):
+        """The mapper's FFT regularisers (src/gaussian_mapper.cpp:930-945, Mapper.* keys of the Replica cfg :140-146).
+        `fused` (default): frequency_loss.FusedFrequencyLoss -- cached |FFT(gt)|, one forward and one inverse real FFT per scale
+        (hipFFT library calls, as in the reference) and three small kernels around them (csrc/freq_loss.hip); otherwise the
+        torch.fft + autograd mirror of the reference's op chain (loss_utils.py), kept as the A/B and parity partner."""
         self.freq_reg = dict(lambda_high=lambda_high, lambda_low=lambda_low, scales=tuple(scales), start=start, until=until,
-                             multi=multi_resolution)
+                             multi=multi_resolution, fused=bool(fused))
+        self._freq_fused = {}
+
+    def _freq_active(self):
+        """(low term on, high term on) at this iteration: the two conditions of src/gaussian_mapper.cpp:932-944."""
+        fr, it = self.freq_reg, self.iteration
+        return (it < fr["until"] and fr["lambda_low"] != 0.0, fr["start"] < it < fr["until"] and fr["lambda_high"] != 0.0)
+
+    def _freq_fused_add(self, image: torch.Tensor, gt: torch.Tensor, dL: torch.Tensor, loss_word: torch.Tensor) -> bool:
+        """Adds the regulariser's gradient to dL and its value to loss_word, both in place; False when it is off."""
+        from .frequency_loss import FusedFrequencyLoss
+        fr = self.freq_reg
+        low_on, high_on = self._freq_active()
+        if not (low_on or high_on):
+            return False
+        key = (self.W, self.H, low_on, high_on)
+        fl = self._freq_fused.get(key)
+        if fl is None:
+            fl = self._freq_fused[key] = FusedFrequencyLoss(
+                self.H, self.W, self.model.device, lambda_high=fr["lambda_high"] if high_on else 0.0, scales=fr["scales"],
+                multi_resolution=fr["multi"], lambda_low=fr["lambda_low"] if low_on else 0.0)
+        fl(image, gt, dL, loss_word)
+        return True
 
     def _freq_grad(self, image: torch.Tensor, gt: torch.Tensor):
         from . import loss_utils
@@ -492,10 +517,14 @@ class ScaffoldTrainerStep:
                 image = image * mask
         loss, dL = self.loss_fn(image, gt)
         if self.freq_reg is not None:
-            floss, fg = self._freq_grad(image, gt)
-            if fg is not None:
-                dL = dL + fg
-                loss = loss + floss
+            if self.freq_reg["fused"]:
+                # loss is element 0 of the fused L1/SSIM object's result words, dL its own gradient buffer: both updated in place
+                self._freq_fused_add(image, gt, dL, loss.view(1))
+            else:
+                floss, fg = self._freq_grad(image, gt)
+                if fg is not None:
+                    dL = dL + fg
+                    loss = loss + floss
         if mask is not None:
             dL = dL * mask
         g = self.engine.backward(dL)
@@ -588,7 +617,8 @@ class ScaffoldTrainerStep:
     def profile_phases(self, kf: Keyframe, gt: torch.Tensor, iters: int = 20) -> Dict[str, float]:
         """Mean milliseconds per phase of one iteration (HIP events on the current stream between the same calls
         training_once issues; measurement support for bench.py, single rank, no densification)."""
-        names = ("prefilter_voxel", "neural_forward", "raster_forward", "loss", "raster_backward", "neural_backward", "adam")
+        names = ("prefilter_voxel", "neural_forward", "raster_forward", "loss", "freq_loss", "raster_backward", "neural_backward",
+                 "adam")
         tot = {n: 0.0 for n in names}
         ng = self.neural
         for _ in range(iters):
@@ -604,19 +634,26 @@ class ScaffoldTrainerStep:
             image = self.engine.forward(self.bg, ng.means3D, ng.colors, ng.opacity, ng.scales, ng.rotations, kf.view, kf.proj,
                                         kf.campos, kf.tanfovx, kf.tanfovy)
             ev[3].record()
-            _, dL = self.loss_fn(image, gt)
+            loss, dL = self.loss_fn(image, gt)
             ev[4].record()
-            g = self.engine.backward(dL)
+            if self.freq_reg is not None:       # the mapper's frequency regulariser, when its iteration window is open
+                if self.freq_reg["fused"]:
+                    self._freq_fused_add(image, gt, dL, loss.view(1))
+                else:
+                    _, fg = self._freq_grad(image, gt)
+                    dL = dL if fg is None else dL + fg
             ev[5].record()
-            ng.backward(g["means3D"], g["colors"], g["opacity"], g["scales"], g["rotations"], self.scaling_reg_weight)
+            g = self.engine.backward(dL)
             ev[6].record()
+            ng.backward(g["means3D"], g["colors"], g["opacity"], g["scales"], g["rotations"], self.scaling_reg_weight)
+            ev[7].record()
             groups = self.model.adam_groups(lrs)
             if self._anchor_count is None:
                 self._adam(groups, self._mlp_count, None)
             else:
                 self._adam(groups[:4], self._anchor_count, None)
                 self._adam(groups[4:], self._mlp_count, None)
-            ev[7].record()
+            ev[8].record()
             torch.cuda.synchronize(self.model.device)
             for i, n in enumerate(names):
                 tot[n] += ev[i].elapsed_time(ev[i + 1])

@@ -20,8 +20,11 @@ lib.ref_l1_ssim.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
 lib.ref_freq_losses.restype = C.c_int
 lib.ref_freq_losses.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 
+lib.ref_multi_scale_loss.restype = C.c_int
+lib.ref_multi_scale_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+
 out = {}
-cases = [(16, 16, 0.2, 1), (48, 64, 0.2, 2), (37, 53, 0.2, 3), (60, 90, 0.35, 4)]
+cases = [(16, 16, 0.2, 1), (48, 64, 0.2, 2), (37, 53, 0.2, 3), (60, 90, 0.35, 4), (68, 120, 0.2, 5)]
 for n, (H, W, lam, seed) in enumerate(cases):
     rng = np.random.default_rng(seed)
     gt = rng.random((3, H, W), dtype=np.float32)
@@ -39,5 +42,11 @@ for n, (H, W, lam, seed) in enumerate(cases):
     dH, dLo = np.zeros((3, H, W), np.float32), np.zeros((3, H, W), np.float32)
     assert lib.ref_freq_losses(img.ctypes.data, gt.ctypes.data, H, W, fr.ctypes.data, dH.ctypes.data, dLo.ctypes.data) == 0
     out[f"case{n}_freq_high_low"], out[f"case{n}_dL_high"], out[f"case{n}_dL_low"] = fr, dH, dLo
-    print(H, W, lam, res, fr)
+    # multi_scale_loss over the Replica cfg's three scales (Mapper.scale_num: 3 -> 1, 1/2, 1/4), piece by piece (see the driver)
+    scales = np.array([1.0, 0.5, 0.25], np.float32)
+    ms = np.zeros(4, np.float32)
+    dM = np.zeros((3, H, W), np.float32)
+    assert lib.ref_multi_scale_loss(img.ctypes.data, gt.ctypes.data, H, W, scales.ctypes.data, 3, ms.ctypes.data, dM.ctypes.data) == 0
+    out[f"case{n}_multi_scale"], out[f"case{n}_dL_multi_scale"] = ms, dM
+    print(H, W, lam, res, fr, ms)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "loss_reference.npz"), **out)

@@ -1,0 +1,201 @@
+"""The mapper's frequency regulariser on the device (src/gaussian_mapper.cpp:930-945; include/loss_utils.h:126-237): the fused
+path (segs-slam_amd/frequency_loss.py, csrc/freq_loss.hip) against the torch.fft + autograd mirror of the reference's op chain
+at the sizes the step runs at, and inside the mapper step.  The mirror itself is pinned by the reference's compiled functions
+(tests/test_loss_reference.py, small fixtures); this file carries that pin to BASELINE's image sizes.
+
+Tolerances: value 1e-5 relative; dL/dimage 1e-4 relative + 1e-5 of the tensor's largest entry (float32 FFTs of ~10^6 points;
+the two paths use different transforms -- real-to-complex against complex -- and a different backward formulation)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(H, W, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.rand(3, H, W, generator=g)
+    img = (gt + 0.2 * torch.randn(3, H, W, generator=g)).clamp(0, 1)
+    img[:, ::7, ::5] = gt[:, ::7, ::5]
+    return img.to(dev).contiguous(), gt.to(dev).contiguous()
+
+
+def _interp64(x, s):
+    import torch.nn.functional as F
+    if s == 1.0:
+        return x
+    return F.interpolate(x.unsqueeze(0), scale_factor=(s, s), mode="bilinear", align_corners=False,
+                         recompute_scale_factor=True).squeeze(0)
+
+
+def _check_against_float64(fl, img, gt, lam, scales, val, dL_minus_base):
+    """The regulariser's gradient is discontinuous where a spectrum magnitude crosses its target's (module docstring of
+    segs-slam_amd/frequency_loss.py) and ill-conditioned where a coefficient is tiny (its phase G/|G| amplifies the
+    transform's rounding by 1/|G|), so the comparison is made on the coefficient spectra the inverse transforms consume:
+    every frequency outside the float64-unstable set -- margin | |G| - |T| | <= 1e-5 |T|, or |G| below 5 % of the level's
+    median magnitude, at some scale it folds into -- must agree to 1e-4 relative + 1e-5 of the largest coefficient; the
+    unstable set must stay below 0.5 % of the spectrum; and dL/dimage must be the exact linear image (inverse transform +
+    transposed resize) of the DEVICE's coefficients to 1e-5 of its largest entry.
+    The resized copies are taken with float32 F.interpolate on the device, the op the reference runs (ATen evaluates the
+    source coordinate scale * (dst + 0.5) - 0.5 in float32 for float32 images), then everything else in float64."""
+    H, W = img.shape[-2:]
+    i64 = img.double()
+    lev32 = [_interp64(img, s) for s in scales]
+    sizes = [tuple(x.shape[-2:]) for x in lev32]
+    leaves = [x.double().detach().requires_grad_(True) for x in lev32]
+    tgt = [_interp64(gt, s).double() for s in scales]
+    terms, unstable = [], []
+    for s, lv, t in zip(scales, leaves, tgt):
+        G, T = torch.fft.fft2(lv), torch.fft.fft2(t)
+        terms.append(lam * s * torch.mean(torch.abs(G.abs() - T.abs())))
+        Ga, Ta = G.abs().detach(), T.abs()
+        unstable.append(((Ga - Ta).abs() <= 1e-5 * Ta) | (Ga < 0.05 * Ga.median()))
+    ref = sum(terms)
+    ref.backward()
+    assert abs(val - float(ref.detach())) <= 1e-5 * float(ref.detach())
+    tol = lambda Dr: 1e-4 * Dr.abs() + 1e-5 * float(Dr.abs().max())  # noqa: E731
+    if fl.folded:
+        # one coefficient spectrum for all scales: reference = transform of the float64 gradient w.r.t. the IMAGE (the exact
+        # 2x / 4x resizes have weights 1/2 in any precision)
+        a = i64.clone().requires_grad_(True)
+        tot = sum(lam * s * torch.mean(torch.abs(torch.fft.fft2(_interp64(a, s)).abs() - torch.fft.fft2(t).abs()))
+                  for s, t in zip(scales, tgt))
+        tot.backward()
+        D_ref = torch.fft.rfft2(a.grad) / (H * W)
+        D_dev = fl.coefficients(0).to(torch.complex128)
+        bad = unstable[0] | unstable[1].repeat(1, 2, 2) | unstable[2].repeat(1, 4, 4)
+        bad = bad[..., : W // 2 + 1]
+        assert float(bad.float().mean()) < 5e-3 * len(scales)        # the union over the scales a frequency folds into
+        ok = (D_dev - D_ref).abs() <= tol(D_ref)
+        assert bool((ok | bad).all()), f"{int((~(ok | bad)).sum())} stable frequencies disagree"
+        implied = torch.fft.irfft2(D_dev, s=(H, W), norm="forward")
+        n_disagree = int((~ok).sum())
+    else:
+        implied = torch.zeros_like(i64)
+        n_disagree = 0
+        for l, (s, lv, (h, w)) in enumerate(zip(scales, leaves, sizes)):
+            D_ref = torch.fft.rfft2(lv.grad) / (h * w)
+            D_dev = fl.coefficients(l).to(torch.complex128)
+            bad = unstable[l][..., : w // 2 + 1]
+            assert float(bad.float().mean()) < 5e-3
+            ok = (D_dev - D_ref).abs() <= tol(D_ref)
+            assert bool((ok | bad).all()), f"level {l}: {int((~(ok | bad)).sum())} stable frequencies disagree"
+            n_disagree += int((~ok).sum())
+            g_l = torch.fft.irfft2(D_dev, s=(h, w), norm="forward")
+            a = img.clone().requires_grad_(True)
+            (g,) = torch.autograd.grad(_interp64(a, s), a, g_l.float())      # transposed resize: ATen's own backward
+            implied += g.double()
+    got = dL_minus_base.double()
+    assert float((got - implied).abs().max()) <= 1e-5 * float(implied.abs().max())
+    return n_disagree
+
+
+@pytest.mark.parametrize("size", [(680, 1200), (1080, 1920), (480, 640), (187, 333), (170, 300), (64, 72)])
+@pytest.mark.parametrize("multi", [True, False])
+@pytest.mark.parametrize("torch_fft", [False, True])
+def test_fused_frequency_loss_matches_float64_mirror_at_step_sizes(size, multi, torch_fft):
+    from segs_slam_amd.frequency_loss import FusedFrequencyLoss
+    dev = torch.device("cuda:0")
+    H, W = size
+    if torch_fft and H * W > 700 * 1300:
+        pytest.skip("the piecewise torch.fft form is covered at the smaller sizes")
+    img, gt = _images(H, W, dev, 11 + H)
+    lam = 0.01
+    scales = (1.0, 0.5, 0.25) if multi else (1.0,)
+    fl = FusedFrequencyLoss(H, W, dev, lambda_high=lam, scales=(1.0, 0.5, 0.25), multi_resolution=multi, torch_fft=torch_fft)
+    assert fl.folded == (multi and not torch_fft and H % 4 == 0 and W % 4 == 0)
+    fl.keep_coefficients()
+    base = torch.randn(3, H, W, device=dev) * 1e-9          # the L1/SSIM gradient the regulariser is added to
+    for _ in range(2):
+        dL = base.clone()
+        loss_word = torch.full((1,), 0.5, device=dev)
+        val = float(fl(img, gt, dL, loss_word))
+    torch.cuda.synchronize()
+    assert abs(float(loss_word) - 0.5 - val) <= 1e-6 + 1e-5 * val
+    disagree = _check_against_float64(fl, img, gt, lam, scales, val, dL - base)
+    assert disagree <= 3 + 2e-4 * 3 * H * W
+
+
+def test_folded_and_per_scale_plans_agree():
+    """The alias-folded evaluation (one transform pair) against the per-scale evaluation (three pairs) of the same plan API:
+    two float32 routes to the same numbers -- value 1e-6, coefficient-implied gradient within the flips' budget."""
+    from segs_slam_amd.frequency_loss import FusedFrequencyLoss
+    dev = torch.device("cuda:0")
+    H, W = 680, 1200
+    img, gt = _images(H, W, dev, 3)
+    folded = FusedFrequencyLoss(H, W, dev, lambda_high=0.01)
+    piecewise = FusedFrequencyLoss(H, W, dev, lambda_high=0.01, torch_fft=True)
+    assert folded.folded and not piecewise.folded
+    da, db = torch.zeros_like(img), torch.zeros_like(img)
+    va, vb = float(folded(img, gt, da)), float(piecewise(img, gt, db))
+    assert abs(va - vb) <= 2e-6 * vb
+    # L2 distance: each flipped frequency moves the gradient by 2 w_l over the whole image
+    rel = float((da - db).norm() / db.norm())
+    assert rel < 5e-3, rel
+
+
+def test_target_spectrum_cache_follows_the_target_tensor():
+    """|FFT(gt)| is cached per target tensor (address, version): another keyframe or an in-place edit must not hit a stale entry."""
+    from segs_slam_amd.frequency_loss import FusedFrequencyLoss
+    dev = torch.device("cuda:0")
+    H, W = 96, 128
+    img, gt = _images(H, W, dev, 5)
+    fl = FusedFrequencyLoss(H, W, dev, lambda_high=1.0, max_cached_targets=2)
+    z = lambda: torch.zeros(3, H, W, device=dev)  # noqa: E731
+    v0 = float(fl(img, gt, z()))
+    assert float(fl(img, gt, z())) == v0 and len(fl._targets) == 1
+    gt2 = gt.flip(-1).contiguous()
+    v2 = float(fl(img, gt2, z()))
+    assert v2 != v0 and len(fl._targets) == 2
+    gt.mul_(0.5)                                   # in place: the version counter moves, the entry is re-made
+    v3 = float(fl(img, gt, z()))
+    assert v3 != v0 and len(fl._targets) == 2      # bounded: the oldest entry went
+    fresh = FusedFrequencyLoss(H, W, dev, lambda_high=1.0)
+    assert float(fresh(img, gt, z())) == v3
+    assert float(fl(img, img.clone(), z())) == 0.0  # identical images: |G| == |T| everywhere, sign(0) = 0
+    d = z()
+    fl(img, img.clone(), d)
+    assert not d.any()
+
+
+def _step_pair(fused, iteration, dev):
+    from segs_slam_amd import mapper_config as mc, neural_gaussians as ng, scenes
+    cfg = mc.load_committed_config("cfg/gaussian_mapper/RGB-D/Replica/office0.yaml")
+    cam = scenes.make_camera(320, 240, 300.0, 300.0, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+    model = ng.synthetic_model(4000, cfg.model, cam, dev, seed=3)
+    step = mc.make_mapper_step(cfg, model, cam.width, cam.height)
+    step.freq_reg["fused"] = fused
+    step.iteration = iteration
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.1, 0.2, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    g = torch.Generator().manual_seed(9)
+    gt = torch.rand(3, cam.height, cam.width, generator=g).to(dev)
+    gt[:, 100:104, :] = 0.0                      # rows the mapper's row mask blanks (src/gaussian_mapper.cpp:917-922)
+    return step, kf, gt
+
+
+@pytest.mark.parametrize("iteration,expect_on", [(10_000, True), (3_000, False), (26_000, False)])
+def test_replica_mapper_step_with_fused_frequency_regulariser_matches_the_mirror(iteration, expect_on):
+    """One forward/backward of the step the Replica cfg describes (Mapper.use_frequency_regularization 1, 3 scales,
+    lambda_high 0.01, window (5 000, 25 500)): loss and every parameter gradient of the fused path against the path that
+    evaluates the regulariser with the reference's op chain + autograd."""
+    dev = torch.device("cuda:0")
+    res = {}
+    for fused in (True, False):
+        step, kf, gt = _step_pair(fused, iteration, dev)
+        assert step._freq_active() == (False, expect_on)
+        step.iteration += 0
+        loss = step._forward_backward(kf, gt)
+        torch.cuda.synchronize()
+        res[fused] = (float(loss), step.model.grads.clone(), step)
+    (la, ga, sa), (lb, gb, _) = res[True], res[False]
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    for name in sa.model.widths:
+        a, b = sa.model.grad(name), res[False][2].model.grad(name)
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-4 * scale, name
+    if expect_on:
+        # and the regulariser is really in there: without it the loss is smaller
+        step, kf, gt = _step_pair(True, 3_000, dev)
+        assert float(step._forward_backward(kf, gt)) < la - 1e-4
