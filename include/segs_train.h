@@ -112,10 +112,6 @@ size_t segs_freq_target_floats(const segs_freq_plan* plan);
 int segs_freq_target(segs_freq_plan* plan, const float* gt, float* target_out, void* stream);
 int segs_freq_loss(segs_freq_plan* plan, const float* image, const float* target, float* dL_inout, float* freq_loss_out,
                    float* loss_inout, void* stream);
-/* tests: the coefficient spectra a segs_freq_loss call hands to its inverse transforms (level 0 of a folded plan holds all
- * scales).  First call (out may be NULL): switch the plan to keeping copies; later calls: out[(3, h_l, w_l/2+1) complex64]. */
-int segs_freq_debug_coefficients(segs_freq_plan* plan, int level, float* out, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -84,7 +84,6 @@ SYMBOLS = {
     "segs_freq_target_floats": (_sz, [_vp]),
     "segs_freq_target": (_i, [_vp, _vp, _vp, _vp]),
     "segs_freq_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "segs_freq_debug_coefficients": (_i, [_vp, _i, _vp, _vp]),
     "segs_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_int64, _f, _i, _vp]),
     "segs_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_int64, _f, _i, _vp, _vp]),
     "segs_adam_step_device": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, _vp, _i, _f, _i, _vp, _vp]),

@@ -370,8 +370,6 @@ struct segs_freq_plan {
   float* grad[MAXL] = {};              // inverse transforms
   float* partial = nullptr;
   char* arena = nullptr;
-  float* keep[MAXL] = {};              // test support (segs_freq_debug_coefficients): copies taken before the inverse transforms
-  bool keep_on = false;
 };
 
 extern "C" {
@@ -468,7 +466,6 @@ void segs_freq_plan_destroy(segs_freq_plan* p) {
   for (int l = 0; l < MAXL; l++)
     if (p->have[l] && f.ok) { f.Destroy(p->r2c[l]); f.Destroy(p->c2r[l]); }
   if (p->arena) (void)hipFree(p->arena);
-  for (int l = 0; l < MAXL; l++) if (p->keep[l]) (void)hipFree(p->keep[l]);
   delete p;
 }
 
@@ -593,7 +590,6 @@ int segs_freq_loss(segs_freq_plan* p, const float* image, const float* target, f
                                                   const_cast<float*>(target + p->toff[0]), const_cast<float*>(target + p->toff[1]),
                                                   const_cast<float*>(target + p->toff[2]), p->weight[0], p->weight[1], p->weight[2], p->partial);
     freq_finish_kernel<<<1, 1024, 0, st>>>(p->partial, (int)nblk, freq_loss_out, loss_inout);
-    if (p->keep_on) (void)hipMemcpyAsync(p->keep[0], p->spec[1], (p->toff[1] - p->toff[0]) * sizeof(float2), hipMemcpyDeviceToDevice, st);
     if (f.ExecC2R(p->c2r[0], reinterpret_cast<hipfftComplex*>(p->spec[1]), p->grad[0]) != HIPFFT_SUCCESS)
       return fft_fail("segs_freq_loss: hipfftExecC2R failed");
     add_kernel<<<(unsigned)((npix + 255) / 256), 256, 0, st>>>(dL_inout, p->grad[0], npix);
@@ -611,32 +607,12 @@ int segs_freq_loss(segs_freq_plan* p, const float* image, const float* target, f
     }
     if (int rc = segs_freq_spectrum_loss(3, p->n, p->h, p->w, specs, tm, p->weight, freq_loss_out, loss_inout,
                                          reinterpret_cast<char*>(p->partial), st)) return rc;
-    for (int l = 0; l < p->n && p->keep_on; l++)
-      (void)hipMemcpyAsync(p->keep[l], p->spec[l], (p->toff[l + 1] - p->toff[l]) * sizeof(float2), hipMemcpyDeviceToDevice, st);
     for (int l = 0; l < p->n; l++)
       if (f.ExecC2R(p->c2r[l], reinterpret_cast<hipfftComplex*>(p->spec[l]), p->grad[l]) != HIPFFT_SUCCESS)
         return fft_fail("segs_freq_loss: hipfftExecC2R failed");
     if (int rc = segs_freq_pyramid_backward_add(dL_inout, 3, p->H, p->W, p->n, p->h, p->w, grads, st)) return rc;
   }
   hipError_t e = hipGetLastError();
-  return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
-}
-
-// test support: the coefficient spectra of a call, i.e. what its inverse transforms consume (a complex-to-real transform may
-// overwrite its input, so they are gone afterwards).  The first call (out == NULL allowed) switches the plan to keeping a copy
-// per level in every later segs_freq_loss; afterwards `out` receives level l's copy -- (3, h_l, w_l/2+1) interleaved
-// complex64; a folded plan has level 0 only: D of all scales together.
-int segs_freq_debug_coefficients(segs_freq_plan* p, int level, float* out, void* stream) {
-  if (!p || level < 0 || level >= p->n || (p->folded && level != 0)) return bad("segs_freq_debug_coefficients: invalid argument");
-  if (!p->keep_on) {
-    for (int l = 0; l < (p->folded ? 1 : p->n); l++)
-      if (hipMalloc(&p->keep[l], (p->toff[l + 1] - p->toff[l]) * sizeof(float2)) != hipSuccess) return bad("segs_freq_debug_coefficients: out of device memory");
-    p->keep_on = true;
-    if (out) return bad("segs_freq_debug_coefficients: nothing kept yet (the call switched keeping on)");
-    return SEGS_OK;
-  }
-  if (!out) return SEGS_OK;
-  hipError_t e = hipMemcpyAsync(out, p->keep[level], (p->toff[level + 1] - p->toff[level]) * sizeof(float2), hipMemcpyDeviceToDevice, (hipStream_t)stream);
   return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }
 

@@ -13,8 +13,8 @@ themselves stay library calls (hipFFT), as in the reference.
 
 The gradient is DISCONTINUOUS in the image wherever a spectrum magnitude crosses its target's (sign(|G_k| - |T_k|) flips): two
 float32 evaluations of the same formula may legitimately disagree by 2 w_l on such a frequency.  The tests therefore compare
-coefficient spectra frequency by frequency and require every disagreement to sit on a frequency whose float64 margin
-| |G_k| - |T_k| | / |T_k| is below 1e-5 (tests/test_frequency_loss_gpu.py).
+dL/dimage against a float64 evaluation in which only frequencies whose float64 margin | |G_k| - |T_k| | / |T_k| is below 1e-5
+may take the device's sign (tests/test_frequency_loss_gpu.py).
 
 low_freq_loss: the reference's mask quirk multiplies both spectra by an all-zero mask, so its gradient is
 identically zero (tests/golden/loss_reference.npz: dL_low == 0 from the reference's own compiled code) while its VALUE is a
@@ -166,19 +166,3 @@ class FusedFrequencyLoss:
                 if loss_inout is not None:
                     loss_inout += low
         return self.value[0]
-
-    def keep_coefficients(self):
-        """Test support: from now on keep what each call hands to its inverse transforms (see coefficients())."""
-        if self._plan is not None:
-            _capi.check(self._lib.segs_freq_debug_coefficients(self._plan, 0, None, self._stream()), "segs_freq_debug_coefficients")
-
-    def coefficients(self, level: int = 0) -> torch.Tensor:
-        """Test support: a copy of the coefficient spectrum of the last call (folded plans: level 0 holds all scales).
-        Plans need keep_coefficients() before that call (a complex-to-real transform may overwrite its input)."""
-        if self._plan is None:
-            return self._spec[level].clone()       # torch's irfft2 works on a copy
-        h, w = self.sizes[level]
-        out = torch.empty((3, h, w // 2 + 1), dtype=torch.complex64, device=self.dev)
-        _capi.check(self._lib.segs_freq_debug_coefficients(self._plan, level, C.c_void_p(out.data_ptr()), self._stream()),
-                    "segs_freq_debug_coefficients")
-        return out

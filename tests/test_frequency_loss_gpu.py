@@ -3,8 +3,8 @@ path (segs-slam_amd/frequency_loss.py, csrc/freq_loss.hip) against the torch.fft
 at the sizes the step runs at, and inside the mapper step.  The mirror itself is pinned by the reference's compiled functions
 (tests/test_loss_reference.py, small fixtures); this file carries that pin to BASELINE's image sizes.
 
-Tolerances: value 1e-5 relative; dL/dimage 1e-4 relative + 1e-5 of the tensor's largest entry (float32 FFTs of ~10^6 points;
-the two paths use different transforms -- real-to-complex against complex -- and a different backward formulation)."""
+Tolerances: value 1e-5 relative; dL/dimage 1e-4 relative + 1e-5 of the tensor's largest entry against a float64 evaluation,
+with the sign of near-tie frequencies arbitrated as _check_against_float64 describes."""
 import numpy as np
 import pytest
 import torch
@@ -28,66 +28,59 @@ def _interp64(x, s):
                          recompute_scale_factor=True).squeeze(0)
 
 
-def _check_against_float64(fl, img, gt, lam, scales, val, dL_minus_base):
-    """The regulariser's gradient is discontinuous where a spectrum magnitude crosses its target's (module docstring of
-    segs-slam_amd/frequency_loss.py) and ill-conditioned where a coefficient is tiny (its phase G/|G| amplifies the
-    transform's rounding by 1/|G|), so the comparison is made on the coefficient spectra the inverse transforms consume:
-    every frequency outside the float64-unstable set -- margin | |G| - |T| | <= 1e-5 |T|, or |G| below 5 % of the level's
-    median magnitude, at some scale it folds into -- must agree to 1e-4 relative + 1e-5 of the largest coefficient; the
-    unstable set must stay below 0.5 % of the spectrum; and dL/dimage must be the exact linear image (inverse transform +
-    transposed resize) of the DEVICE's coefficients to 1e-5 of its largest entry.
-    The resized copies are taken with float32 F.interpolate on the device, the op the reference runs (ATen evaluates the
-    source coordinate scale * (dst + 0.5) - 0.5 in float32 for float32 images), then everything else in float64."""
+def _check_against_float64(img, gt, lam, scales, val, got):
+    """dL/dimage of the device against a float64 evaluation of the reference's formula.
+
+    The regulariser's gradient is discontinuous where a spectrum magnitude crosses its target's: sign(|G_k| - |T_k|) is
+    decided by rounding when the two agree to float32 precision, and each such frequency moves the whole gradient image by
+    2 w_s.  The float64 side therefore lists its NEAR TIES (| |G_k| - |T_k| | <= 1e-5 |T_k|), and for each takes the device's
+    sign if the device's gradient says so (projection of the residual on that frequency's own gradient image, obtained by
+    autograd).  Nothing else is adjusted: after that the stated bar applies to every entry of dL/dimage -- 1e-4 relative
+    + 1e-5 of its largest entry -- and the value to 1e-5 relative.  Returns (near ties, signs taken from the device).
+
+    Sizes that are not multiples of 4 resize with non-trivial bilinear weights: those copies are taken with float32
+    F.interpolate on the device, the op the reference runs (ATen forms the source coordinate scale * (dst + 0.5) - 0.5 in
+    float32 for float32 images), and its own backward carries the level gradients to the image; exact 2x / 4x resizes
+    (weights 1/2 in any precision) run in float64 throughout."""
     H, W = img.shape[-2:]
-    i64 = img.double()
-    lev32 = [_interp64(img, s) for s in scales]
-    sizes = [tuple(x.shape[-2:]) for x in lev32]
-    leaves = [x.double().detach().requires_grad_(True) for x in lev32]
-    tgt = [_interp64(gt, s).double() for s in scales]
-    terms, unstable = [], []
+    exact = H % 4 == 0 and W % 4 == 0
+    src = img.double() if exact else img
+    a = src.clone().requires_grad_(True)
+    levels = [_interp64(a, s) for s in scales]
+    leaves = [x.detach().double().requires_grad_(True) for x in levels]
+    tgt = [_interp64(gt.double() if exact else gt, s).double() for s in scales]
+
+    def to_image(level_grads):
+        g = torch.autograd.grad(levels, a, [x.to(lv.dtype) for x, lv in zip(level_grads, levels)], retain_graph=True)[0]
+        return g.double()
+
+    spectra, total = [], 0.0
     for s, lv, t in zip(scales, leaves, tgt):
-        G, T = torch.fft.fft2(lv), torch.fft.fft2(t)
-        terms.append(lam * s * torch.mean(torch.abs(G.abs() - T.abs())))
-        Ga, Ta = G.abs().detach(), T.abs()
-        unstable.append(((Ga - Ta).abs() <= 1e-5 * Ta) | (Ga < 0.05 * Ga.median()))
-    ref = sum(terms)
-    ref.backward()
-    assert abs(val - float(ref.detach())) <= 1e-5 * float(ref.detach())
-    tol = lambda Dr: 1e-4 * Dr.abs() + 1e-5 * float(Dr.abs().max())  # noqa: E731
-    if fl.folded:
-        # one coefficient spectrum for all scales: reference = transform of the float64 gradient w.r.t. the IMAGE (the exact
-        # 2x / 4x resizes have weights 1/2 in any precision)
-        a = i64.clone().requires_grad_(True)
-        tot = sum(lam * s * torch.mean(torch.abs(torch.fft.fft2(_interp64(a, s)).abs() - torch.fft.fft2(t).abs()))
-                  for s, t in zip(scales, tgt))
-        tot.backward()
-        D_ref = torch.fft.rfft2(a.grad) / (H * W)
-        D_dev = fl.coefficients(0).to(torch.complex128)
-        bad = unstable[0] | unstable[1].repeat(1, 2, 2) | unstable[2].repeat(1, 4, 4)
-        bad = bad[..., : W // 2 + 1]
-        assert float(bad.float().mean()) < 5e-3 * len(scales)        # the union over the scales a frequency folds into
-        ok = (D_dev - D_ref).abs() <= tol(D_ref)
-        assert bool((ok | bad).all()), f"{int((~(ok | bad)).sum())} stable frequencies disagree"
-        implied = torch.fft.irfft2(D_dev, s=(H, W), norm="forward")
-        n_disagree = int((~ok).sum())
-    else:
-        implied = torch.zeros_like(i64)
-        n_disagree = 0
-        for l, (s, lv, (h, w)) in enumerate(zip(scales, leaves, sizes)):
-            D_ref = torch.fft.rfft2(lv.grad) / (h * w)
-            D_dev = fl.coefficients(l).to(torch.complex128)
-            bad = unstable[l][..., : w // 2 + 1]
-            assert float(bad.float().mean()) < 5e-3
-            ok = (D_dev - D_ref).abs() <= tol(D_ref)
-            assert bool((ok | bad).all()), f"level {l}: {int((~(ok | bad)).sum())} stable frequencies disagree"
-            n_disagree += int((~ok).sum())
-            g_l = torch.fft.irfft2(D_dev, s=(h, w), norm="forward")
-            a = img.clone().requires_grad_(True)
-            (g,) = torch.autograd.grad(_interp64(a, s), a, g_l.float())      # transposed resize: ATen's own backward
-            implied += g.double()
-    got = dL_minus_base.double()
-    assert float((got - implied).abs().max()) <= 1e-5 * float(implied.abs().max())
-    return n_disagree
+        G, T = torch.fft.fft2(lv), torch.fft.fft2(t).abs()
+        spectra.append((G, T))
+        total = total + lam * s * torch.mean(torch.abs(G.abs() - T))
+    ref = float(total.detach())
+    assert abs(val - ref) <= 1e-5 * ref
+    g_ref = to_image(torch.autograd.grad(total, leaves, retain_graph=True))
+    resid = got.double() - g_ref
+    ties = taken = 0
+    for l, (s, (G, T)) in enumerate(zip(scales, spectra)):
+        near = ((G.abs().detach() - T).abs() <= 1e-5 * T).nonzero()
+        ties += len(near)
+        assert len(near) <= 20 + 1e-4 * T.numel()
+        for c, ky, kx in near.tolist():
+            term = lam * s * torch.abs(G[c, ky, kx].abs() - T[c, ky, kx]) / T.numel()
+            lg = [torch.zeros_like(x) for x in leaves]
+            lg[l] = torch.autograd.grad(term, leaves[l], retain_graph=True)[0]
+            g_k = to_image(lg)                      # this frequency's share of the gradient; the other sign gives -g_k
+            if float((resid * (-2 * g_k)).sum()) > 0.5 * float(((2 * g_k) ** 2).sum()):
+                g_ref = g_ref - 2 * g_k
+                resid = resid + 2 * g_k
+                taken += 1
+    tol = 1e-4 * g_ref.abs() + 1e-5 * float(g_ref.abs().max())
+    worst = float((resid.abs() - tol).max())
+    assert worst <= 0, f"{int((resid.abs() > tol).sum())} entries outside the bar after {taken} of {ties} near ties took the device's sign"
+    return ties, taken
 
 
 @pytest.mark.parametrize("size", [(680, 1200), (1080, 1920), (480, 640), (187, 333), (170, 300), (64, 72)])
@@ -104,7 +97,6 @@ def test_fused_frequency_loss_matches_float64_mirror_at_step_sizes(size, multi, 
     scales = (1.0, 0.5, 0.25) if multi else (1.0,)
     fl = FusedFrequencyLoss(H, W, dev, lambda_high=lam, scales=(1.0, 0.5, 0.25), multi_resolution=multi, torch_fft=torch_fft)
     assert fl.folded == (multi and not torch_fft and H % 4 == 0 and W % 4 == 0)
-    fl.keep_coefficients()
     base = torch.randn(3, H, W, device=dev) * 1e-9          # the L1/SSIM gradient the regulariser is added to
     for _ in range(2):
         dL = base.clone()
@@ -112,8 +104,8 @@ def test_fused_frequency_loss_matches_float64_mirror_at_step_sizes(size, multi, 
         val = float(fl(img, gt, dL, loss_word))
     torch.cuda.synchronize()
     assert abs(float(loss_word) - 0.5 - val) <= 1e-6 + 1e-5 * val
-    disagree = _check_against_float64(fl, img, gt, lam, scales, val, dL - base)
-    assert disagree <= 3 + 2e-4 * 3 * H * W
+    ties, taken = _check_against_float64(img, gt, lam, scales, val, dL - base)
+    print(f"{W}x{H} multi={multi} torch_fft={torch_fft}: {ties} near ties, {taken} took the device's sign")
 
 
 def test_folded_and_per_scale_plans_agree():
