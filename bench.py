@@ -130,10 +130,18 @@ def main():
     os.dup2(2, 1)
 
     import numpy as np
+
+    from segs_slam_amd import scenes
+
+    # The C++ drop-in path (libgaussian_rasterizer.so -> libcuda_rasterizer.so -> C ABI) is timed by its own driver in a child
+    # process that has finished before this process touches the GPU.
+    want_extras = args.gpus == 1 and args.mode == "raster" and not args.no_extras and "WORLD_SIZE" not in os.environ
+    sc0 = scenes.make_config_scene(args.workload, keyframe=0) if want_extras else None
+    cpp_dropin = cpp_dropin_block(sc0) if want_extras else None
+
     import torch
     import torch.distributed as dist
 
-    from segs_slam_amd import scenes
     from segs_slam_amd.raster_engine import KernelProfile, RasterEngine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,7 +165,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # ---- workload: same Gaussians on every rank, one keyframe (camera pose) per rank
-    sc = scenes.make_config_scene(args.workload, keyframe=rank)
+    sc = sc0 if (sc0 is not None and rank == 0) else scenes.make_config_scene(args.workload, keyframe=rank)
     cam = sc.camera
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     bg, m3, col, op, sca, rot = t(sc.bg), t(sc.means3D), t(sc.colors), t(sc.opacity), t(sc.scales), t(sc.rotations)
@@ -350,6 +358,10 @@ def main():
                           "source": "one HIP event per step on the launch stream, inside the timed region (device time between "
                                     "step ends; the line's ms_per_step is the host clock over all K steps)"}
         if world == 1 and args.mode == "raster" and not args.no_extras:
+            try:
+                out["dropin"] = dropin_block(sc, dev, (bg, m3, col, op, sca, rot, view, proj, campos), dL, cpp_dropin, world * args.steps / elapsed)
+            except Exception as e:  # noqa: BLE001  (extra blocks never fail the bench line)
+                out["dropin"] = {"error": f"{type(e).__name__}: {e}"}
             extras = [("render_only_ms", lambda: render_only(eng, (bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy))),
                       ("mapper_step", lambda: mapper_step_block(dev)), ("replica_step", lambda: replica_step_block(dev)),
                       ("config3", lambda: config3_block(dev))]
@@ -366,6 +378,80 @@ def main():
         print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def cpp_dropin_block(sc, steps: int = 50, warmup: int = 10):
+    """fwd+bwd iterations per second of the headline workload through the C++ drop-in: GaussianRasterizer::forward and the
+    autograd backward of csrc/torch_boundary/libgaussian_rasterizer.so, driven by `boundary_test --bench` (a child process;
+    the scene travels in a temporary file).  Twice: default flags (the reference's R / point_list / ranges bit for bit) and
+    SEGS_RASTER_TIGHT_BINNING (segs_raster.h)."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    exe = os.path.join(ROOT, "segs-slam_amd", "csrc", "torch_boundary", "boundary_test")
+    if not os.path.exists(exe):
+        return {"error": "csrc/torch_boundary/boundary_test is not built"}
+    cam = sc.camera
+    out = {"what": "GaussianRasterizer::forward + autograd backward (C++/LibTorch-ROCm drop-in, reference signatures), fresh outputs and "
+                   "allocator-grown scratch per call, one host synchronisation on num_rendered per forward; timed by boundary_test --bench "
+                   f"in a child process, {steps} steps after {warmup}"}
+    with tempfile.TemporaryDirectory(prefix="segs_bench_") as d:
+        path = os.path.join(d, "scene.bin")
+        with open(path, "wb") as f:
+            np.array([sc.P, cam.width, cam.height], np.int32).tofile(f)
+            np.array([cam.tanfovx, cam.tanfovy], np.float32).tofile(f)
+            for a in (sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, sc.rotations, cam.world_view_transform,
+                      cam.full_proj_transform, cam.camera_center, sc.dL_dout_color):
+                np.ascontiguousarray(a, np.float32).tofile(f)
+        for label, flags in (("reference_lists", 0), ("tight_binning", 32)):
+            try:
+                r = subprocess.run([exe, "--bench", path, str(steps), str(warmup), str(flags)], capture_output=True, text=True, timeout=600)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                out[label] = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+            except Exception as e:  # noqa: BLE001
+                out[label] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def dropin_block(sc, dev, tensors, dL, cpp_dropin, resident_its, steps: int = 50, warmup: int = 10):
+    """What an unchanged SEGS-SLAM gets by swapping the libraries: fwd+bwd iterations per second of the headline workload through
+    the reference-shaped entry points (RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA: fresh output tensors and scratch
+    per call, one host synchronisation on num_rendered per forward) -- (i) the Python mirror of src/rasterize_points.cu over the
+    C ABI, (ii) the C++/LibTorch-ROCm library (cpp_dropin_block) -- each with the reference's lists and with
+    SEGS_RASTER_TIGHT_BINNING; next to the resident path the headline `value` is measured on."""
+    import torch
+    from segs_slam_amd import _capi, rasterize_points as rp
+    cam = sc.camera
+    bg, m3, col, op, sca, rot, view, proj, campos = tensors
+    e = torch.empty(0, device=dev)
+    lib = _capi.lib()
+
+    def one():
+        R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(bg, m3, col, op, sca, rot, 1.0, e, view, proj, cam.tanfovx,
+                                                                        cam.tanfovy, cam.height, cam.width, e, 0, campos, False)
+        rp.RasterizeGaussiansBackwardCUDA(bg, m3, radii, col, sca, rot, 1.0, e, view, proj, cam.tanfovx, cam.tanfovy, dL, e, 0,
+                                          campos, geom, R, binning, img)
+        return R
+    py = {}
+    for label, flags in (("reference_lists", 0), ("tight_binning", 32)):
+        old = lib.segs_raster_set_flags(flags)
+        try:
+            for _ in range(warmup):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                R = one()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+        finally:
+            lib.segs_raster_set_flags(old)
+        py[label] = {"iters_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "num_rendered_returned": R, "steps": steps, "warmup": warmup}
+    return {"workload": f"{sc.P} Gaussians, {cam.width}x{cam.height} (the headline workload), fwd+bwd raster",
+            "resident_path_iters_per_s": resident_its,
+            "python_reference_shaped": dict(py, what="segs_slam_amd.rasterize_points.RasterizeGaussiansCUDA + RasterizeGaussiansBackwardCUDA "
+                                                    "(mirror of src/rasterize_points.cu:36-193 over the C ABI)"),
+            "cpp_gaussian_rasterizer": cpp_dropin}
 
 
 def _percentiles(ms):

@@ -58,6 +58,15 @@ const char* segs_last_error(void);
 /* SEGS_RASTER_UNFUSED_BINNING (A/B measurements and tests): fill the range table and the status words with their own kernel
  * (identify_tile_ranges) after the tile-id sort instead of inside its last scatter pass.  Same results. */
 #define SEGS_RASTER_UNFUSED_BINNING 16u
+/* SEGS_RASTER_TIGHT_BINNING (reference-shaped segs_rasterize_forward only; the resident entry points always do this): bin
+ * what the resident forward bins -- the bounding box of the alpha >= 1/255 ellipse intersected with the reference's 3-sigma
+ * square instead of the square itself (rasterizer_impl.cu:70-111, auxiliary.h:47-57), and leave out, while sorting, every
+ * instance that reaches no pixel of its tile.  Image, radii and gradients are what the default gives (image bit for bit);
+ * the returned num_rendered is the number of instances BINNED, not the reference's R, and point_list / ranges / n_contrib
+ * inside the scratch describe the shorter lists.  Legal for a drop-in because the three scratch buffers are opaque between
+ * forward and backward (src/rasterize_points.cu:28-34; rasterizer_impl.h:22-73) and R is only ever handed back to backward
+ * (src/gaussian_rasterizer.cpp:60-88,120-141).  The segs_debug_unpack_* helpers describe default-mode scratch only. */
+#define SEGS_RASTER_TIGHT_BINNING 32u
 uint32_t segs_raster_set_flags(uint32_t flags);
 
 /* Resident mode only, per host thread; returns the previous pointer.  When set, segs_rasterize_forward_resident also

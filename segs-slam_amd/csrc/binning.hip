@@ -30,46 +30,36 @@ namespace segs {
 constexpr int PREFIX_ROWS = PREFIX_ROWS_PER_WG;  // gs_layout.h
 
 // ---------------------------------------------------------------------------------------------
-// K5: exclusive scan of the per-workgroup tiles_touched sums written by preprocess_fwd_kernel.
-// One 1024-thread workgroup; in-place; total (= num_rendered R) to *total.
+// K5 (reference: cub::DeviceScan::InclusiveSum + the D2H copy of its last element, rasterizer_impl.cu:276-281): what the
+// host needs before it can size the binning scratch -- the TOTAL of the per-workgroup tiles_touched sums written by
+// preprocess_fwd_kernel (= num_rendered R) and the depth range of the binned Gaussians.  The offsets themselves are formed
+// later, in depth order (ordered_offsets_kernel), so this is a reduction, not a scan: one 1024-thread workgroup, every
+// load of a thread in flight at once.  (Until round 4 it also wrote the exclusive scan of the sums back in place -- twelve
+// dependent rounds of load / wave scan / barrier at 3 M Gaussians, 46 us for a result nothing read any more.)
 __global__ void __launch_bounds__(1024) scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblocks,
                                                                const uint32_t* __restrict__ depth_range,
                                                                uint32_t* __restrict__ total) {
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t carry_s;
-  __shared__ uint32_t s_dmax, s_dnmin;
+  __shared__ uint32_t w_sum[16], w_dmax[16], w_dnmin[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) { carry_s = 0; s_dmax = 0; s_dnmin = 0; }
-  __syncthreads();
-  uint32_t dmax = 0, dnmin = 0;
-  for (int base = 0; base < nblocks; base += 1024) {
-    const int i = base + tid;
-    const uint32_t v = i < nblocks ? block_sums[i] : 0u;
-    if (i < nblocks) { dmax = max(dmax, depth_range[i]); dnmin = max(dnmin, depth_range[nblocks + i]); }
-    uint32_t x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      uint32_t y = __shfl_up(x, off, 64);
-      if (lane >= off) x += y;
-    }
-    if (lane == 63) wave_tot[wv] = x;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wv; w++) wbase += wave_tot[w];
-    const uint32_t carry = carry_s;
-    if (i < nblocks) block_sums[i] = carry + wbase + x - v;  // exclusive
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + wbase + x;
-    __syncthreads();
+  uint32_t sum = 0, dmax = 0, dnmin = 0;
+  for (int i = tid; i < nblocks; i += 1024) {
+    sum += block_sums[i];
+    dmax = max(dmax, depth_range[i]);
+    dnmin = max(dnmin, depth_range[nblocks + i]);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off, 64);
     dmax = max(dmax, (uint32_t)__shfl_down((int)dmax, off, 64));
     dnmin = max(dnmin, (uint32_t)__shfl_down((int)dnmin, off, 64));
   }
-  if (lane == 0) { atomicMax(&s_dmax, dmax); atomicMax(&s_dnmin, dnmin); }
+  if (lane == 0) { w_sum[wv] = sum; w_dmax[wv] = dmax; w_dnmin[wv] = dnmin; }
   __syncthreads();
-  if (tid == 0) { total[0] = carry_s; total[1] = s_dnmin; total[2] = s_dmax; }  // R, max(~depth), max(depth)
+  if (tid == 0) {
+    uint32_t s = 0, a = 0, b = 0;
+    for (int w = 0; w < 16; w++) { s += w_sum[w]; a = max(a, w_dmax[w]); b = max(b, w_dnmin[w]); }
+    total[0] = s; total[1] = b; total[2] = a;  // R, max(~depth), max(depth)
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -360,10 +360,11 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
 
   int R = 0;
   uint32_t hdr[3] = {0u, 0u, 0u};  // num_rendered, max(~depth_bits), max(depth_bits)
+  const bool tight = (g_flags & SEGS_RASTER_TIGHT_BINNING) != 0u;   // segs_raster.h: shorter lists, same image and gradients
   if (P > 0) {
     int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales,
                             scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M,
-                            cam_pos, st);
+                            cam_pos, st, nullptr, nullptr, nullptr, tight ? PREPROCESS_TIGHT_RECT : 0u);
     if (rc) return rc;
     { PROF(K_SCAN);
     scan_block_sums_kernel<<<1, 1024, 0, st>>>(G.block_sums(), G.L.nblocks, G.block_sums() + (G.L.nblocks + 1), G.num_rendered());
@@ -391,7 +392,7 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
     while (dbits < 32 && (dspan >> dbits) != 0u) dbits++;
     uint32_t* total_scratch = (uint32_t*)(bin + GS.block_sums) + G.L.nblocks;
     const bool nine = (dbits + 8) / 9 < (dbits + 7) / 8;   // e.g. the usual 26 bits: three 9-bit passes instead of four 8-bit ones
-    int rc = run_binning(G, bin, BL, GS, ranges, P, R, nullptr, dmin, dbits, dmin + dspan, gx, gy, total_scratch, st, false, false, nine);
+    int rc = run_binning(G, bin, BL, GS, ranges, P, R, nullptr, dmin, dbits, dmin + dspan, gx, gy, total_scratch, st, false, tight, nine);
     if (rc) return rc;
   }
   { PROF(K_RENDER_FWD);

@@ -4,10 +4,14 @@
 //          scales(P,3) rotations(P,4) view(16) proj(16) campos(3) dL(3,H,W) points_for_knn reuse means3D
 // out.bin: int32 R ; image(3,H,W) ; radii(P) as float ; grads: means3D(P,3) means2D(P,3) opacity(P) scales(P,3) rotations(P,4)
 //          colors(P,3) ; dist2(P) ; visible_filter radii(P) as float
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
+#include <string>
 #include <vector>
 
+#include "../../../include/segs_raster.h"
 #include "gaussian_rasterizer.h"
 
 static torch::Tensor rd(std::ifstream& f, std::vector<int64_t> shape) {
@@ -22,8 +26,56 @@ static void wr(std::ofstream& f, const torch::Tensor& t) {
   f.write(reinterpret_cast<const char*>(c.data_ptr<float>()), c.numel() * 4);
 }
 
+// boundary_test --bench <in.bin> <steps> <warmup> <flags>: throughput of the drop-in path exactly as an unchanged caller
+// drives it -- GaussianRasterizer::forward (fresh output tensors, the three scratch byte tensors grown by the allocator
+// callback, one host synchronisation on num_rendered per call, src/rasterize_points.cu:36-114) and the autograd backward
+// (src/gaussian_rasterizer.cpp:91-154), gradients reset to undefined between iterations like optimizer.zero_grad(true)
+// (src/gaussian_mapper.cpp:1029).  `flags`: segs_raster_set_flags bits (0 = the reference's lists bit for bit, 32 =
+// SEGS_RASTER_TIGHT_BINNING).  Prints one JSON object.
+static int bench_main(int argc, char** argv) {
+  if (argc < 6) { std::fprintf(stderr, "usage: boundary_test --bench in.bin steps warmup flags\n"); return 2; }
+  std::ifstream f(argv[2], std::ios::binary);
+  if (!f) { std::fprintf(stderr, "cannot open %s\n", argv[2]); return 2; }
+  const int steps = std::atoi(argv[3]), warmup = std::atoi(argv[4]);
+  const unsigned flags = (unsigned)std::strtoul(argv[5], nullptr, 0);
+  int32_t hdr[3]; float tf[2];
+  f.read(reinterpret_cast<char*>(hdr), 12);
+  f.read(reinterpret_cast<char*>(tf), 8);
+  const int P = hdr[0], W = hdr[1], H = hdr[2];
+  auto bg = rd(f, {3}), means3D = rd(f, {P, 3}), colors = rd(f, {P, 3}), opacity = rd(f, {P, 1}), scales = rd(f, {P, 3}),
+       rotations = rd(f, {P, 4}), view = rd(f, {4, 4}), proj = rd(f, {4, 4}), campos = rd(f, {3}), dL = rd(f, {3, H, W});
+  std::vector<torch::Tensor*> leaves = {&means3D, &colors, &opacity, &scales, &rotations};
+  for (auto* t : leaves) t->set_requires_grad(true);
+  auto means2D = torch::zeros_like(means3D).set_requires_grad(true);
+  GaussianRasterizationSettings rs(H, W, tf[0], tf[1], bg, 1.0f, view, proj, 0, campos, false);
+  GaussianRasterizer rast(rs);
+  torch::Tensor none;
+  segs_raster_set_flags(flags);
+  int64_t visible = 0;
+  auto one = [&]() {
+    auto out = rast.forward(means3D, means2D, opacity, false, true, true, true, false, none, colors, scales, rotations, none);
+    std::get<0>(out).backward(dL);
+    for (auto* t : leaves) t->mutable_grad() = torch::Tensor();
+    means2D.mutable_grad() = torch::Tensor();
+    return std::get<1>(out);
+  };
+  for (int i = 0; i < warmup; i++) one();
+  torch::cuda::synchronize();
+  const auto t0 = std::chrono::steady_clock::now();
+  torch::Tensor radii;
+  for (int i = 0; i < steps; i++) radii = one();
+  torch::cuda::synchronize();
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  visible = (radii > 0).sum().item<int64_t>();
+  std::printf("{\"iters_per_s\": %.3f, \"ms_per_step\": %.5f, \"steps\": %d, \"warmup\": %d, \"flags\": %u, \"P\": %d, "
+              "\"P_visible\": %lld, \"width\": %d, \"height\": %d}\n", steps / sec, sec / steps * 1e3, steps, warmup, flags, P,
+              (long long)visible, W, H);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: boundary_test in.bin out.bin\n"); return 2; }
+  if (argc >= 2 && std::string(argv[1]) == "--bench") return bench_main(argc, argv);
+  if (argc < 3) { std::fprintf(stderr, "usage: boundary_test in.bin out.bin | boundary_test --bench in.bin steps warmup flags\n"); return 2; }
   std::ifstream f(argv[1], std::ios::binary);
   int32_t hdr[3]; float tf[2];
   f.read(reinterpret_cast<char*>(hdr), 12);

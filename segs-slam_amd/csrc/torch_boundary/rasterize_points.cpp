@@ -38,8 +38,10 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
   if (means3D.ndimension() != 2 || means3D.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");
   const int P = means3D.size(0), H = image_height, W = image_width;
   auto float_opts = means3D.options().dtype(torch::kFloat32);
-  torch::Tensor out_color = torch::full({NUM_CHANNELS, H, W}, 0.0, float_opts);
-  torch::Tensor radii = torch::full({P}, 0, means3D.options().dtype(torch::kInt32));
+  // The reference fills both with zeros (:68-69), which only shows when P == 0 (:81 leaves the zero image): with Gaussians
+  // the render kernel writes every pixel and the per-Gaussian kernel every radius, so the fills (37 MB at 3 M / 1080p) go
+  torch::Tensor out_color = P != 0 ? torch::empty({NUM_CHANNELS, H, W}, float_opts) : torch::full({NUM_CHANNELS, H, W}, 0.0, float_opts);
+  torch::Tensor radii = P != 0 ? torch::empty({P}, means3D.options().dtype(torch::kInt32)) : torch::full({P}, 0, means3D.options().dtype(torch::kInt32));
   auto byte_opts = torch::TensorOptions(torch::kByte).device(means3D.device());
   torch::Tensor geomBuffer = torch::empty({0}, byte_opts), binningBuffer = torch::empty({0}, byte_opts),
                 imgBuffer = torch::empty({0}, byte_opts);
@@ -70,7 +72,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
   auto o = means3D.options().dtype(torch::kFloat32);
   // every row is written by the kernels: empty() instead of the reference's nine torch::zeros (:149-157)
   torch::Tensor dL_dmeans3D = torch::empty({P, 3}, o), dL_dmeans2D = torch::empty({P, 3}, o), dL_dcolors = torch::empty({P, NUM_CHANNELS}, o),
-                dL_dconic = torch::empty({P, 2, 2}, o), dL_dopacity = torch::empty({P, 1}, o), dL_dcov3D = torch::empty({P, 6}, o),
+                dL_dopacity = torch::empty({P, 1}, o), dL_dcov3D = torch::empty({P, 6}, o),   // (dL_dconic :153 is internal: not materialised)
                 dL_dsh = torch::zeros({P, M, 3}, o);
   const bool has_sr = scales.numel() != 0;
   torch::Tensor dL_dscales = has_sr ? torch::empty({P, 3}, o) : torch::zeros({P, 3}, o);
@@ -84,7 +86,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                   reinterpret_cast<char*>(geomBuffer.contiguous().data_ptr()),
                                   reinterpret_cast<char*>(binningBuffer.contiguous().data_ptr()),
                                   reinterpret_cast<char*>(imageBuffer.contiguous().data_ptr()), ptr(dL), ptr(dL_dmeans2D),
-                                  ptr(dL_dconic), ptr(dL_dopacity), ptr(dL_dcolors), ptr(dL_dmeans3D), ptr(dL_dcov3D), ptr(dL_dsh),
+                                  nullptr, ptr(dL_dopacity), ptr(dL_dcolors), ptr(dL_dmeans3D), ptr(dL_dcov3D), ptr(dL_dsh),
                                   has_sr ? ptr(dL_dscales) : nullptr, has_sr ? ptr(dL_drotations) : nullptr, cur_stream(means3D)),
           "segs_rasterize_backward");
   }

@@ -54,8 +54,12 @@ class RasterEngine:
         # SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY (segs_raster.h): candidate-domain inputs of segs_neural_forward
         # SEGS_RASTER_KEEP_DEAD_INSTANCES: resident forwards bin the reference's full bounding squares (R == R_reference)
         self.flags = (1 if skip_nonpositive_opacity else 0) | (2 if keep_dead_instances else 0)
-        # SEGS_RASTER_EXTRA_FLAGS: extra segs_raster.h flag bits for A/B measurements (e.g. 16 = SEGS_RASTER_UNFUSED_BINNING)
-        self.flags |= int(os.environ.get("SEGS_RASTER_EXTRA_FLAGS", "0"), 0)
+        # SEGS_RASTER_EXTRA_FLAGS: A/B measurements only, and only the bit meant for them (16 = SEGS_RASTER_UNFUSED_BINNING,
+        # same results); anything else -- a test-support bit, a malformed value -- is ignored rather than changing every engine
+        try:
+            self.flags |= int(os.environ.get("SEGS_RASTER_EXTRA_FLAGS", "0"), 0) & 16
+        except ValueError:
+            pass
         self.R_reference = 0
         self.R_live = 0
         self.capacity = 0

@@ -67,8 +67,10 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
     _require_gpu(means3D, "means3D")
     dev = means3D.device
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-    out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    # the reference zero-fills both (:68-69); that only shows for P == 0 (:81) -- otherwise every pixel and radius is written
+    mk = torch.empty if P != 0 else torch.zeros
+    out_color = mk((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    radii = mk((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _ResizableBuffer(dev), _ResizableBuffer(dev), _ResizableBuffer(dev)
     rendered = 0
     if P != 0:  # rasterize_points.cu:81 (P == 0 leaves the zero image, not the background)
@@ -101,7 +103,7 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
     dL_dmeans3D = torch.empty((P, 3), **opts)
     dL_dmeans2D = torch.empty((P, 3), **opts)
     dL_dcolors = torch.empty((P, NUM_CHANNELS), **opts)
-    dL_dconic = torch.empty((P, 2, 2), **opts)
+    # dL_dconic (P,2,2) is an internal product of the reference's backward (:153), never returned: not materialised here
     dL_dopacity = torch.empty((P, 1), **opts)
     dL_dcov3D = torch.empty((P, 6), **opts)
     dL_dsh = torch.zeros((P, M, 3), **opts)
@@ -118,7 +120,7 @@ def RasterizeGaussiansBackwardCUDA(background, means3D, radii, colors, scales, r
                 P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(sca),
                 float(scale_modifier), _ptr(rot), _ptr(cov), _ptr(view), _ptr(proj), _ptr(cam), float(tan_fovx),
                 float(tan_fovy), _ptr(rad), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dL),
-                _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D),
+                _ptr(dL_dmeans2D), None, _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D),
                 _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales) if has_sr else None,
                 _ptr(dL_drotations) if has_sr else None, _stream(dev))
         _capi.check(st, "segs_rasterize_backward")
