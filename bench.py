@@ -81,6 +81,7 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (exercises the RCCL calls on a one-GPU box)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--neural-flags", type=int, default=0, help="segs_neural_set_flags bits for A/B profiles (1 = SEGS_NEURAL_ONE_KERNEL_BACKWARD)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra blocks of the line (mapper_step, config3, render_only_ms): A/B runs and profiles")
     return ap.parse_args()
@@ -143,6 +144,9 @@ def main():
     import torch.distributed as dist
 
     from segs_slam_amd.raster_engine import KernelProfile, RasterEngine
+    if args.neural_flags:
+        from segs_slam_amd import _capi
+        _capi.lib().segs_neural_set_flags(args.neural_flags)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -322,6 +326,7 @@ def main():
                        "forward": "sync (reference API)" if args.sync_forward else "resident (no host sync)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc.get("hbm_bytes") if pmc else None, "traffic_source": pmc_src,
+                         "traffic_stale": pmc.get("stale") if pmc else None,
                          "algorithmic_bytes_per_launch": dom_bytes(ab_live), "priced_on": "instances_live (what the launch walks)",
                          "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"], "timing": dom_src,
                          "on_reference_num_rendered": {"algorithmic_bytes_per_launch": dom_bytes(ab_ref),
@@ -341,14 +346,14 @@ def main():
             a = pmc["SQ_INSTS_VALU"] / t_dom / 1e9
             out["roofline_valu"] = {"bound": "valu", "kernel": dominant, "achieved": a, "peak": VALU_PEAK_GINST,
                                     "unit": "G wave-instructions/s", "frac": a / VALU_PEAK_GINST,
-                                    "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "source": pmc_src,
+                                    "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "source": pmc_src, "stale": pmc.get("stale"),
                                     "note": "SQ_INSTS_VALU per launch / launch time against 1024 SIMDs x 2.4 GHz / 2 cycles per "
                                             "wave64 instruction; v_exp/v_rcp/permlane take 8 and v_cndmask/v_cmp/DPP 4 cycles"}
         if pmc and "write_bytes" in pmc:
             a = pmc["write_bytes"] / t_dom / 1e9
             out["roofline_atomic"] = {"bound": "global float atomics", "kernel": dominant, "achieved": a, "peak": ATOMIC_PEAK_GBPS,
                                       "unit": "GB/s", "frac": a / ATOMIC_PEAK_GBPS, "write_bytes_per_launch": pmc["write_bytes"],
-                                      "algorithmic_atomic_bytes": 36 * R_live, "source": pmc_src}
+                                      "algorithmic_atomic_bytes": 36 * R_live, "source": pmc_src, "stale": pmc.get("stale")}
         try:   # the tile kernels are reported in (pixel, Gaussian) pairs per second next to the byte figure
             out["raster"].update(pair_rates(eng, cam, per_step))
         except Exception as e:  # noqa: BLE001  (measurement garnish only; never fail the bench line over it)
@@ -640,6 +645,10 @@ def pmc_entry(workload, kernel):
     e = tab.get("segs::" + kernel)
     if not e:
         return None, None
+    # counters cannot be collected inside the timed run; say so when they were taken from another state of the kernel sources
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_summary import kernel_source_sha
+    e = dict(e, stale=tab.get("_kernel_source_sha") != kernel_source_sha(ROOT))
     return e, os.path.relpath(files[-1], ROOT)
 
 

@@ -42,6 +42,13 @@ typedef struct segs_neural_dims {
 
 #define SEGS_NEURAL_MAX_TENSORS 18
 
+/* Behaviour switches of segs_neural_backward, per host thread; returns the previous value.
+ * SEGS_NEURAL_ONE_KERNEL_BACKWARD (A/B measurements and tests): run a model WITHOUT feature bank through the one-kernel
+ * backward the feature-bank model uses (chain and weight gradients in one wave) instead of the chain-wave / gradient-wave
+ * pairs.  Same gradients up to the summation order of the weight-gradient partials. */
+#define SEGS_NEURAL_ONE_KERNEL_BACKWARD 1u
+uint32_t segs_neural_set_flags(uint32_t flags);
+
 /* Offsets and element counts of the parameter tensors inside the flat block, in the order listed above.
  * Any of offsets/counts/ntensors/total may be NULL. */
 int segs_neural_param_layout(const segs_neural_dims* dims, int64_t* offsets, int64_t* counts, int* ntensors, int64_t* total);

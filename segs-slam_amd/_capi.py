@@ -38,6 +38,7 @@ SYMBOLS = {
     "segs_training_statis_guarded": (_i, [_i, _i] + [_vp] * 10),
     "segs_anchor_growing_temp_bytes": (_sz, [_i, _i]),
     "segs_anchor_growing_level": (_i, [_i, _i, _i, _i] + [_vp] * 7 + [_f, _f, _f, _i] + [_vp] * 5),
+    "segs_neural_set_flags": (C.c_uint, [C.c_uint]),
     "segs_neural_param_layout": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "segs_neural_temp_bytes": (_sz, [_vp, _i]),
     "segs_neural_forward": (_i, [_vp, _i] + [_vp] * 16),

@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
   // no tile.
   // The ranges are cut from the tiles that HOLD keys (n may come from the device and be well below the launch's capacity):
   // cut from the capacity they would leave the last XCDs idle.
-#ifdef SORT_TILE_IDENTITY
+#if defined(SEGS_MEASURE) && defined(SORT_TILE_IDENTITY)
   const int tile_id = (int)blockIdx.x;
 #else
   const int tiles_in_use = (int)(((size_t)n + SORT_TILE - 1) / SORT_TILE);
@@ -628,12 +628,12 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(
     const int lp = r * SORT_THREADS + tid;
     if (lp < nout) {
       const K k = s_keys[lp];
-#ifdef ABLATE_SCATTER_LINEAR   // measurement only (tools/ubench_sort_passes.hip): full-line stores, wrong order
+#if defined(SEGS_MEASURE) && defined(ABLATE_SCATTER_LINEAR)   // measurement only (tools/ubench_sort_passes.hip): full-line stores, wrong order
       const size_t gp = tile_base + (size_t)lp + (size_t)(gdelta[digit_of<BITS>(k, shift, km) & dmask] & 0);
 #else
       const size_t gp = (size_t)((int64_t)lp + (int64_t)gdelta[digit_of<BITS>(k, shift, km) & dmask]);
 #endif
-#ifdef ABLATE_SCATTER_NO_STORE
+#if defined(SEGS_MEASURE) && defined(ABLATE_SCATTER_NO_STORE)
       if (k == (K)0x12345677 && gp == 77) keys_out[gp] = k;
       continue;
 #endif

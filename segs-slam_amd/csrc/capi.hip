@@ -102,9 +102,11 @@ uint32_t getHigherMsb(uint32_t n) {
 // that latency for nothing (50 k Gaussians at 640x480: 0.206 -> 0.187 ms per step with one tile per chunk).  Many tiles:
 // longer chunks keep the row scan short (3 M Gaussians at 1080p: 1.102 / 1.108 / 1.126 ms with 4 / 2 / 1).
 int count_chunk_tiles(int nblocks) {
-  // measurement switch; anything but 1, 2 or 4 tiles per chunk is ignored (the tables are sized for chunks of >= 1 tile)
+#ifdef SEGS_MEASURE   // measurement builds only (tools/): anything but 1, 2 or 4 tiles per chunk is ignored
   static const int chunk_override = [] { const char* e = getenv("SEGS_COUNT_CHUNK"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
-  return chunk_override > 0 ? chunk_override : (nblocks <= 256 ? 1 : (nblocks <= 2048 ? 2 : SORT_COUNT_CHUNK_TILES));
+  if (chunk_override > 0) return chunk_override;
+#endif
+  return nblocks <= 256 ? 1 : (nblocks <= 2048 ? 2 : SORT_COUNT_CHUNK_TILES);
 }
 // What the caller of the tile-id sort fuses into its last pass (run_binning).
 struct SortFusion {
@@ -267,7 +269,11 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   LAUNCH_TRY("ordered_block_sums_kernel");
   // tile-id sort: two 8-bit passes in general; ONE 11-bit pass when the image has at most 2048 tiles and the instances fit
   // SORT_WIDE_MAX_TILES sort tiles (640x480: three launches and a pass over the instances less)
-  static const bool no_wide = getenv("SEGS_NO_WIDE_DIGIT") != nullptr;   // measurement switch
+#ifdef SEGS_MEASURE   // measurement builds only (tools/)
+  static const bool no_wide = getenv("SEGS_NO_WIDE_DIGIT") != nullptr;
+#else
+  constexpr bool no_wide = false;
+#endif
   const bool wide_digit = !no_wide && bit <= 11 && BL.nblocks <= SORT_WIDE_MAX_TILES;
   const int tpasses = wide_digit ? 1 : (bit + 7) / 8;
   const int side = tpasses & 1;

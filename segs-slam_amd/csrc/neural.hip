@@ -1527,7 +1527,16 @@ WJobs make_jobs(const Layout& L) {
 
 }  // namespace
 
+namespace { thread_local uint32_t g_neural_flags = 0u; }
+
 extern "C" {
+
+uint32_t segs_neural_set_flags(uint32_t flags) {
+  const uint32_t old = g_neural_flags;
+  g_neural_flags = flags;
+  return old;
+}
+
 
 int segs_neural_param_layout(const segs_neural_dims* dims, int64_t* offsets, int64_t* counts, int* ntensors, int64_t* total) {
   Layout L;
@@ -1563,7 +1572,8 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
   pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small, T.count, T.gsum + L.total + 8);
   const int nb = (A + 256 * CV_ROUNDS - 1) / (256 * CV_ROUNDS);
   compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity);
-  static const hipError_t fwd_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS);
+  // (a per-device attribute: set on every call -- it is cheap -- so that a process driving several GPUs gets it on each)
+  const hipError_t fwd_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS);
   if (fwd_attr != hipSuccess) return segs::set_hip_error(fwd_attr, __func__);
   neural_fwd_kernel<<<NEURAL_GRID, FWD_WAVES * 64, FWD_LDS, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
                                         camera_center, means3D, colors, opacity, scales, rotations, neural_opacity, T.count + 1);
@@ -1595,7 +1605,7 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   constexpr size_t pair_lds = pair_run > pair_end ? pair_run : pair_end;
   static_assert(bwd_lds <= 160 * 1024 && pair_lds <= 160 * 1024, "one workgroup per CU");
   auto allow_lds = [](const void* kernel, size_t bytes) { return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
-  static const hipError_t attr_rc[3] = {allow_lds(reinterpret_cast<const void*>(neural_bwd_kernel<false>), bwd_lds),
+  const hipError_t attr_rc[3] = {allow_lds(reinterpret_cast<const void*>(neural_bwd_kernel<false>), bwd_lds),
                                         allow_lds(reinterpret_cast<const void*>(neural_bwd_kernel<true>), bwd_lds),
                                         allow_lds(reinterpret_cast<const void*>(neural_bwd_pair_kernel), pair_lds)};
   for (const hipError_t rc_attr : attr_rc)
@@ -1605,8 +1615,8 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   float* reg_sum = scaling_reg_out ? T.gsum + L.total + 8 : nullptr;
   // Plain model: chain waves + weight-gradient waves (neural_bwd_pair_kernel).  The feature bank's epilogue keeps the 32 features
   // and works through the scratch rows: the one-kernel form.  SEGS_NEURAL_BWD_ONE_ROLE=1 runs the plain model through that form
-  // too (the A/B of profiles/).
-  static const bool one_role = [] { const char* e = getenv("SEGS_NEURAL_BWD_ONE_ROLE"); return e && e[0] == '1'; }();
+  // too (SEGS_NEURAL_ONE_KERNEL_BACKWARD, segs_neural.h: the A/B of profiles/ and tests/test_neural_gpu.py).
+  const bool one_role = (g_neural_flags & SEGS_NEURAL_ONE_KERNEL_BACKWARD) != 0u;
   if (!L.bank && !one_role)
     neural_bwd_pair_kernel<<<BWD_GRID, 512, pair_lds, st>>>(
         L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small, camera_center, dL_dmeans3D,

@@ -246,7 +246,7 @@ __device__ __forceinline__ void pixel_role(BwdLds& L, int nb, int lane, float px
     const float2 q2 = *reinterpret_cast<const float2*>(&L.rec[sl][2]);
     const float dx = q0.x - pxf, dy = q0.y - pyf;
     const float power2 = dx * (q0.z * dx + q0.w * dy) + (q1.x * dy) * dy;
-#ifdef ABLATE_NO_TRANS
+#if defined(SEGS_MEASURE) && defined(ABLATE_NO_TRANS)
     const float ar = q1.y * (power2 * 0.001f + 1.0f);
 #else
     const float ar = q1.y * fast_exp2(power2);  // o * G
@@ -255,7 +255,7 @@ __device__ __forceinline__ void pixel_role(BwdLds& L, int nb, int lane, float px
     const bool ok = __float_as_uint(q2.y) < last_contributor && power2 <= 0.0f && ar >= 1.0f / 255.0f;
     const float aw = ok ? ar : 0.f;      // o * G (the clamp at 0.99 is not differentiated, backward.cu:497); 0 on skipped pairs
     const float ae = fminf(0.99f, aw);   // alpha; 0 makes every update below a no-op
-#ifdef ABLATE_NO_TRANS
+#if defined(SEGS_MEASURE) && defined(ABLATE_NO_TRANS)
     const float rinv = 1.f + ae;
 #else
     const float rinv = fast_rcp(1.f - ae);
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
       if (use_bg) pixel_role<true>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, accd);
       else pixel_role<false>(L, nb, lane, pxf, pyf, last_contributor, dp0, dp1, dp2, T_final, bg_dot_dpixel, T, accd);
       wave_lds_fence();
-#ifdef ABLATE_NO_GAUSS_ROLE
+#if defined(SEGS_MEASURE) && defined(ABLATE_NO_GAUSS_ROLE)
       continue;   // (the do-while's condition is evaluated)
 #endif
       // ---------------- (2) Gaussian role: lane = (part, gs): slot gs, pixels part*16 .. part*16+15
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
         const int slot = 4 * j + part;
         if (slot < nb && gs < 9) {
           const uint32_t id = __float_as_uint(reinterpret_cast<const float*>(&L.rec[slot][2])[2]);
-#ifndef ABLATE_NO_ATOMICS
+#if !(defined(SEGS_MEASURE) && defined(ABLATE_NO_ATOMICS))
           atomicAdd(gacc + (size_t)id * GACC_DWORDS + gs, mom[slot][gs]);
 #endif
         }

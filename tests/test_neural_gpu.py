@@ -269,46 +269,34 @@ def test_second_slab_of_persistent_workgroups_is_consistent(case):
     assert float((big.mlp_grads - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
-_ONE_ROLE_SCRIPT = """
-import sys, numpy as np, torch
-sys.path.insert(0, {root!r})
-from oracle import neural_ref
-from segs_slam_amd import neural_gaussians as ng
-dev = torch.device("cuda:0")
-kw = {kw!r}
-rd, md = neural_ref.NeuralDims(**kw), ng.ModelDims(**kw)
-A = {A}
-anchor, offset, feat, scaling_log, mlp = neural_ref.random_model(rd, A, 91)
-m = ng.ScaffoldModel(A, md, dev)
-m.load(anchor, offset, feat, scaling_log, mlp)
-g = torch.Generator().manual_seed(5)
-radii = torch.where(torch.rand(A, generator=g) < 0.8, torch.tensor(3), torch.tensor(0)).to(torch.int32).to(dev)
-grads = [torch.randn(A * 10, n, generator=g).to(dev) for n in (3, 3, 1, 3, 4)]
-gen = ng.NeuralGaussians(m)
-gen.forward(torch.tensor([0.1, -0.2, -0.5], device=dev), torch.tensor([0.3, -0.1, 0.2, 0.9, 0.1, -0.3, 0.2], device=dev), radii)
-gen.backward(*grads, scaling_reg_weight=0.01)
-torch.cuda.synchronize()
-np.save({out!r}, m.grads.cpu().numpy())
-"""
-
-
-def test_wave_pair_backward_equals_the_one_kernel_backward(tmp_path):
+def test_wave_pair_backward_equals_the_one_kernel_backward():
     """The plain model's backward runs as pairs of chain / weight-gradient waves (neural_bwd_pair_kernel); the one-kernel form
-    it replaced is still in the library behind SEGS_NEURAL_BWD_ONE_ROLE=1 (the switch is read once per process, hence the two
-    child processes).  The arithmetic of an anchor is the same in both: per-anchor gradients must be bit-identical."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    it replaced (still the feature-bank model's) takes the plain model too under SEGS_NEURAL_ONE_KERNEL_BACKWARD
+    (include/segs_neural.h).  The arithmetic of an anchor is the same in both: per-anchor gradients must be bit-identical."""
+    from segs_slam_amd import _capi, neural_gaussians as ng
+    dev = torch.device("cuda:0")
+    kw, A = CASES[1], 40001
+    rd, md = neural_ref.NeuralDims(**kw), ng.ModelDims(**kw)
+    anchor, offset, feat, scaling_log, mlp = neural_ref.random_model(rd, A, 91)
+    g = torch.Generator().manual_seed(5)
+    radii = torch.where(torch.rand(A, generator=g) < 0.8, torch.tensor(3), torch.tensor(0)).to(torch.int32).to(dev)
+    grads = [torch.randn(A * 10, n, generator=g).to(dev) for n in (3, 3, 1, 3, 4)]
+    lib = _capi.lib()
     outs = []
-    for one_role in ("0", "1"):
-        out = str(tmp_path / f"grads_{one_role}.npy")
-        env = dict(os.environ, SEGS_NEURAL_BWD_ONE_ROLE=one_role)
-        subprocess.run([sys.executable, "-c", _ONE_ROLE_SCRIPT.format(root=root, kw=CASES[1], A=40001, out=out)], check=True, env=env,
-                       timeout=300)
-        outs.append(np.load(out))
+    for flags in (0, 1):
+        m = ng.ScaffoldModel(A, md, dev)
+        m.load(anchor, offset, feat, scaling_log, mlp)
+        gen = ng.NeuralGaussians(m)
+        gen.forward(torch.tensor([0.1, -0.2, -0.5], device=dev), torch.tensor([0.3, -0.1, 0.2, 0.9, 0.1, -0.3, 0.2], device=dev), radii)
+        old = lib.segs_neural_set_flags(flags)
+        try:
+            gen.backward(*grads, scaling_reg_weight=0.01)
+        finally:
+            assert lib.segs_neural_set_flags(old) == flags
+        torch.cuda.synchronize()
+        outs.append(m.grads.cpu().numpy().copy())
     assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
-    n_anchor = 40001 * (3 + 30 + 32 + 6)   # the four per-anchor segments of the bucket; the MLP block follows
+    n_anchor = A * (3 + 30 + 32 + 6)   # the four per-anchor segments of the bucket; the MLP block follows
     assert np.array_equal(outs[0][:n_anchor], outs[1][:n_anchor])
     # the visible-anchor list is compacted with one atomic per 2048 anchors, so its block order -- and with it the order in which
     # the MLP weight gradients are summed -- differs from run to run: same bound as the split-model test above

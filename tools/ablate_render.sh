@@ -10,7 +10,7 @@ trap 'rm -rf "$TMP"' EXIT
 cd "$ROOT/segs-slam_amd/csrc"
 make -s
 for v in BASE ABLATE_NO_ATOMICS ABLATE_NO_GAUSS_ROLE ABLATE_NO_TRANS "ABLATE_NO_GAUSS_ROLE -DABLATE_NO_TRANS"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -fno-slp-vectorize -D$v -c render.hip -o "$TMP/render.o"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -fno-slp-vectorize -DSEGS_MEASURE -D$v -c render.hip -o "$TMP/render.o"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$TMP/libsegs_ablate.so" "$TMP/render.o" $(ls _obj/*.o | grep -v '/render\.o$')
   echo "== $v"
   (cd "$ROOT" && SEGS_RASTER_LIB="$TMP/libsegs_ablate.so" python bench.py --workload $WL --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "

@@ -13,12 +13,13 @@ SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
       "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_IFETCH SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM"
       "FETCH_SIZE" "WRITE_SIZE")
 for mode in pair one_role; do
-  if [ $mode = one_role ]; then export SEGS_NEURAL_BWD_ONE_ROLE=1; else unset SEGS_NEURAL_BWD_ONE_ROLE; fi
+  # bench.py --neural-flags N: segs_neural_set_flags bits (1 = SEGS_NEURAL_ONE_KERNEL_BACKWARD, segs_neural.h)
+  if [ $mode = one_role ]; then NF="--neural-flags 1"; else NF=""; fi
   dirs=""
   for i in "${!SETS[@]}"; do
     d=$OUT/${TAG}_pmcn_${mode}_$i
     rm -rf $d
-    rocprofv3 --kernel-trace --pmc ${SETS[$i]} --output-format csv -d $d -o run -- python3 $CMD > /dev/null 2> $OUT/${TAG}_pmcn_${mode}_$i.log || { echo "pass $i ($mode) failed"; tail -5 $OUT/${TAG}_pmcn_${mode}_$i.log; }
+    rocprofv3 --kernel-trace --pmc ${SETS[$i]} --output-format csv -d $d -o run -- python3 $CMD $NF > /dev/null 2> $OUT/${TAG}_pmcn_${mode}_$i.log || { echo "pass $i ($mode) failed"; tail -5 $OUT/${TAG}_pmcn_${mode}_$i.log; }
     dirs="$dirs $d"
     echo "pass $mode $i done"
   done

@@ -7,8 +7,19 @@ FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB-like units of 1024 B.  
 gfx950's FETCH_SIZE tallies 128-B requests at 64 B, so `fetch_bytes_corrected` = 2 x FETCH_SIZE (an upper bound for
 the narrow gathers, exact for wide streaming reads); WRITE_SIZE is exact for 16-B stores and float atomics.
 """
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
+
+
+def kernel_source_sha(root=None):
+    """sha256 over the kernel sources (segs-slam_amd/csrc/*.hip, *.h) in name order: bench.py compares it with the tree it
+    runs from and marks counter figures taken from another state of the kernels as stale."""
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "segs-slam_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "segs-slam_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -44,10 +55,13 @@ def main():
         if "fetch_bytes_corrected" in e and "write_bytes" in e:
             e["hbm_bytes"] = e["fetch_bytes_corrected"] + e["write_bytes"]
         res[kern] = e
+    res["_kernel_source_sha"] = kernel_source_sha()
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print("| kernel | launches | fetch MB (2x corrected) | write MB | other |")
     print("|---|---|---|---|---|")
     for k, e in res.items():
+        if not isinstance(e, dict):
+            continue
         other = {c: round(v, 1) for c, v in e.items() if c not in ("launches", "FETCH_SIZE", "WRITE_SIZE", "fetch_bytes_corrected", "write_bytes", "hbm_bytes")}
         print(f"| {k} | {e['launches']} | {e.get('fetch_bytes_corrected', 0)/1e6:.2f} | {e.get('write_bytes', 0)/1e6:.2f} | {other} |")
 

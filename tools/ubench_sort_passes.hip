@@ -1,6 +1,6 @@
 // Per-kernel timing of the two device sorts of the binning stage on synthetic keys of the 1080p_3m sizes (measurement
 // only; includes csrc/binning.hip directly so that ABLATE_* variants can be compiled):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude [-DABLATE_SCATTER_LINEAR] tools/ubench_sort_passes.hip -o /tmp/ubench_sort
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -DSEGS_MEASURE [-DABLATE_SCATTER_LINEAR] tools/ubench_sort_passes.hip -o /tmp/ubench_sort
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
