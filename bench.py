@@ -271,6 +271,12 @@ def main():
     dominant = max((k for k in per_step if k != "memset"), key=lambda k: per_step[k])
     sort_names = ("radix_count_kernel", "radix_scan_kernel", "radix_scatter_kernel")
 
+    dist_extra = None
+    if use_dist and args.mode == "raster" and not args.no_extras:
+        try:
+            dist_extra = dist_blocks(world, rank, dev, sharded_opt, args.force_dist)
+        except Exception as e:  # noqa: BLE001  (every rank takes the same path: a failure is one of construction, not of one rank)
+            dist_extra = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         eng.check()
         # The reference's num_rendered R (bounding-square duplication, from the calibrating reference-shaped forward) prices
@@ -375,6 +381,8 @@ def main():
                     out[key] = fn()
                 except Exception as e:  # noqa: BLE001  (extra blocks never fail the bench line)
                     out[key] = {"error": f"{type(e).__name__}: {e}"}
+        if dist_extra is not None:
+            out["keyframe_parallel"] = dist_extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc)
         if args.breakdown:
@@ -457,6 +465,89 @@ def dropin_block(sc, dev, tensors, dL, cpp_dropin, resident_its, steps: int = 50
             "python_reference_shaped": dict(py, what="segs_slam_amd.rasterize_points.RasterizeGaussiansCUDA + RasterizeGaussiansBackwardCUDA "
                                                     "(mirror of src/rasterize_points.cu:36-193 over the C ABI)"),
             "cpp_gaussian_rasterizer": cpp_dropin}
+
+
+def _timed_dist_steps(step_fn, ex_of, world, dev, steps, warmup):
+    """`steps` keyframe-parallel iterations between two barriers (max over ranks), every collective of the exchange bracketed by
+    events on the launch stream.  -> (wall seconds, {collective: {ms per step, bytes per call, bus GB/s}}, exchange ms per step)."""
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step_fn()
+    torch.cuda.synchronize()
+    ex = ex_of()
+    ex.timing = []
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    per = {}
+    for label, a, b, nbytes in ex.timing:
+        e = per.setdefault(label, {"ms": 0.0, "calls": 0, "bytes_per_call": nbytes})
+        e["ms"] += a.elapsed_time(b)
+        e["calls"] += 1
+    ex.timing = None
+    total_ms = 0.0
+    for label, e in per.items():
+        ms = e["ms"] / e["calls"]
+        total_ms += e["ms"] / steps
+        # bus bandwidth as rccl-tests defines it: all-reduce moves 2 (N-1)/N of the buffer per rank, the two halves (N-1)/N
+        factor = (2.0 if label == "all_reduce" else 1.0) * (world - 1) / max(world, 1)
+        per[label] = {"ms_per_call": ms, "calls_per_step": e["calls"] / steps, "bytes_per_call": e["bytes_per_call"],
+                      "bus_GBps": (e["bytes_per_call"] * factor / (ms * 1e-3) / 1e9) if (ms > 0 and world > 1) else None}
+    return float(tt.item()), per, total_ms
+
+
+def dist_blocks(world, rank, dev, sharded_opt, force, steps: int = 40, warmup: int = 8):
+    """N > 1 (or --force-dist): BASELINE's two 8-GPU configurations as blocks of the same line, so that the first scaling run
+    records them and not only the raster headline's 168 MB worst case -- config 5 (anchor-level mapper step, 300 k anchors x 10
+    offsets, 1200x680, ScanNet model dimensions) and config 4 (trainer step over explicit Gaussians, 640x480, TUM intrinsics),
+    one keyframe per rank, the gradient exchange timed by events around its collectives."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from segs_slam_amd import neural_gaussians as ng, scenes
+    from segs_slam_amd.gaussian_trainer import TrainerStep, keyframe_tensors
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    out = {"world_size_reported_by_backend": dist.get_world_size(), "backend": dist.get_backend()}
+    # ---- config 5
+    cam = scenes.make_config_camera("c5", keyframe=rank)
+    dims = ng.ModelDims(appearance_dim=16, use_feat_bank=False)
+    model = ng.synthetic_model(300_000, dims, scenes.make_config_camera("c5"), dev, seed=0)     # identical replicas
+    tstep = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
+    tstep.sharded_optimizer, tstep.single_rank_collectives = sharded_opt, force
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    gt = torch.rand(3, cam.height, cam.width, device=dev)
+    tstep.keyframe_for = lambda step, n: 0
+    wall, per, ex_ms = _timed_dist_steps(lambda: tstep.training_once([kf], [gt]), tstep._exchange, world, dev, steps, warmup)
+    ex = tstep._exchange()
+    out["mapper_step_c5"] = {"workload": f"anchor-level mapper step, {model.A} anchors x 10 offsets, {cam.width}x{cam.height}, appearance_dim 16, "
+                                         "no feature bank, one keyframe per rank",
+                             "iters_per_s": world * steps / wall, "ms_per_step": wall / steps * 1e3, "steps": steps, "warmup": warmup,
+                             "exchange": "reduce-scatter -> sharded Adam -> all-gather" if ex.sharded else "dense all-reduce",
+                             "exchanged_MB": ex.n * 4 / 1e6, "bucket_MB": (ex.offset + ex.n) * 4 / 1e6,
+                             "frozen_anchor_segment_left_out": ex.offset > 0, "exchange_ms_per_step": ex_ms, "collectives": per,
+                             "dropped_steps": tstep.dropped_steps()}
+    del tstep, model
+    torch.cuda.empty_cache()
+    # ---- config 4
+    sc = scenes.make_config_scene("c4", keyframe=rank)
+    ts4 = TrainerStep.on_gpu(sc, dev, sharded_optimizer=sharded_opt, single_rank_collectives=force)
+    kfs, gts = [keyframe_tensors(sc.camera, dev)], [torch.rand(3, sc.camera.height, sc.camera.width, device=dev)]
+    ts4.keyframe_for = lambda step, n: 0
+    wall, per, ex_ms = _timed_dist_steps(lambda: ts4.training_once(kfs, gts), lambda: ts4.exchange, world, dev, steps, warmup)
+    out["trainer_step_c4"] = {"workload": f"trainer step (raster + L1/SSIM + fused Adam), {sc.P} Gaussians, {sc.camera.width}x{sc.camera.height}, one keyframe per rank",
+                              "iters_per_s": world * steps / wall, "ms_per_step": wall / steps * 1e3, "steps": steps, "warmup": warmup,
+                              "exchange": "reduce-scatter -> sharded Adam -> all-gather" if ts4.exchange.sharded else "dense all-reduce",
+                              "exchanged_MB": ts4.exchange.n * 4 / 1e6, "exchange_ms_per_step": ex_ms, "collectives": per}
+    return out
 
 
 def _percentiles(ms):

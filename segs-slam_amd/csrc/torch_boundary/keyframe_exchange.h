@@ -1,7 +1,11 @@
 // keyframe_exchange.h -- the one exchange of a keyframe-parallel mapper iteration in C++, over a c10d backend
 // (c10d::ProcessGroupNCCL = RCCL over xGMI in production; any c10d::Backend works, tests rehearse with Gloo).
 //
-// C++ twin of segs-slam_amd/keyframe_parallel.py::BucketExchange -- same semantics, same names:
+// C++ counterpart of segs-slam_amd/keyframe_parallel.py::BucketExchange -- same method names and the same two exchanges,
+// WITHOUT three refinements of the Python side: the overflow word always takes its own (asynchronous) all-reduce instead of
+// riding in the dense gradient all-reduce, `sharded` is an explicit bool (no "auto" by bucket size), and a frozen anchor
+// segment is exchanged with the rest (no `offset`).  Results are the same; the fixed cost per step is the larger of the two
+// measured in DESIGN.md section 6.
 //   * FLAG: the resident rasterizer's overflow word of every rank, summed asynchronously right after the forward; the summed
 //     word guards statistics and optimizer on the device (segs_training_statis_guarded, segs_adam_step_device), so every
 //     replica drops the same steps and no rank synchronises with its device to find out;

@@ -43,11 +43,20 @@ class BucketExchange:
     AUTO_SHARD_BYTES = 32 << 20
 
     def __init__(self, n: int, device, process_group=None, sharded=True, single_rank_collectives: bool = False,
-                 grads: Optional[torch.Tensor] = None):
+                 grads: Optional[torch.Tensor] = None, offset: int = 0):
+        """`offset`: the exchange covers elements [offset, offset + n) of the buckets handed to reduce_gradients() / gather()
+        (which are then offset + n long); what lies in front -- a frozen segment nobody updates, e.g. the anchor positions
+        under Optimization.position_lr_* = 0 -- never crosses a link.  Ranges (shard_range, clip_segments) stay in
+        whole-bucket coordinates."""
         self.pg = process_group
         self.world, self.rank = _group_info(process_group)
         self.n = int(n)
+        self.offset = int(offset)
+        assert self.offset % self.ALIGN == 0, "the exchanged range must start on a 16-byte boundary"
         self.device = torch.device(device)
+        # measurement support (bench.py): when set to a list, every collective of reduce_gradients() / gather() is bracketed
+        # by two events on the current stream, appended as (label, start, end, bytes)
+        self.timing = None
         if sharded == "auto":
             sharded = self.n * 4 >= self.AUTO_SHARD_BYTES
         # single_rank_collectives: issue every collective even with ONE rank in an initialised group (bench.py --force-dist,
@@ -67,8 +76,8 @@ class BucketExchange:
         # stream -- which is most of the dense exchange's fixed cost on a 0.3 ms step.  `_ext` = the bucket + that element.
         self._ext, self._piggy = None, False
         if grads is not None and self.active and not self.sharded and grads.dtype == torch.float32:
-            st, off = grads.untyped_storage(), grads.storage_offset()
-            if grads.numel() == self.n and grads.is_contiguous() and st.nbytes() >= (off + self.n + 1) * 4:
+            st, off = grads.untyped_storage(), grads.storage_offset() + self.offset
+            if grads.numel() == self.offset + self.n and grads.is_contiguous() and st.nbytes() >= (off + self.n + 1) * 4:
                 self._ext = torch.empty(0, dtype=torch.float32, device=grads.device).set_(st, off, (self.n + 1,))
         if self.sharded:
             f = dict(dtype=torch.float32, device=self.device)
@@ -79,12 +88,13 @@ class BucketExchange:
 
     # ---- ranges
     def shard_range(self, rank: Optional[int] = None) -> Tuple[int, int]:
-        """[lo, hi) of the bucket this rank updates (the whole bucket when not sharded)."""
+        """[lo, hi) of the bucket this rank updates, in whole-bucket coordinates (the whole bucket, the part in front of the
+        exchanged range included, when not sharded)."""
         if not self.sharded:
-            return 0, self.n
+            return 0, self.offset + self.n
         r = self.rank if rank is None else rank
         lo = min(r * self.shard_len, self.n)
-        return lo, min(lo + self.shard_len, self.n)
+        return self.offset + lo, self.offset + min(lo + self.shard_len, self.n)
 
     def clip_segments(self, segments: Sequence[Tuple[int, int, float]]) -> List[Tuple[int, int, float]]:
         """(offset, count, lr) Adam segments intersected with this rank's shard."""
@@ -103,6 +113,7 @@ class BucketExchange:
         only PLACED there (as a float) and summed by reduce_gradients(); `allow_piggyback=False` for the steps that must read
         the summed word on the host before the gradients are exchanged (adjust_anchor iterations)."""
         self._piggy = False
+        self._piggy_summed = False
         if not self.active:
             self._local = local_flag
             return
@@ -121,9 +132,14 @@ class BucketExchange:
         self._flag_work = dist.all_reduce(self.flag, group=self.pg, async_op=True)
 
     def wait_flag(self) -> torch.Tensor:
-        """Make the current stream wait for the flag; returns the device word (non-zero: some rank's pass is invalid)."""
+        """Make the current stream wait for the flag; returns the device word (non-zero: some rank's pass is invalid).
+
+        CONTRACT when the word rides with the gradients (dense exchange, allow_piggyback): the returned view is a FLOAT32
+        element that holds only this rank's own word until reduce_gradients() has run; it is the summed word -- any non-zero
+        bit pattern means drop -- only for work enqueued after that call.  A caller that needs the sum earlier (a host read
+        before the gradient exchange) must pass allow_piggyback=False to reduce_flag_async(); flag_on_host() enforces this."""
         if self._piggy:
-            return self._ext[self.n:]          # holds the sum once reduce_gradients() has run: any non-zero bit pattern = drop
+            return self._ext[self.n:]
         if not self.active:
             if getattr(self, "_local", None) is not None:
                 return self._local
@@ -136,26 +152,47 @@ class BucketExchange:
             self._flag_work = None
         return self.flag
 
+    def flag_on_host(self) -> int:
+        """The summed overflow word read on the host (synchronises).  Refuses to hand out an un-summed word."""
+        if self._piggy and not self._piggy_summed:
+            raise RuntimeError("the overflow word rides with the gradients and has not been summed yet: call reduce_gradients() "
+                               "first, or start the step with reduce_flag_async(..., allow_piggyback=False)")
+        w = self.wait_flag()
+        return int(w.view(torch.int32).item()) if w.dtype == torch.float32 else int(w.item())
+
+    def _timed(self, label: str, nbytes: int, fn):
+        if self.timing is None or self.device.type != "cuda":
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self.timing.append((label, a, b, nbytes))
+        return out
+
     # ---- gradients
     def reduce_gradients(self, grads: torch.Tensor, dense: bool = False):
         """dense (or an unsharded exchange): grads <- sum over ranks (in place).  sharded: grads[lo:hi] <- sum over ranks; the
         rest of the bucket still holds this rank's own contribution and must be cleared by the caller before the next
         backward accumulates.  `dense=True` is for the steps whose shard partition changes between this call and the
         optimizer (a densification that re-sizes the bucket): every element must then hold the sum, whoever updates it."""
-        assert grads.numel() == self.n
+        assert grads.numel() == self.offset + self.n
         if not self.active:
             return
+        if self.offset:
+            grads = grads[self.offset:]
         if self._piggy:
             assert grads.data_ptr() == self._ext.data_ptr(), "the exchange was built for another gradient bucket"
-            dist.all_reduce(self._ext, group=self.pg)      # gradients + the overflow word behind them
+            self._timed("all_reduce", (self.n + 1) * 4, lambda: dist.all_reduce(self._ext, group=self.pg))      # gradients + the overflow word behind them
+            self._piggy_summed = True
             return
         if dense or not self.sharded:
-            dist.all_reduce(grads, group=self.pg)
+            self._timed("all_reduce", self.n * 4, lambda: dist.all_reduce(grads, group=self.pg))
             return
         if self._emulate:
             # same RESULT as the reduce-scatter below, outside the shard included: there the bucket keeps this rank's own
             # contribution (an emulation that left the full sum everywhere would hide a step reading outside its shard)
-            lo, hi = self.shard_range()
+            lo, hi = (x - self.offset for x in self.shard_range())
             own = grads.clone()
             dist.all_reduce(grads, group=self.pg)
             own[lo:hi] = grads[lo:hi]
@@ -165,8 +202,8 @@ class BucketExchange:
         if self._send is not None:
             self._send[:self.n].copy_(grads)
             src = self._send
-        lo, hi = self.shard_range()
-        dist.reduce_scatter_tensor(self._shard, src, group=self.pg)
+        lo, hi = (x - self.offset for x in self.shard_range())
+        self._timed("reduce_scatter", self.shard_len * self.world * 4, lambda: dist.reduce_scatter_tensor(self._shard, src, group=self.pg))
         grads[lo:hi].copy_(self._shard[:hi - lo])
 
     # ---- parameters
@@ -174,8 +211,10 @@ class BucketExchange:
         """bucket <- concatenation of every rank's shard (parameters after the sharded Adam; moments before a densification)."""
         if not self.sharded:
             return
-        assert bucket.numel() == self.n
-        lo, hi = self.shard_range()
+        assert bucket.numel() == self.offset + self.n
+        if self.offset:
+            bucket = bucket[self.offset:]
+        lo, hi = (x - self.offset for x in self.shard_range())
         if hi - lo < self.shard_len:
             self._shard[hi - lo:].zero_()          # (only the last rank's shard has a padded tail)
         self._shard[:hi - lo].copy_(bucket[lo:hi])
@@ -183,10 +222,10 @@ class BucketExchange:
             parts = [torch.empty_like(self._shard) for _ in range(self.world)]
             dist.all_gather(parts, self._shard, group=self.pg)
             for r, part in enumerate(parts):
-                a, b = self.shard_range(r)
+                a, b = (x - self.offset for x in self.shard_range(r))
                 bucket[a:b].copy_(part[:b - a])
         elif self._full is None:
-            dist.all_gather_into_tensor(bucket, self._shard, group=self.pg)
+            self._timed("all_gather", self.shard_len * self.world * 4, lambda: dist.all_gather_into_tensor(bucket, self._shard, group=self.pg))
         else:
-            dist.all_gather_into_tensor(self._full, self._shard, group=self.pg)
+            self._timed("all_gather", self.shard_len * self.world * 4, lambda: dist.all_gather_into_tensor(self._full, self._shard, group=self.pg))
             bucket.copy_(self._full[:self.n])

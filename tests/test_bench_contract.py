@@ -45,6 +45,15 @@ def test_bench_stdout_stays_one_json_line_with_rccl_initialised():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
+    # BASELINE's 8-GPU configurations ride in the same line whenever a process group is up (here: one RCCL rank, every
+    # collective forced), with the exchange timed by events around its collectives
+    kp = d["keyframe_parallel"]
+    assert "error" not in kp, kp
+    assert kp["world_size_reported_by_backend"] == 1 and kp["backend"] == "nccl"
+    c5, c4 = kp["mapper_step_c5"], kp["trainer_step_c4"]
+    assert c5["iters_per_s"] > 0 and c5["frozen_anchor_segment_left_out"] and c5["exchanged_MB"] < c5["bucket_MB"]
+    assert c5["exchange_ms_per_step"] > 0 and c5["collectives"] and c5["dropped_steps"] == 0
+    assert c4["iters_per_s"] > 0 and c4["exchange_ms_per_step"] > 0
 
 
 @pytest.mark.gpu
@@ -61,4 +70,8 @@ def test_bench_starts_its_own_ranks_without_a_launcher(mode):
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and "cpu_baseline" not in d
+    if mode == "raster":
+        kp = d["keyframe_parallel"]
+        assert "error" not in kp and kp["world_size_reported_by_backend"] == 2, kp
+        assert kp["mapper_step_c5"]["iters_per_s"] > 0 and kp["trainer_step_c4"]["iters_per_s"] > 0
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
