@@ -150,6 +150,22 @@ GaussianTrainerStep::GaussianTrainerStep(int64_t num_anchors, const ScaffoldDims
 
 GaussianTrainerStep::~GaussianTrainerStep() {
   if (status_event_) (void)hipEventDestroy((hipEvent_t)status_event_);
+  if (freq_.plan) segs_freq_plan_destroy(freq_.plan);
+}
+
+void GaussianTrainerStep::enable_frequency_regularization(float lambda_high, const std::vector<float>& scales, int64_t start,
+                                                          int64_t until, bool multi_resolution) {
+  if (freq_.plan) { segs_freq_plan_destroy(freq_.plan); freq_.plan = nullptr; }
+  freq_.targets.clear();
+  freq_.on = lambda_high != 0.f;
+  freq_.lambda_high = lambda_high;
+  freq_.multi = multi_resolution;
+  freq_.scales = multi_resolution ? scales : std::vector<float>{1.0f};   // high_frequency_loss = the s = 1 term with weight 1
+  freq_.start = start;
+  freq_.until = until;
+  if (!freq_.on) return;
+  check(segs_freq_plan_create(H_, W_, (int)freq_.scales.size(), freq_.scales.data(), lambda_high, &freq_.plan), "segs_freq_plan_create");
+  freq_value_ = torch::zeros({1}, torch::TensorOptions().dtype(torch::kFloat32).device(dev_));
 }
 
 // candidate-domain buffers (capacity * n_offsets rows) and the rasterizer's per-Gaussian outputs; re-made when the map
@@ -301,6 +317,17 @@ void GaussianTrainerStep::forward_backward(const KeyframeView& kf, const torch::
   check(segs_l1_ssim_loss(fp(out_color_), fp(gt_image), H_, W_, (float)opt_.lambda_dssim, fp(loss_out_), fp(dL_dimage_),
                           (char*)loss_temp_.data_ptr(), st),
         "segs_l1_ssim_loss");
+  if (freq_.on && iteration_ > freq_.start && iteration_ < freq_.until) {   // src/gaussian_mapper.cpp:938
+    auto hit = freq_.targets.find(gt_image.data_ptr());
+    if (hit == freq_.targets.end()) {
+      if (freq_.targets.size() >= 1024) freq_.targets.clear();
+      auto tab = torch::empty({(int64_t)segs_freq_target_floats(freq_.plan)}, torch::TensorOptions().dtype(torch::kFloat32).device(dev_));
+      check(segs_freq_target(freq_.plan, fp(gt_image), fp(tab), st), "segs_freq_target");
+      hit = freq_.targets.emplace(gt_image.data_ptr(), tab).first;
+    }
+    check(segs_freq_loss(freq_.plan, fp(out_color_), fp(hit->second), fp(dL_dimage_), fp(freq_value_), fp(loss_out_), st), "segs_freq_loss");
+  }
+  if (dL_mask_.defined()) dL_dimage_.mul_(dL_mask_);
   if (last_resident_) {
     check(segs_rasterize_backward_resident((char*)geom_r_.data_ptr(), (char*)binning_r_.data_ptr(), (char*)img_r_.data_ptr(), capacity_,
                                            (int)rows, (int)P, 0, 0, fp(bg_), W_, H_, fp(means3D_), nullptr, fp(scales_), 1.0f, fp(rotations_),
@@ -370,6 +397,7 @@ torch::Tensor GaussianTrainerStep::trainingOnce(const KeyframeView& kf, const to
   // a densification may re-size the bucket, so the shard partition the optimizer clips to below is not the one a
   // reduce-scatter would have summed for: every element gets the full sum on those steps
   exchange().reduce_gradients(model_.grads, adjust_now);
+  if (on_gradients) on_gradients(model_.grads);
   bool adjusted = false;
   if (in_stat_window) {
     d->training_statis(neural_opacity_, visible_radii_, radii_, dL_dmean2D_, guard, world() > 1, cur_stream(dev_));

@@ -18,6 +18,7 @@
 
 #include <torch/csrc/distributed/c10d/Backend.hpp>
 
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -119,6 +120,21 @@ class GaussianTrainerStep {
   // Nothing in it waits for the device except the first, calibrating pass and the adjust_anchor iterations.
   torch::Tensor trainingOnce(const KeyframeView& kf, const torch::Tensor& gt_image);
 
+  // The mapper's frequency regulariser (src/gaussian_mapper.cpp:930-945; Mapper.* keys of the configuration): between
+  // iterations `start` and `until` (exclusive, as :938) loss += lambda_high * multi_scale_loss(image, gt, scales) -- or
+  // high_frequency_loss when not multi_resolution -- through the plan entry points of segs_train.h (hipFFT inside the library,
+  // |FFT(gt)| cached per target tensor).  low_freq_loss has a zero gradient in the reference and
+  // lambda_low = 0 in every shipped configuration: not evaluated here.
+  void enable_frequency_regularization(float lambda_high, const std::vector<float>& scales, int64_t start, int64_t until,
+                                       bool multi_resolution = true);
+  torch::Tensor frequency_loss() { return freq_value_; }   // value of the regulariser in the last iteration (1 device float)
+
+  // test support: dL/dimage is multiplied by this (H,W) mask before the raster backward (the parity tests blank the pixels
+  // whose compositing decisions sit on a threshold, on both sides); and a callback that sees the gradient bucket exactly as
+  // the optimizer receives it (after the exchange, before Adam clears it)
+  void set_image_gradient_mask(const torch::Tensor& mask_hw) { dL_mask_ = mask_hw; }
+  std::function<void(const torch::Tensor&)> on_gradients;
+
   torch::Tensor image() { return out_color_; }
   torch::Tensor scaling_reg() { return scaling_reg_; }
   int64_t iteration() const { return iteration_; }
@@ -172,7 +188,15 @@ class GaussianTrainerStep {
   bool last_resident_ = false, status_pending_ = false;
   void* status_event_ = nullptr;
   // loss
-  torch::Tensor loss_temp_, loss_out_, dL_dimage_, scaling_reg_;
+  torch::Tensor loss_temp_, loss_out_, dL_dimage_, scaling_reg_, dL_mask_, freq_value_;
+  struct FreqReg {
+    bool on = false, multi = true;
+    float lambda_high = 0.f;
+    std::vector<float> scales;
+    int64_t start = 0, until = 0;
+    segs_freq_plan* plan = nullptr;
+    std::map<const void*, torch::Tensor> targets;   // |FFT(gt)| tables per target tensor (a keyframe's image does not change)
+  } freq_;
 };
 
 }  // namespace segs_host

@@ -131,6 +131,57 @@ static int run_single(const char* in, const char* out) {
   return 0;
 }
 
+// trainer_test --chain <in.bin> <out.bin>: what tests/test_cpp_trainer.py needs to hold the C++ host against the float64 /
+// oracle chain DIRECTLY (not through the Python step): in.bin as for the plain mode, followed by a (H,W) float mask that
+// dL/dimage is multiplied with (the oracle's stable pixels) and int32 freq_start, freq_until + float lambda_high (0 = no
+// frequency regulariser; scales 1, 1/2, 1/4).  out.bin per step: loss, scaling_reg, freq_loss ; then per step the gradient
+// bucket as the optimizer received it and the parameter bucket after the step ; visible_radii (A) as float, image of the
+// FIRST step (3,H,W).
+static int run_chain(const char* in, const char* out) {
+  std::ifstream f(in, std::ios::binary);
+  int32_t hdr[6]; float tf[3];
+  f.read(reinterpret_cast<char*>(hdr), sizeof(hdr));
+  f.read(reinterpret_cast<char*>(tf), sizeof(tf));
+  const int A = hdr[0], W = hdr[1], H = hdr[2], n_steps = hdr[5];
+  segs_host::ScaffoldDims dims;
+  dims.appearance_dim = hdr[3];
+  dims.use_feat_bank = hdr[4] != 0;
+  segs_host::GaussianTrainerStep step(A, dims, W, H, torch::Device(torch::kCUDA, 0), segs_host::ScaffoldOptimization(), tf[2]);
+  step.param("anchor").copy_(rd(f, {A, 3}));
+  step.param("offset").copy_(rd(f, {A, dims.n_offsets, 3}));
+  step.param("anchor_feat").copy_(rd(f, {A, dims.feat_dim}));
+  step.param("scaling").copy_(rd(f, {A, 6}));
+  step.mlp_params().copy_(rd(f, {step.mlp_params().numel()}));
+  segs_host::KeyframeView kf;
+  kf.view = rd(f, {4, 4}); kf.proj = rd(f, {4, 4}); kf.campos = rd(f, {3}); kf.pose7 = rd(f, {7});
+  kf.tanfovx = tf[0]; kf.tanfovy = tf[1];
+  auto gt = rd(f, {3, H, W});
+  step.set_image_gradient_mask(rd(f, {H, W}));
+  int32_t fr[2]; float lam;
+  f.read(reinterpret_cast<char*>(fr), sizeof(fr));
+  f.read(reinterpret_cast<char*>(&lam), 4);
+  if (lam != 0.f) step.enable_frequency_regularization(lam, {1.0f, 0.5f, 0.25f}, fr[0], fr[1], true);
+  std::vector<torch::Tensor> grads, params;
+  step.on_gradients = [&](const torch::Tensor& g) { grads.push_back(g.clone()); };
+  std::vector<float> scal;
+  torch::Tensor first_image, first_radii;
+  for (int it = 0; it < n_steps; it++) {
+    auto loss = step.trainingOnce(kf, gt);
+    scal.push_back(loss.item<float>());
+    scal.push_back(step.scaling_reg().item<float>());
+    scal.push_back(lam != 0.f ? step.frequency_loss().item<float>() : 0.f);
+    params.push_back(step.params_flat().clone());
+    if (it == 0) { first_image = step.image().clone(); first_radii = step.visible_radii().slice(0, 0, A).clone(); }
+  }
+  torch::cuda::synchronize();
+  std::ofstream o(out, std::ios::binary);
+  o.write(reinterpret_cast<const char*>(scal.data()), scal.size() * 4);
+  for (int it = 0; it < n_steps; it++) { wr(o, grads[it]); wr(o, params[it]); }
+  wr(o, first_radii); wr(o, first_image);
+  std::printf("trainer_test --chain ok A=%d %dx%d steps=%d\n", A, W, H, n_steps);
+  return 0;
+}
+
 static int run_mapper(int argc, char** argv) {
   const char* in = argv[2];
   const char* out = argv[3];
@@ -213,6 +264,7 @@ static int run_mapper(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   if (argc >= 4 && std::string(argv[1]) == "--mapper") return run_mapper(argc, argv);
+  if (argc >= 4 && std::string(argv[1]) == "--chain") return run_chain(argv[2], argv[3]);
   if (argc < 3) { std::fprintf(stderr, "usage: trainer_test in.bin out.bin | trainer_test --mapper in.bin out.bin [...]\n"); return 2; }
   return run_single(argv[1], argv[2]);
 }

@@ -226,3 +226,108 @@ def test_cpp_exchange_through_a_one_rank_rccl_group(tmp_path):
     assert a["steps"] == b["steps"] == (c["n_steps"], c["n_steps"] - 1)
     assert list(a["sizes"][:9]) == list(b["sizes"][:9]) and abs(a["A"] - b["A"]) <= 0.005 * a["A"]
     np.testing.assert_allclose(a["losses"][:10], b["losses"][:10], rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,freq", [("replica", True), ("scannet", False)])
+def test_cpp_trainer_matches_the_oracle_chain_directly(tmp_path, cfg, freq):
+    """The C++ host against the float64 / oracle chain itself (tests/test_step_parity_gpu.py::ReferenceScaffoldStep), not
+    through the Python step -- an error common to both hosts' use of the C ABI would pass a host-against-host comparison.
+    `trainer_test --chain` runs two iterations and dumps, per iteration, the gradient bucket as its optimizer received it and
+    the parameters afterwards.  First iteration: anchor visibility exact, loss 1e-5, image and every bucket gradient at the
+    raster bar against the chain.  Both iterations: torch.optim.Adam fed the C++ host's own bucket gradient must land on its
+    parameters (every live entry, 1e-3 of the update: parameters are stored in float32, a 5e-3 step on a 0.5 value carries 1e-5 of
+    rounding by itself).  With `freq`, the Replica configuration's frequency regulariser is on
+    in C++ (segs_freq_* plan API) and is added to the chain with the torch.fft mirror + float64 autograd."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_step_parity_gpu import DIMS, ReferenceScaffoldStep, _grad_check
+    from segs_slam_amd import loss_utils, neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    W, H, A, n_steps, reg = 320, 240, 3000, 2, 0.01
+    cam = scenes.make_camera(W, H, 300.0, 300.0, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+    dims = ng.ModelDims(**DIMS[cfg])
+    model = ng.synthetic_model(A, dims, cam, dev, seed=21)
+    pose7 = (0.1, -0.05, 0.02, 0.98, 0.05, -0.1, 0.15)
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(11))
+    lam_f = 0.01 if freq else 0.0
+
+    opt = ng.ScaffoldOptimizationParams()
+    ref = ReferenceScaffoldStep(model, DIMS[cfg], cam, opt.lambda_dssim, reg)
+    ref.sync_params(model)
+    loss_ref, image_ref, unstable = ref.forward(gt, pose7)
+
+    fin, fout = tmp_path / "chain_in.bin", tmp_path / "chain_out.bin"
+    with open(fin, "wb") as f:
+        np.array([A, W, H, dims.appearance_dim, int(dims.use_feat_bank), n_steps], np.int32).tofile(f)
+        np.array([cam.tanfovx, cam.tanfovy, reg], np.float32).tofile(f)
+        for name in ("anchor", "offset", "anchor_feat", "scaling"):
+            model.param(name).cpu().numpy().astype(np.float32).tofile(f)
+        model.mlp_params.cpu().numpy().astype(np.float32).tofile(f)
+        for a in (cam.world_view_transform, cam.full_proj_transform, cam.camera_center, np.array(pose7, np.float32), gt.numpy(),
+                  (~unstable).float().numpy()):
+            np.ascontiguousarray(a, np.float32).tofile(f)
+        np.array([0, 1000], np.int32).tofile(f)
+        np.array([lam_f], np.float32).tofile(f)
+    subprocess.check_call([os.path.join(TB, "trainer_test"), "--chain", str(fin), str(fout)])
+    raw = np.fromfile(fout, np.float32)
+    n = model.params.numel()
+    scal = raw[:3 * n_steps].reshape(n_steps, 3)
+    pos = 3 * n_steps
+    g_cpp, p_cpp = [], []
+    for _ in range(n_steps):
+        g_cpp.append(raw[pos:pos + n]); p_cpp.append(raw[pos + n:pos + 2 * n]); pos += 2 * n
+    radii_cpp = raw[pos:pos + A].astype(np.int32); pos += A
+    img_cpp = raw[pos:pos + 3 * H * W].reshape(3, H, W)
+
+    # ---- first iteration against the chain
+    if freq:
+        # The regulariser of src/gaussian_mapper.cpp:938-945 in float64 (torch.fft mirror + autograd), evaluated AT THE C++
+        # HOST'S IMAGE: its gradient is discontinuous wherever a spectrum magnitude crosses the target's (frequency_loss.py),
+        # and the oracle's image differs from the device's by up to 1e-4 -- enough to flip the sign of a handful of the
+        # 230 k frequencies, each of which moves dL/dimage by 0.6 % everywhere.  The rest of the chain stays at the oracle's image.
+        img64 = torch.from_numpy(img_cpp.copy()).double().requires_grad_(True)
+        fl = lam_f * loss_utils.multi_scale_loss(img64, gt.double(), (1.0, 0.5, 0.25))
+        (gfl,) = torch.autograd.grad(fl, img64)
+        ref.dL = ref.dL + gfl
+        loss_ref += float(fl)
+        assert abs(float(scal[0, 2]) - float(fl)) <= 1e-5 * float(fl)
+    grads_ref = ref.backward()
+    assert np.array_equal(radii_cpp, ref.radii), "prefilter_voxel radii differ"
+    total = float(scal[0, 0]) + float(scal[0, 1])      # trainingOnce's word holds L1/SSIM (+ the frequency term); the scaling regulariser is separate
+    assert abs(total - loss_ref) <= 1e-5 * abs(loss_ref), (total, loss_ref)
+    ok = ~unstable.numpy()
+    assert np.all(np.abs(img_cpp - image_ref.numpy())[:, ok] <= 1e-4 * np.abs(image_ref.numpy())[:, ok] + 2e-5)
+    g0 = torch.from_numpy(g_cpp[0].copy())
+    for name in list(ref.p) + list(ref.mlp):
+        got = model._view(g0, name).numpy()
+        _grad_check(f"{name} (C++ host)", got, grads_ref[name].reshape(got.shape))
+
+    # ---- both iterations: the optimizer, fed the C++ host's own gradient
+    adam = ReferenceScaffoldStep(model, DIMS[cfg], cam, opt.lambda_dssim, reg)
+    step_lr = ng.ScaffoldTrainerStep(model, W, H, opt)        # (only for learning_rates(): the schedule of updateLearningRate)
+    p_before = model.params.cpu().numpy().copy()
+    live = np.zeros(n, dtype=bool)
+    for name in ("anchor", "offset", "anchor_feat", "scaling"):
+        o, cnt = model.segments[name]
+        live[o:o + cnt] = True
+    live[model.mlp_offset:] = True
+    for it in range(n_steps):
+        adam.sync_params_from_flat(model, p_before)
+        gt_it = torch.from_numpy(g_cpp[it].copy())
+        adam.adam({nm: model._view(gt_it, nm).numpy() for nm in list(adam.p) + list(adam.mlp)}, step_lr.learning_rates(it + 1))
+        p_ref = np.zeros(n, np.float32)
+        v = torch.from_numpy(p_ref)
+        for nm in adam.p:
+            model._view(v, nm).copy_(adam.p[nm].reshape(model._view(v, nm).shape))
+        for nm in adam.mlp:
+            model._view(v, nm).copy_(adam.mlp[nm])
+        upd_cpp, upd_ref = (p_cpp[it] - p_before)[live], (p_ref - p_before)[live]
+        off = np.abs(upd_cpp - upd_ref) > 1e-3 * np.abs(upd_ref) + 1.2e-7 * np.abs(p_before[live]) + 1e-9    # (+ one float32 ulp of the parameter itself)
+        if off.any():
+            idx = np.flatnonzero(live)[off]
+            seg = {nm: int(((idx >= o) & (idx < o + c)).sum()) for nm, (o, c) in list(model.segments.items()) + [("mlp", (model.mlp_offset, model.mlp_total))]}
+            worst = np.argmax(np.abs(upd_cpp - upd_ref))
+            raise AssertionError((it, int(off.sum()), seg, float(upd_cpp[worst]), float(upd_ref[worst])))
+        assert float((upd_ref != 0).mean()) > 0.7
+        p_before = p_cpp[it].copy()

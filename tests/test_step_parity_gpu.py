@@ -81,6 +81,18 @@ class ReferenceScaffoldStep:
                 for n, q in self.params.items():
                     q.copy_((self.p if n in self.p else self.mlp)[n])
 
+    def sync_params_from_flat(self, model, flat: np.ndarray):
+        """Parameters of an Adam-only instance <- a host copy of the model's bucket (the optimizer state stays this chain's)."""
+        t = torch.from_numpy(flat)
+        for n in self.p:
+            self.p[n] = model._view(t, n).clone()
+        for n in self.mlp:
+            self.mlp[n] = model._view(t, n).clone()
+        if self.opt is not None:
+            with torch.no_grad():
+                for n, q in self.params.items():
+                    q.copy_((self.p if n in self.p else self.mlp)[n].reshape(q.shape))
+
     def visible(self):
         cam = self.cam
         return gs_oracle.visible_filter(self.p["anchor"].numpy(), self.exp_scales, self.rotation.numpy(), 1.0,
@@ -176,6 +188,9 @@ def test_scaffold_training_once_matches_reference_chain(cfg):
     model = ng.synthetic_model(A, dims, cam, dev, seed=21)
     step = ng.ScaffoldTrainerStep(model, W, H, scaling_reg_weight=0.01)
     ref = ReferenceScaffoldStep(model, DIMS[cfg], cam, step.opt.lambda_dssim, 0.01)
+    # a second torch.optim.Adam that is fed the DEVICE's own bucket gradient: the optimizer wiring (groups, learning rates,
+    # step counts, bias corrections, eps) checked on every live parameter, independent of gradient noise (see below)
+    ref_same_grad = ReferenceScaffoldStep(model, DIMS[cfg], cam, step.opt.lambda_dssim, 0.01)
     p_init = model.params.cpu().numpy().copy()
 
     # the step's loss object, with dL/dimage zeroed on the reference's unstable pixels (set before each iteration)
@@ -231,6 +246,8 @@ def test_scaffold_training_once_matches_reference_chain(cfg):
         this_zero = (gref_flat.numpy() == 0) & (gflat == 0)
         zero_both = this_zero if zero_both is None else (zero_both & this_zero)
         ref.adam(grads_ref, step.learning_rates(step.iteration))
+        ref_same_grad.sync_params_from_flat(model, p_before)
+        ref_same_grad.adam({n: model._view(g, n).cpu().numpy() for n in list(ref.p) + list(ref.mlp)}, step.learning_rates(step.iteration))
     assert step._mlp_count.value() == 2
     # the second step's update (first and second moments carry the first step's gradient)
     p_init = p_before
@@ -257,12 +274,27 @@ def test_scaffold_training_once_matches_reference_chain(cfg):
     upd, upd_ref = (p_gpu - p_init)[solid], (p_ref - p_init)[solid]
     bad = np.abs(upd - upd_ref) > 1e-3 * np.abs(upd_ref) + 2e-7
     assert bad.mean() < 1e-4, (float(bad.mean()), float(np.abs(upd - upd_ref).max()), float(np.abs(upd_ref).max()))
-    covered = float((zero_both | solid)[live].mean())
-    # measured on this scene: 58 % solid, 24 % zero, 18 % noise (offsets of Gaussians a few pixels see)
-    assert covered > 0.80 and solid[live].mean() > 0.50, (covered, float(solid[live].mean()), float(zero_both[live].mean()))
     noise = live & ~zero_both & ~solid
     lr_max = max(step.learning_rates(step.iteration).values())
     assert np.all(np.abs(p_gpu - p_init)[noise] <= 2.0 * lr_max * 1.001), float(np.abs(p_gpu - p_init)[noise].max())
+    # How much of the bucket the oracle-gradient comparison above can speak for is a property of the scene, not of the code:
+    # 58 % solid, 24 % zero, 18 % noise here (offsets of Gaussians a few pixels see).  Round 3 asserted "covered > 0.90", saw
+    # 0.823 on the GPU box and lowered the bound to 0.80 / 0.50 -- a threshold fitted to its own measurement.  It is printed
+    # now, not asserted; what IS asserted for every live parameter is the optimizer itself: torch.optim.Adam fed the bucket
+    # gradient the device's Adam received must land on the device's parameters (1e-3 of the update + 1e-9: two float32
+    # evaluations of LibTorch's formula), for both steps' moments, all groups, all learning rates.
+    print(f"oracle-gradient Adam comparison covers {float((zero_both | solid)[live].mean()):.3f} of the live parameters "
+          f"(solid {float(solid[live].mean()):.3f}, zero {float(zero_both[live].mean()):.3f})")
+    p_same = np.zeros_like(p_gpu)
+    same_view = torch.from_numpy(p_same)
+    for name in ("anchor", "offset", "anchor_feat", "scaling"):
+        model._view(same_view, name).copy_(ref_same_grad.p[name].reshape(model._view(same_view, name).shape))
+    for name in model.mlp_layout:
+        model._view(same_view, name).copy_(ref_same_grad.mlp[name])
+    upd_dev, upd_same = (p_gpu - p_init)[live], (p_same - p_init)[live]
+    off = np.abs(upd_dev - upd_same) > 1e-3 * np.abs(upd_same) + 1.2e-7 * np.abs(p_init[live]) + 1e-9    # (+ one float32 ulp of the parameter itself)
+    assert not off.any(), (int(off.sum()), int(live.sum()), float(np.abs(upd_dev - upd_same).max()))
+    assert float((upd_same != 0).mean()) > 0.7      # and it is not a comparison of zeros
 
 
 def test_config4_trainer_step_gradients_match_oracle():
