@@ -71,7 +71,8 @@ def parse_args():
     ap.add_argument("--sync-forward", action="store_true",
                     help="use the reference-shaped forward that blocks on a D2H copy of num_rendered every step "
                          "(default: resident no-sync entry points after one calibrating step)")
-    ap.add_argument("--graph", action="store_true", help="replay the resident fwd+bwd from a captured hipGraph (N=1 only); the "
+    ap.add_argument("--graph", action="store_true", help="N=1 only: replay the step from a captured hipGraph -- raster mode: the resident "
+                    "fwd+bwd; trainer / scaffold mode: the whole iteration (staging buffers for keyframe, target and learning rates). The "
                     "dominant kernel's HIP-event timing then comes from the profiled steps after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -234,6 +235,14 @@ def main():
     # ---- timed region: exactly K steps, barrier + sync on both sides; the tile kernels are timed live with HIP events on
     # their launch stream inside this region
     graph = None
+    step_graph = bool(args.graph and world == 1 and tstep is not None)
+    if step_graph:
+        # trainer / scaffold modes: the step object replays its own whole-iteration graph (enable_graph); a few more steps so
+        # that the capture itself happens before the timed region
+        tstep.enable_graph(True)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
     if args.graph and world == 1 and args.mode == "raster" and not args.sync_forward:
         eng.check()
         graph = torch.cuda.CUDAGraph()
@@ -242,7 +251,7 @@ def main():
         torch.cuda.synchronize()
     fence()
     step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one record per step: p10 / p50 / p90
-    with KernelProfile(LIVE_EVENT_KERNELS if graph is None else []) as prof_live:
+    with KernelProfile(LIVE_EVENT_KERNELS if (graph is None and not step_graph) else []) as prof_live:
         t0 = time.perf_counter()
         step_events[0].record()
         for i in range(args.steps):
@@ -262,6 +271,9 @@ def main():
     # ---- per-kernel table: the same steady-state steps once more, every kernel bracketed by HIP events (not in the timed
     # region: two event records per kernel would perturb it)
     n_prof = max(1, min(args.steps, 20))
+    replays = getattr(tstep, "graph_replays", 0) if step_graph else 0
+    if step_graph:
+        tstep.enable_graph(False)      # the per-kernel table needs the eager launches (events cannot go inside a replay)
     with KernelProfile() as prof_all:
         for _ in range(n_prof):
             step()
@@ -329,7 +341,9 @@ def main():
                        "P": eng.P_active, "P_visible": P_vis, "num_rendered": R_ref, "instances_binned": eng.R, "instances_live": R_live,
                        "width": cam.width, "height": cam.height,
                        "sort_passes": {"depth_keys_P": passes_depth, "tile_keys_R": passes_tile}, "parallelism": f"keyframe-dp{world}",
-                       "forward": "sync (reference API)" if args.sync_forward else "resident (no host sync)"},
+                       "forward": "sync (reference API)" if args.sync_forward else "resident (no host sync)",
+                       "hipgraph": (f"whole iteration replayed from a captured hipGraph ({replays} replays)" if step_graph else
+                                    ("resident fwd+bwd replayed from a captured hipGraph" if graph is not None else "off"))},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc.get("hbm_bytes") if pmc else None, "traffic_source": pmc_src,
                          "traffic_stale": pmc.get("stale") if pmc else None,

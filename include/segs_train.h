@@ -53,6 +53,19 @@ int segs_adam_step_device(float* param, float* grad, float* exp_avg, float* exp_
                           double beta1, double beta2, double eps, int64_t* device_steps, int call_index,
                           float grad_scale, int zero_grad, const uint32_t* skip_flag, void* stream);
 
+/* hipGraph-capturable form of segs_adam_step_device: nothing in the launch depends on a host value that changes from step to
+ * step, so a captured iteration can be replayed.  The learning rates are read from DEVICE memory (device_lr[i] for segment i;
+ * segments[i].lr is ignored) and the parity of the step-count pair is a third device word: device_steps3 points at THREE int64
+ * words, [0], [1] the pair of segs_adam_step_device and [2] = number of calls so far (its low bit says which word holds the
+ * count), flipped by a one-thread kernel behind the update.  A caller that alternates between the two forms keeps [2] equal
+ * to its own call count.  segs_set_doubles writes up to 16 host doubles into device memory through kernel arguments (they are
+ * copied at launch time: no pinned staging buffer to keep alive, nothing to wait for) -- the learning-rate refresh before a
+ * replay. */
+int segs_adam_step_graph(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments, int nseg,
+                         const double* device_lr, double beta1, double beta2, double eps, int64_t* device_steps3,
+                         float grad_scale, int zero_grad, const uint32_t* skip_flag, void* stream);
+int segs_set_doubles(double* device_dst, const double* host_values, int n, void* stream);
+
 /* Fused L1 + SSIM loss of the trainer/mapper step and its gradient w.r.t. the rendered image:
  *     loss = (1 - lambda) * mean|img1 - img2| + lambda * (1 - mean(SSIM(img1, img2)))
  * (src/gaussian_trainer.cpp:89-90, src/gaussian_mapper.cpp:924-928 with loss_utils::l1_loss / ssim,

@@ -88,6 +88,8 @@ SYMBOLS = {
     "segs_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_int64, _f, _i, _vp]),
     "segs_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, C.c_int64, _f, _i, _vp, _vp]),
     "segs_adam_step_device": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_double, C.c_double, C.c_double, _vp, _i, _f, _i, _vp, _vp]),
+    "segs_adam_step_graph": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, C.c_double, C.c_double, C.c_double, _vp, _f, _i, _vp, _vp]),
+    "segs_set_doubles": (_i, [_vp, _vp, _i, _vp]),
     "segs_profile_begin": (_i, [C.c_uint]),
     "segs_profile_end": (_i, []),
     "segs_profile_kernel_count": (_i, []),

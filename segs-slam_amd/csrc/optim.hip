@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
                                                    float* __restrict__ v, SegTable tab, float b1, float b2, float omb1, float omb2,
                                                    float sqrt_bc2, float eps, float gscale, int zero_grad,
                                                    const uint32_t* __restrict__ skip_flag, long long* __restrict__ steps, int parity,
-                                                   double beta1, double beta2) {
+                                                   double beta1, double beta2, const double* __restrict__ device_lr) {
   // guarded step: the gradients of an iteration the resident rasterizer flagged as overflowed are discarded on the
   // device (parameters and moments untouched, gradient bucket cleared) without the host having to look first
   const bool skip = skip_flag != nullptr && *skip_flag != 0u;
@@ -59,10 +59,13 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
   if (DEVICE_STEP) {
     __shared__ float s_ss, s_sqrt_bc2;
     if (threadIdx.x == 0) {
+      // parity < 0 (segs_adam_step_graph): which word of the pair holds the count is itself a device word, steps[2], flipped by
+      // adam_flip_kernel behind this launch -- so that the same launch can be replayed from a hipGraph step after step
+      if (parity < 0) parity = (int)(steps[2] & 1);
       const long long done = steps[parity];
       const double t = (double)(done + 1);
       const double bc1 = 1.0 - pow(beta1, t), bc2 = 1.0 - pow(beta2, t);
-      s_ss = (float)(tab.lr[s] / bc1);
+      s_ss = (float)((device_lr ? device_lr[s] : tab.lr[s]) / bc1);
       s_sqrt_bc2 = (float)sqrt(bc2);
       if (blockIdx.x == 0) steps[parity ^ 1] = skip ? done : done + 1;
     }
@@ -119,12 +122,19 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
     }
   }
 }
+
+__global__ void adam_flip_kernel(long long* steps) { steps[2] += 1; }
+template <int N>
+struct Doubles { double v[N]; };
+__global__ void set_doubles_kernel(double* dst, Doubles<16> vals, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
 }  // namespace
 
 namespace {
 int adam_launch(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments, int nseg,
                 double beta1, double beta2, double eps, int64_t step, float grad_scale, int zero_grad, const uint32_t* skip_flag,
-                long long* device_steps, int parity, void* stream) {
+                long long* device_steps, int parity, void* stream, const double* device_lr = nullptr) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !segments || nseg <= 0 || nseg > MAX_SEG || (!device_steps && step <= 0))
     return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   SegTable tab{};
@@ -154,11 +164,13 @@ int adam_launch(float* param, float* grad, float* exp_avg, float* exp_avg_sq, co
   if (device_steps)
     adam_kernel<true><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, tab, (float)beta1, (float)beta2,
                                                                     (float)(1.0 - beta1), (float)(1.0 - beta2), sqrt_bc2, (float)eps,
-                                                                    grad_scale, zero_grad, skip_flag, device_steps, parity & 1, beta1, beta2);
+                                                                    grad_scale, zero_grad, skip_flag, device_steps, parity < 0 ? -1 : (parity & 1), beta1, beta2,
+                                                                    device_lr);
   else
     adam_kernel<false><<<(int)blocks, 256, 0, (hipStream_t)stream>>>(param, grad, exp_avg, exp_avg_sq, tab, (float)beta1, (float)beta2,
                                                                      (float)(1.0 - beta1), (float)(1.0 - beta2), sqrt_bc2, (float)eps,
-                                                                     grad_scale, zero_grad, skip_flag, nullptr, 0, beta1, beta2);
+                                                                     grad_scale, zero_grad, skip_flag, nullptr, 0, beta1, beta2, nullptr);
+  if (device_steps && parity < 0) adam_flip_kernel<<<1, 1, 0, (hipStream_t)stream>>>(device_steps);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }
@@ -184,4 +196,22 @@ extern "C" int segs_adam_step(float* param, float* grad, float* exp_avg, float* 
                               void* stream) {
   return segs_adam_step_guarded(param, grad, exp_avg, exp_avg_sq, segments, nseg, beta1, beta2, eps, step, grad_scale, zero_grad,
                                 nullptr, stream);
+}
+
+extern "C" int segs_adam_step_graph(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const segs_adam_segment* segments,
+                                    int nseg, const double* device_lr, double beta1, double beta2, double eps, int64_t* device_steps3,
+                                    float grad_scale, int zero_grad, const uint32_t* skip_flag, void* stream) {
+  if (!device_steps3 || !device_lr) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "null device step state / learning-rate table");
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, segments, nseg, beta1, beta2, eps, 0, grad_scale, zero_grad, skip_flag,
+                     (long long*)device_steps3, -1, stream, device_lr);
+}
+
+extern "C" int segs_set_doubles(double* device_dst, const double* host_values, int n, void* stream) {
+  if (!device_dst || !host_values || n < 0 || n > 16) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "segs_set_doubles: null pointer or n > 16");
+  if (n == 0) return SEGS_OK;
+  Doubles<16> vals{};
+  for (int i = 0; i < n; i++) vals.v[i] = host_values[i];
+  set_doubles_kernel<<<1, 64, 0, (hipStream_t)stream>>>(device_dst, vals, n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }

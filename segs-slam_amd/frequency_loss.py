@@ -136,6 +136,21 @@ class FusedFrequencyLoss:
             self._targets.popitem(last=False)
         return hit
 
+    def target_block(self, gt: torch.Tensor) -> torch.Tensor:
+        """The flat |FFT| table block of `gt` (plan path): what apply() reads."""
+        assert self._plan is not None
+        return self.target_magnitudes(gt)[0]
+
+    def apply(self, image: torch.Tensor, target_block: torch.Tensor, dL_inout: torch.Tensor, loss_inout: Optional[torch.Tensor] = None):
+        """__call__ with the target tables handed in (plan path, lambda_low = 0): a fixed launch sequence over fixed addresses,
+        i.e. what a captured iteration replays; the caller copies the keyframe's block into its staging buffer beforehand."""
+        assert self._plan is not None and self.lambda_low == 0.0 and target_block.numel() == self._target_floats
+        st = self._lib.segs_freq_loss(self._plan, C.c_void_p(image.data_ptr()), C.c_void_p(target_block.data_ptr()),
+                                      C.c_void_p(dL_inout.data_ptr()), C.c_void_p(self.value.data_ptr()),
+                                      None if loss_inout is None else C.c_void_p(loss_inout.data_ptr()), self._stream())
+        _capi.check(st, "segs_freq_loss")
+        return self.value[0]
+
     def __call__(self, image: torch.Tensor, gt: torch.Tensor, dL_inout: torch.Tensor, loss_inout: Optional[torch.Tensor] = None):
         assert image.is_cuda and image.is_contiguous() and gt.is_contiguous() and dL_inout.is_contiguous()
         assert image.shape == (3, self.H, self.W) == gt.shape == dL_inout.shape and image.dtype == torch.float32

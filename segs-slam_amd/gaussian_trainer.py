@@ -57,14 +57,30 @@ class DeviceStepCount:
     the device drops does not advance it, and the host never has to find out."""
 
     def __init__(self, device):
-        self.words = torch.zeros(2, dtype=torch.int64, device=device)
+        # [0], [1]: the pair; [2]: the call count as the hipGraph-capturable form keeps it on the device (segs_adam_step_graph)
+        self.words = torch.zeros(3, dtype=torch.int64, device=device)
         self.calls = 0
+        self._device_calls_current = True     # words[2] == calls (the eager form does not touch words[2])
 
     def clone(self) -> "DeviceStepCount":
         c = DeviceStepCount(self.words.device)
         c.words.copy_(self.words)
         c.calls = self.calls
+        c._device_calls_current = self._device_calls_current
         return c
+
+    def eager_call(self) -> int:
+        """Call index for segs_adam_step_device (host-side parity); the device-side call count falls behind."""
+        call = self.calls
+        self.calls += 1
+        self._device_calls_current = False
+        return call
+
+    def sync_device_calls(self):
+        """Before capturing / replaying segs_adam_step_graph after eager calls: bring words[2] up to the host's count."""
+        if not self._device_calls_current:
+            self.words[2:3].fill_(self.calls)
+            self._device_calls_current = True
 
     def value(self) -> int:
         """Steps taken so far (synchronises; for tests and checkpoints)."""
@@ -112,8 +128,7 @@ class FusedAdam:
         for i, (o, n, lr) in enumerate(groups):
             segs[i].offset, segs[i].count, segs[i].lr = o, n, lr
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        call = self.count.calls
-        self.count.calls += 1
+        call = self.count.eager_call()
         st = self._lib.segs_adam_step_device(p(params_flat), p(grads_flat), p(self.exp_avg), p(self.exp_avg_sq), segs, len(groups),
                                              self.opt.beta1, self.opt.beta2, self.opt.eps, p(self.count.words), call,
                                              float(grad_scale), 1, p(guard) if guard is not None else None,
@@ -225,6 +240,10 @@ class TrainerStep:
         lrs = self.learning_rates(self.iteration)
         k = self.keyframe_for(self.iteration - 1, len(keyframes))
         ex = self.exchange
+        if getattr(self, "use_graph", False) and not ex.active:
+            loss = self._training_once_graph(keyframes[k], gt_images[k], lrs)
+            if loss is not None:
+                return loss
         dL_fn = lambda im: self.loss_and_grad(im, gt_images[k])  # noqa: E731
         if self._backend_takes_hook:
             loss = self.render_backward(self.params, keyframes[k], dL_fn, after_forward=ex.reduce_flag_async)
@@ -236,6 +255,63 @@ class TrainerStep:
         self.optimizer.step(self.params_flat, self.grads_flat, lrs, self.P, 1.0 / self.world, exchange=ex, guard=flag)
         ex.gather(self.params_flat)
         return loss
+
+    # ---- whole-iteration hipGraph (the on_gpu wiring: HIP raster engine + fused loss + fused Adam) -------------------------
+    def enable_graph(self, on: bool = True):
+        """Replay the iteration from a captured hipGraph (single rank, calibrated resident rasterizer): the keyframe matrices,
+        the target image and the learning rates go through staging buffers refreshed before each replay; same kernels, same
+        arguments, same order as the eager path."""
+        assert getattr(self, "engine", None) is not None and isinstance(self.optimizer, FusedAdam), "graph mode needs TrainerStep.on_gpu()"
+        self.use_graph, self._graphs, self._stage, self.graph_replays = bool(on), {}, None, 0
+
+    def _training_once_graph(self, keyframe, gt, lrs):
+        from . import _capi
+        eng, opt = self.engine, self.optimizer
+        if not eng.resident or eng.capacity <= 0 or not eng.poll() or eng.capacity <= 0:
+            return None
+        view, proj, campos, tanx, tany = keyframe
+        dev = self.params_flat.device
+        if self._stage is None:
+            self._stage = dict(packed=torch.zeros(35, dtype=torch.float32, device=dev), gt=torch.empty_like(gt),
+                               lr=torch.zeros(16, dtype=torch.float64, device=dev))
+        st = self._stage
+        groups = field_segments(lrs, self.P)
+        key = (eng.capacity, eng._bin_r.data_ptr(), float(tanx), float(tany), tuple(gt.shape))
+        pk = st["packed"]
+        pk[0:16].copy_(view.reshape(-1)); pk[16:32].copy_(proj.reshape(-1)); pk[32:35].copy_(campos.reshape(-1))
+        st["gt"].copy_(gt)
+        vals = (C.c_double * len(groups))(*[float(g[2]) for g in groups])
+        stream = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)  # noqa: E731
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        _capi.check(_capi.lib().segs_set_doubles(p(st["lr"]), vals, len(groups), stream()), "segs_set_doubles")
+        opt.count.sync_device_calls()
+        g = self._graphs.get(key)
+        if g is None:
+            skf = (pk[0:16].view(4, 4), pk[16:32].view(4, 4), pk[32:35], tanx, tany)
+            guard = eng._status[3:4]
+            segs = (_capi.AdamSegment * len(groups))()
+            for i, (o, n, _) in enumerate(groups):
+                segs[i].offset, segs[i].count, segs[i].lr = o, n, 0.0
+
+            def body():
+                self.render_backward(self.params, skf, lambda im: self.loss_and_grad(im, st["gt"]))
+                rc = _capi.lib().segs_adam_step_graph(p(self.params_flat), p(self.grads_flat), p(opt.exp_avg), p(opt.exp_avg_sq), segs,
+                                                      len(groups), p(st["lr"]), opt.opt.beta1, opt.opt.beta2, opt.opt.eps, p(opt.count.words),
+                                                      1.0, 1, p(guard), stream())
+                _capi.check(rc, "segs_adam_step_graph")
+
+            eng.check(raise_on_overflow=False)
+            if eng.capacity <= 0:
+                return None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            self._graphs = {key: g}
+        g.replay()
+        opt.count.calls += 1
+        eng.after_graph_replay()
+        self.graph_replays += 1
+        return self.fused_loss.out[0]
 
     # ---- product wiring -------------------------------------------------------------------------------
     @staticmethod

@@ -287,6 +287,14 @@ class Keyframe:
     tanfovx: float
     tanfovy: float
 
+    def packed(self) -> torch.Tensor:
+        """view | proj | campos | pose7 as one 42-float device tensor (made once): one copy refreshes a captured iteration's
+        staging keyframe."""
+        pk = getattr(self, "_packed", None)
+        if pk is None:
+            pk = self._packed = torch.cat([self.view.reshape(-1), self.proj.reshape(-1), self.campos.reshape(-1), self.pose7.reshape(-1)]).contiguous()
+        return pk
+
     @classmethod
     def from_pose(cls, q_wxyz, t_xyz, width: int, height: int, fx: float, fy: float, device, znear: float = 0.01,
                   zfar: float = 100.0) -> "Keyframe":
@@ -356,6 +364,13 @@ class ScaffoldTrainerStep:
         # (src/gaussian_mapper.cpp:917-922).  Off by default (trainer semantics); mapper_config.make_mapper_step turns it on.
         self.row_mask = False
         self._row_mask_cache = {}
+        # Whole-iteration hipGraph (enable_graph): the iterations between two adjust_anchor calls issue a fixed launch sequence
+        # over fixed addresses once the per-iteration values (keyframe matrices, target image, learning rates, the frequency
+        # regulariser's target tables) sit in staging buffers refreshed before each replay.
+        self.use_graph = False
+        self._graphs = {}
+        self._graph_stage = {}
+        self.graph_replays = 0
 
     def set_background(self, white: bool):
         """bg_color of GaussianMapper's constructor (src/gaussian_mapper.cpp:61-67)."""
@@ -422,8 +437,7 @@ class ScaffoldTrainerStep:
         """Fused Adam over `groups` (restricted to this rank's shard of the bucket when the optimizer is sharded), guarded by
         the summed overflow word, step count on the device."""
         groups = self._exchange().clip_segments(groups)
-        call = count.calls
-        count.calls += 1                 # the launch below always happens (an empty shard still advances the count)
+        call = count.eager_call()        # the launch below always happens (an empty shard still advances the count)
         if not groups:
             groups = [(0, 0, 0.0)]
         segs = (_capi.AdamSegment * len(groups))()
@@ -564,6 +578,10 @@ class ScaffoldTrainerStep:
         d = self.densifier
         in_stat_window = d is not None and self.model.A > 0 and d.p.start_stat < self.iteration < d.p.update_until  # gaussian_mapper.cpp:961-968
         adjust_now = in_stat_window and self.iteration > d.p.update_from and self.iteration % d.p.update_interval == 0
+        if self.use_graph and not adjust_now and not ex.active:
+            loss = self._training_once_graph(keyframes[k], gt_images[k], lrs, in_stat_window)
+            if loss is not None:
+                return loss
         loss = self._forward_backward(keyframes[k], gt_images[k], ex, flag_on_host=adjust_now)
         flag = ex.wait_flag()
         if adjust_now:
@@ -613,6 +631,119 @@ class ScaffoldTrainerStep:
             ex.gather(self.model.params)
             self.model.grads.zero_()      # outside this rank's shard the bucket still holds its own contribution
         return loss
+
+    # ---- whole-iteration hipGraph ------------------------------------------------------------------------------------
+    def enable_graph(self, on: bool = True):
+        """Replay the iterations whose launch sequence is fixed (single rank, no adjust_anchor this iteration, a calibrated
+        resident rasterizer, a target without blanked rows) from a captured hipGraph.  Same kernels, same arguments, same
+        order as the eager path: parameters stay bit-identical (tests/test_graph_step_gpu.py); what goes is the host's
+        per-launch cost and the gaps between dependent small launches."""
+        self.use_graph = bool(on)
+        self._graphs.clear()
+
+    def _graph_stage_for(self, fl):
+        key = (self.W, self.H)
+        st = self._graph_stage.get(key)
+        if st is None:
+            dev = self.model.device
+            pk = torch.zeros(42, dtype=torch.float32, device=dev)
+            st = dict(packed=pk, gt=torch.empty((3, self.H, self.W), dtype=torch.float32, device=dev),
+                      lr=torch.zeros(16, dtype=torch.float64, device=dev), table=None)
+            self._graph_stage[key] = st
+        if fl is not None and (st["table"] is None or st["table"].numel() != fl._target_floats):
+            st["table"] = torch.empty(fl._target_floats, dtype=torch.float32, device=self.model.device)
+        return st
+
+    def _training_once_graph(self, kf: Keyframe, gt: torch.Tensor, lrs, in_stat_window: bool):
+        """One iteration from the captured graph; None when this iteration has to take the eager path."""
+        self.use_level(gt.shape[-1], gt.shape[-2])
+        eng, m = self.engine, self.model
+        if m.A == 0 or not eng.resident or eng.capacity <= 0 or not eng.poll() or eng.capacity <= 0:
+            return None                                  # not calibrated (or an overflow just came to light): eager, which re-sizes
+        if m.capacity * m.dims.n_offsets > eng.P:
+            return None
+        if self.row_mask and self._row_mask_of(gt)[0] is not None:
+            return None                                  # a target with blanked rows multiplies image and gradient by its mask: eager
+        fl = None
+        if self.freq_reg is not None:
+            low_on, high_on = self._freq_active()
+            if low_on or (high_on and not self.freq_reg["fused"]):
+                return None
+            if high_on:
+                from .frequency_loss import FusedFrequencyLoss
+                fr = self.freq_reg
+                fkey = (self.W, self.H, False, True)
+                fl = self._freq_fused.get(fkey)
+                if fl is None:
+                    fl = self._freq_fused[fkey] = FusedFrequencyLoss(self.H, self.W, m.device, lambda_high=fr["lambda_high"], scales=fr["scales"],
+                                                                      multi_resolution=fr["multi"])
+        st = self._graph_stage_for(fl)
+        groups = m.adam_groups(lrs)
+        split = self._anchor_count is not None
+        key = (self.W, self.H, m.A, m.capacity, id(eng), eng.capacity, eng._bin_r.data_ptr(), float(kf.tanfovx), float(kf.tanfovy),
+               bool(in_stat_window), fl is not None, split, len(groups), m.params.data_ptr())
+        # ---- refresh the staging buffers (ordinary stream work in front of the replay)
+        st["packed"].copy_(kf.packed())
+        st["gt"].copy_(gt)
+        if fl is not None:
+            st["table"].copy_(fl.target_block(gt))
+        vals = (C.c_double * len(groups))(*[float(g[2]) for g in groups])
+        _capi.check(self._lib.segs_set_doubles(_p(st["lr"]), vals, len(groups), self._stream()), "segs_set_doubles")
+        counts = (self._anchor_count, self._mlp_count) if split else (self._mlp_count,)
+        for c in counts:
+            c.sync_device_calls()
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) > 16:
+                self._graphs.clear()
+            pk = st["packed"]
+            skf = Keyframe(pk[0:16].view(4, 4), pk[16:32].view(4, 4), pk[32:35], pk[35:42], kf.tanfovx, kf.tanfovy)
+            status = eng._status
+            guard = C.c_void_p(status[3:4].data_ptr())
+            d = self.densifier
+            seg_all = [(o, n) for o, n, _ in groups]
+
+            def adam(seg, lr_off, count):
+                segs = (_capi.AdamSegment * len(seg))()
+                for i, (o, n) in enumerate(seg):
+                    segs[i].offset, segs[i].count, segs[i].lr = o, n, 0.0
+                lr_ptr = C.c_void_p(st["lr"].data_ptr() + 8 * lr_off)
+                rc = self._lib.segs_adam_step_graph(_p(m.params), _p(m.grads), _p(m.exp_avg), _p(m.exp_avg_sq), segs, len(seg), lr_ptr,
+                                                    self.opt.beta1, self.opt.beta2, self.opt.eps, _p(count.words), 1.0, 1, guard, self._stream())
+                _capi.check(rc, "segs_adam_step_graph")
+
+            def body():
+                image = self.render(skf)
+                loss, dL = self.loss_fn(image, st["gt"])
+                if fl is not None:
+                    fl.apply(image, st["table"], dL, loss.view(1))
+                gr = eng.backward(dL)
+                self.neural.backward(gr["means3D"], gr["colors"], gr["opacity"], gr["scales"], gr["rotations"], self.scaling_reg_weight)
+                if in_stat_window:
+                    d.training_statis(self.neural, self.visible_radii, eng.radii, eng.dL_dmean2D, guard, into_delta=False)
+                if split:
+                    adam(seg_all[:4], 0, self._anchor_count)
+                    adam(seg_all[4:], 4, self._mlp_count)
+                else:
+                    adam(seg_all, 0, self._mlp_count)
+
+            eng.check(raise_on_overflow=False)           # nothing pending while the capture runs
+            if eng.capacity <= 0:
+                return None
+            if fl is not None and not getattr(fl, "_ran_eagerly", False):
+                # the FFT library sets a transform up on its first execution: not inside a capture
+                fl.apply(eng.out_color, st["table"], torch.zeros_like(st["gt"]))
+                fl._ran_eagerly = True
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            self._graphs[key] = g
+        g.replay()
+        for c in counts:
+            c.calls += 1                                 # (the device-side call count advanced with the replay)
+        eng.after_graph_replay()
+        self.graph_replays += 1
+        return self.loss_fn.out[0]
 
     def profile_phases(self, kf: Keyframe, gt: torch.Tensor, iters: int = 20) -> Dict[str, float]:
         """Mean milliseconds per phase of one iteration (HIP events on the current stream between the same calls

@@ -122,6 +122,19 @@ class RasterEngine:
                 return False
         return True
 
+    def poll(self) -> bool:
+        """check() without waiting: resolves the last status read-back only if the device has got there.  For the hipGraph
+        replay loop, where waiting for the previous step's event would serialise host and device."""
+        if self.resident and self._status_host is not None and self._status_pending and self._status_event.query():
+            return self.check(raise_on_overflow=False)
+        return True
+
+    def after_graph_replay(self):
+        """Bookkeeping of a resident forward + backward that ran from a captured graph (the Python side of forward() did not)."""
+        self._status_event.record(torch.cuda.current_stream(self.device))
+        self._status_pending = True
+        self._last_resident = True
+
     def forward(self, bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
                 scale_modifier: float = 1.0) -> torch.Tensor:
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
