@@ -627,12 +627,19 @@ def mapper_step_block(dev, steps: int = 50, warmup: int = 10):
     torch.cuda.synchronize()
     eng = tstep.engine
     eng.check()
+    # how much of the candidate domain is alive: rows the rasterizer bins (radius > 0 after the opacity skip and the frustum
+    # cull) and rows whose neural opacity is positive (the reference's compacted P) out of anchors x offsets candidate rows
+    n_binned = int((eng.radii[:eng.P_active] > 0).sum().item())
+    n_kept = int(tstep.neural.mask().sum().item())
+    n_visible_anchors = int((tstep.visible_radii[:model.A] > 0).sum().item())
+    live = {"candidate_rows": eng.P_active, "visible_anchors": n_visible_anchors, "neural_opacity_positive": n_kept,
+            "binned_by_the_rasterizer": n_binned, "binned_fraction_of_candidates": n_binned / max(eng.P_active, 1)}
     return {"workload": f"anchor-level mapper step, config-5 size: {model.A} anchors x {dims.n_offsets} offsets -> {eng.P_active} candidate "
                         f"Gaussians, {cam.width}x{cam.height}, appearance_dim 16, no feature bank; instances binned {eng.R}, live {eng.R_live}",
             "iters_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "steps": steps, "warmup": warmup, "step_ms": pc,
             "phase_ms": {k: round(v, 4) for k, v in phases.items()},
             "render_only_ms": _percentiles([rev[i].elapsed_time(rev[i + 1]) for i in range(20)]),
-            "dropped_steps": tstep.dropped_steps()}
+            "dropped_steps": tstep.dropped_steps(), "candidates": live}
 
 
 def replica_step_block(dev, anchors: int = 50_000, steps: int = 50, warmup: int = 10, iteration: int = 10_000,

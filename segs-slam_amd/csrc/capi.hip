@@ -121,7 +121,8 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
                const uint32_t* n_dev = nullptr, bool drop_dead = false, bool iota_vals = false, const uint32_t* aux_in = nullptr,
                uint32_t* aux_final = nullptr, int pack_shift = 0 /* > 0 (with iota_vals, aux_in, no aux_final): the FIRST pass packs
                min(aux_in[i], tmax) into the value's bits from pack_shift up; the caller takes the sorted values apart */,
-               const SortFusion& fuse = SortFusion()) {
+               const SortFusion& fuse = SortFusion(), const K* first_keys = nullptr /* the FIRST pass reads its keys here instead of
+               from its ping-pong side (keys produced before the sort scratch existed) */) {
   if (n <= 0) return SEGS_OK;
   uint32_t* n_live = (uint32_t*)(bin + L.n_live);
   const int passes = (end_bit + BITS - 1) / BITS;
@@ -132,7 +133,7 @@ int sort_pairs(char* bin, const BinningLayout& L, int n, int end_bit, uint32_t d
   const int chunk_tiles = count_chunk_tiles(L.nblocks);
   const int nchunks = (L.nblocks + chunk_tiles - 1) / chunk_tiles;
   for (int p = 0; p < passes; p++) {
-    const K* kin = (const K*)(bin + L.keys[side]);
+    const K* kin = (p == 0 && first_keys) ? first_keys : (const K*)(bin + L.keys[side]);
     const uint32_t* vin = (const uint32_t*)(bin + L.vals[side]);
     K* kout = (K*)(bin + L.keys[side ^ 1]);
     uint32_t* vout = (uint32_t*)(bin + L.vals[side ^ 1]);
@@ -230,7 +231,8 @@ int run_preprocess(const Geom& G, int P, int W, int H, const float* means3D, con
 // `total_out` (3 device words) receives the instance count produced by the depth-ordered scan.
 int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSortLayout& GS, uint2* ranges, int P, int n_cap,
                 const uint32_t* n_dev, uint32_t dmin, int dbits, uint32_t dcull, uint32_t gx, uint32_t gy, uint32_t* total_out,
-                hipStream_t st, bool depth_keys_ready = false, bool drop_dead = false, bool nine_bit_depth = false) {
+                hipStream_t st, bool depth_keys_ready = false, bool drop_dead = false, bool nine_bit_depth = false,
+                const uint32_t* depth_keys_src = nullptr /* with depth_keys_ready: where K1 left the keys, if not in the sort scratch */) {
   const int bit = (int)getHigherMsb(gx * gy);
   // (1)
   char* gbin = bin + GS.base;
@@ -254,8 +256,8 @@ int run_binning(const Geom& G, char* bin, const BinningLayout& BL, const GaussSo
   int pack_shift = (32 - idx_bits >= 6 && !(g_flags & SEGS_RASTER_GATHER_TILES_TOUCHED)) ? idx_bits : 0;
   if (pack_shift && (g_flags & SEGS_RASTER_TEST_NARROW_PACK)) pack_shift = 30;
   uint32_t* aux_final = pack_shift ? nullptr : G.offsets();
-  int rc = nine_bit_depth ? sort_pairs<uint32_t, 9>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), aux_final, pack_shift)
-                          : sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), aux_final, pack_shift);
+  int rc = nine_bit_depth ? sort_pairs<uint32_t, 9>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), aux_final, pack_shift, SortFusion(), depth_keys_src)
+                          : sort_pairs<uint32_t>(gbin, GL, P, dbits, dmin, dbits, st, nullptr, drop_culled, true, G.touched(), aux_final, pack_shift, SortFusion(), depth_keys_src);
   if (rc) return rc;
   uint32_t* order = (uint32_t*)(gbin + GL.vals[0]);
   const uint32_t* ng_dev = drop_culled ? (const uint32_t*)(gbin + GL.n_live) : nullptr;
@@ -367,10 +369,16 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
   int R = 0;
   uint32_t hdr[3] = {0u, 0u, 0u};  // num_rendered, max(~depth_bits), max(depth_bits)
   const bool tight = (g_flags & SEGS_RASTER_TIGHT_BINNING) != 0u;   // segs_raster.h: shorter lists, same image and gradients
+  // Tight mode has no use for the per-Gaussian bin records (they feed make_depth_keys_kernel and the debug unpackers): K1 writes
+  // the 32-bit depth keys of the resident forward instead -- into the bin records' place, the sort scratch does not exist before
+  // R is known -- and the depth sort's first pass reads them there (16 B x P less to write, one launch and a 12 B x P pass less).
+  uint2* const ranges_early = (uint2*)(img + IL.ranges);
+  bool fast_keys = tight;
   if (P > 0) {
     int rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales,
                             scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M,
-                            cam_pos, st, nullptr, nullptr, nullptr, tight ? PREPROCESS_TIGHT_RECT : 0u);
+                            cam_pos, st, fast_keys ? (uint32_t*)G.bin() : nullptr, nullptr, fast_keys ? ranges_early : nullptr,
+                            tight ? PREPROCESS_TIGHT_RECT : 0u);
     if (rc) return rc;
     { PROF(K_SCAN);
     scan_block_sums_kernel<<<1, 1024, 0, st>>>(G.block_sums(), G.L.nblocks, G.block_sums() + (G.L.nblocks + 1), G.num_rendered());
@@ -380,6 +388,14 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
     HIP_TRY(hipStreamSynchronize(st));
     R = (int)hdr[0];
     if (R < 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "num_rendered overflows int32");
+    if (fast_keys && R > 0 && (hdr[2] - DEPTH_KEY_MIN) >= ((1u << DEPTH_KEY_BITS) - 1u)) {
+      // a binned depth beyond the 27-bit key range of the three 9-bit passes (13 107 m): redo K1 for the exact-range sort
+      fast_keys = false;
+      rc = run_preprocess(G, P, width, height, means3D, colors_precomp, opacities, cov3D_precomp ? nullptr : scales, scale_modifier,
+                          rotations, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, shs, D, M, cam_pos, st, nullptr,
+                          nullptr, nullptr, PREPROCESS_TIGHT_RECT);
+      if (rc) return rc;
+    }
   }
   const BinningLayout BL = binning_layout(R);            // instance-level state (what backward re-parses)
   const GaussSortLayout GS = gauss_sort_layout(R, P);    // + Gaussian-level depth sort scratch behind it
@@ -398,7 +414,9 @@ int segs_rasterize_forward(segs_alloc_fn geometry_alloc, void* geometry_ctx, seg
     while (dbits < 32 && (dspan >> dbits) != 0u) dbits++;
     uint32_t* total_scratch = (uint32_t*)(bin + GS.block_sums) + G.L.nblocks;
     const bool nine = (dbits + 8) / 9 < (dbits + 7) / 8;   // e.g. the usual 26 bits: three 9-bit passes instead of four 8-bit ones
-    int rc = run_binning(G, bin, BL, GS, ranges, P, R, nullptr, dmin, dbits, dmin + dspan, gx, gy, total_scratch, st, false, tight, nine);
+    int rc = fast_keys ? run_binning(G, bin, BL, GS, ranges, P, R, nullptr, DEPTH_KEY_MIN, DEPTH_KEY_BITS, 0xFFFFFFFFu, gx, gy, total_scratch,
+                                     st, true, true, true, (const uint32_t*)G.bin())
+                       : run_binning(G, bin, BL, GS, ranges, P, R, nullptr, dmin, dbits, dmin + dspan, gx, gy, total_scratch, st, false, tight, nine);
     if (rc) return rc;
   }
   { PROF(K_RENDER_FWD);

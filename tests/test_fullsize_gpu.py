@@ -168,3 +168,31 @@ def test_reference_shaped_entry_points_with_tight_binning_flag(workload):
     for name, a, b in zip(names, g1, g0):
         if name not in ("dL_dcov3D", "dL_dsh"):      # not produced on the scales + rotations / precomputed-colour path
             assert_grad_close(name, a, b)
+
+
+def test_tight_binning_falls_back_to_the_exact_depth_range_for_far_scenes():
+    """The tight reference-shaped forward sorts 27 bits of depth above the near plane's pattern (three 9-bit passes, keys
+    written by K1); a binned depth beyond that range -- 13 107 m -- is known to the host after its one synchronisation
+    (the depth maximum rides with num_rendered) and sends the call through the exact-range sort instead.  Same image."""
+    from segs_slam_amd import _capi, rasterize_points as rp, scenes
+    from test_raster_gpu import _t
+    sc = scenes.make_scene(3000, 160, 96, 140.0, 140.0, seed=31)
+    sc.means3D *= 4000.0          # view depths 4 000 ... 24 000: part of the scene lies beyond the key range
+    sc.scales *= 4000.0 * 2.5
+    cam = sc.camera
+    bg, m3, col, op, sca, rot, view, proj, campos = [_t(x) for x in (sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, sc.rotations,
+                                                                     cam.world_view_transform, cam.full_proj_transform, cam.camera_center)]
+    e = torch.empty(0, device=DEV)
+    lib = _capi.lib()
+    out = []
+    for flags in (0, 32):
+        old = lib.segs_raster_set_flags(flags)
+        try:
+            out.append(rp.RasterizeGaussiansCUDA(bg, m3, col, op, sca, rot, 1.0, e, view, proj, cam.tanfovx, cam.tanfovy, cam.height,
+                                                 cam.width, e, 0, campos, False))
+        finally:
+            lib.segs_raster_set_flags(old)
+    torch.cuda.synchronize()
+    (R0, c0, r0, *_), (R1, c1, r1, *_) = out
+    assert float((m3 @ view[:3, 2] + view[3, 2]).max()) > 13200.0
+    assert torch.equal(c0, c1) and torch.equal(r0, r1) and 0 < R1 <= R0 and float(c0.abs().max()) > 0
