@@ -384,7 +384,7 @@ def main():
                                     "step ends; the line's ms_per_step is the host clock over all K steps)"}
         if world == 1 and args.mode == "raster" and not args.no_extras:
             try:
-                out["dropin"] = dropin_block(sc, dev, (bg, m3, col, op, sca, rot, view, proj, campos), dL, cpp_dropin, world * args.steps / elapsed)
+                out["dropin"] = dropin_block(sc, cpp_dropin, world * args.steps / elapsed)
             except Exception as e:  # noqa: BLE001  (extra blocks never fail the bench line)
                 out["dropin"] = {"error": f"{type(e).__name__}: {e}"}
             extras = [("render_only_ms", lambda: render_only(eng, (bg, m3, col, op, sca, rot, view, proj, campos, cam.tanfovx, cam.tanfovy))),
@@ -430,55 +430,33 @@ def cpp_dropin_block(sc, steps: int = 50, warmup: int = 10):
             for a in (sc.bg, sc.means3D, sc.colors, sc.opacity, sc.scales, sc.rotations, cam.world_view_transform,
                       cam.full_proj_transform, cam.camera_center, sc.dL_dout_color):
                 np.ascontiguousarray(a, np.float32).tofile(f)
+        py = {"what": "segs_slam_amd.rasterize_points.RasterizeGaussiansCUDA + RasterizeGaussiansBackwardCUDA (mirror of "
+                      "src/rasterize_points.cu:36-193 over the C ABI), timed by tools/dropin_python.py in a child process of its own per variant"}
         for label, flags in (("reference_lists", 0), ("tight_binning", 32)):
-            try:
-                r = subprocess.run([exe, "--bench", path, str(steps), str(warmup), str(flags)], capture_output=True, text=True, timeout=600)
-                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                out[label] = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
-            except Exception as e:  # noqa: BLE001
-                out[label] = {"error": f"{type(e).__name__}: {e}"}
-    return out
+            for dst, cmd in ((out, [exe, "--bench", path, str(steps), str(warmup), str(flags)]),
+                             (py, [sys.executable, os.path.join(ROOT, "tools", "dropin_python.py"), path, str(steps), str(warmup), str(flags)])):
+                try:
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                    dst[label] = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+                except Exception as e:  # noqa: BLE001
+                    dst[label] = {"error": f"{type(e).__name__}: {e}"}
+    return {"cpp": out, "python": py}
 
 
-def dropin_block(sc, dev, tensors, dL, cpp_dropin, resident_its, steps: int = 50, warmup: int = 10):
+def dropin_block(sc, children, resident_its):
     """What an unchanged SEGS-SLAM gets by swapping the libraries: fwd+bwd iterations per second of the headline workload through
     the reference-shaped entry points (RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA: fresh output tensors and scratch
     per call, one host synchronisation on num_rendered per forward) -- (i) the Python mirror of src/rasterize_points.cu over the
-    C ABI, (ii) the C++/LibTorch-ROCm library (cpp_dropin_block) -- each with the reference's lists and with
-    SEGS_RASTER_TIGHT_BINNING; next to the resident path the headline `value` is measured on."""
-    import torch
-    from segs_slam_amd import _capi, rasterize_points as rp
+    C ABI, (ii) the C++/LibTorch-ROCm library -- each with the reference's lists and with SEGS_RASTER_TIGHT_BINNING, each variant
+    in a child process of its own (cpp_dropin_block: a process that calls nothing else, like the mapper; inside this one the
+    tensor library's caching allocator, filled by everything the bench ran before, turned the per-call allocations of the
+    wrappers into device allocations and doubled the wall time of a loop whose kernels took 1.08 ms); next to the resident path
+    the headline `value` is measured on."""
     cam = sc.camera
-    bg, m3, col, op, sca, rot, view, proj, campos = tensors
-    e = torch.empty(0, device=dev)
-    lib = _capi.lib()
-
-    def one():
-        R, color, radii, geom, binning, img = rp.RasterizeGaussiansCUDA(bg, m3, col, op, sca, rot, 1.0, e, view, proj, cam.tanfovx,
-                                                                        cam.tanfovy, cam.height, cam.width, e, 0, campos, False)
-        rp.RasterizeGaussiansBackwardCUDA(bg, m3, radii, col, sca, rot, 1.0, e, view, proj, cam.tanfovx, cam.tanfovy, dL, e, 0,
-                                          campos, geom, R, binning, img)
-        return R
-    py = {}
-    for label, flags in (("reference_lists", 0), ("tight_binning", 32)):
-        old = lib.segs_raster_set_flags(flags)
-        try:
-            for _ in range(warmup):
-                one()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                R = one()
-            torch.cuda.synchronize()
-            wall = time.perf_counter() - t0
-        finally:
-            lib.segs_raster_set_flags(old)
-        py[label] = {"iters_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "num_rendered_returned": R, "steps": steps, "warmup": warmup}
     return {"workload": f"{sc.P} Gaussians, {cam.width}x{cam.height} (the headline workload), fwd+bwd raster",
             "resident_path_iters_per_s": resident_its,
-            "python_reference_shaped": dict(py, what="segs_slam_amd.rasterize_points.RasterizeGaussiansCUDA + RasterizeGaussiansBackwardCUDA "
-                                                    "(mirror of src/rasterize_points.cu:36-193 over the C ABI)"),
-            "cpp_gaussian_rasterizer": cpp_dropin}
+            "python_reference_shaped": (children or {}).get("python"), "cpp_gaussian_rasterizer": (children or {}).get("cpp")}
 
 
 def _timed_dist_steps(step_fn, ex_of, world, dev, steps, warmup):
