@@ -449,10 +449,8 @@ def dropin_block(sc, children, resident_its):
     the reference-shaped entry points (RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA: fresh output tensors and scratch
     per call, one host synchronisation on num_rendered per forward) -- (i) the Python mirror of src/rasterize_points.cu over the
     C ABI, (ii) the C++/LibTorch-ROCm library -- each with the reference's lists and with SEGS_RASTER_TIGHT_BINNING, each variant
-    in a child process of its own (cpp_dropin_block: a process that calls nothing else, like the mapper; inside this one the
-    tensor library's caching allocator, filled by everything the bench ran before, turned the per-call allocations of the
-    wrappers into device allocations and doubled the wall time of a loop whose kernels took 1.08 ms); next to the resident path
-    the headline `value` is measured on."""
+    in a child process of its own (cpp_dropin_block: a process that calls nothing else, like the mapper); next to the resident
+    path the headline `value` is measured on."""
     cam = sc.camera
     return {"workload": f"{sc.P} Gaussians, {cam.width}x{cam.height} (the headline workload), fwd+bwd raster",
             "resident_path_iters_per_s": resident_its,

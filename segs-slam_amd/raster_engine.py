@@ -23,12 +23,15 @@ class _GrowBuffer:
     def __init__(self, device):
         self.device = device
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = _capi.ALLOC_FN(self._alloc)
 
-    def _alloc(self, _ctx, nbytes):
-        if self.tensor.numel() < nbytes:
-            self.tensor = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
-        return self.tensor.data_ptr()
+    def callback(self):
+        """A fresh ctypes callback per call, not kept on the object (a stored one is a reference cycle: the buffers of a dropped
+        engine would wait for the cyclic garbage collector; see rasterize_points._ResizableBuffer)."""
+        def _alloc(_ctx, nbytes, box=self):
+            if box.tensor.numel() < nbytes:
+                box.tensor = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=box.device)
+            return box.tensor.data_ptr()
+        return _capi.ALLOC_FN(_alloc)
 
 
 def split_flat(flat: torch.Tensor, P: int):
@@ -171,8 +174,9 @@ class RasterEngine:
             return self.out_color
         self._last_resident = False
         n = C.c_int(0)
+        gcb, bcb, icb = self.geom.callback(), self.binning.callback(), self.img.callback()
         st = self._lib.segs_rasterize_forward(
-            self.geom.cb, None, self.binning.cb, None, self.img.cb, None, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
+            gcb, None, bcb, None, icb, None, self.P_active, 0, 0, p(bg), self.W, self.H, p(means3D),
             None, p(colors), p(opacity), p(scales), float(scale_modifier), p(rotations), None, p(viewmatrix), p(projmatrix),
             p(campos), float(tanfovx), float(tanfovy), 0, p(self.out_color), p(self.radii), self._stream(), C.byref(n))
         _capi.check(st, "segs_rasterize_forward")

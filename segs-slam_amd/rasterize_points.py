@@ -46,16 +46,23 @@ def _require_gpu(t: torch.Tensor, name: str):
 
 
 class _ResizableBuffer:
-    """resizeFunctional (src/rasterize_points.cu:28-34): a byte tensor grown by the allocator callback."""
+    """resizeFunctional (src/rasterize_points.cu:28-34): a byte tensor grown by the allocator callback.
+
+    The callback object is made per call (`callback()`) and NOT kept on the buffer: a ctypes callback stored on the object whose
+    bound method it wraps is a reference cycle, and the scratch tensor -- 0.8 GB per call at 3 M Gaussians -- then lives until the
+    cyclic garbage collector runs instead of until the caller drops it: the tensor library's caching allocator kept answering
+    the next calls with fresh device allocations (5.5 GB reserved after seven calls, a device allocation right after the host
+    synchronisation of most forwards; round 4 found it through a 5x slower benchmark loop)."""
 
     def __init__(self, device):
         self.device = device
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = _capi.ALLOC_FN(self._alloc)
 
-    def _alloc(self, _ctx, nbytes):
-        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-        return self.tensor.data_ptr()
+    def callback(self):
+        def _alloc(_ctx, nbytes, box=self):
+            box.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=box.device)
+            return box.tensor.data_ptr()
+        return _capi.ALLOC_FN(_alloc)
 
 
 def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -79,9 +86,10 @@ def RasterizeGaussiansCUDA(background, means3D, colors, opacity, scales, rotatio
                                    viewmatrix, projmatrix, campos)]
         bg, m3, shc, col, opa, sca, rot, cov, view, proj, cam = keep
         n = C.c_int(0)
+        gcb, bcb, icb = geom.callback(), binning.callback(), img.callback()
         with torch.cuda.device(dev):
             st = _capi.lib().segs_rasterize_forward(
-                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg), W, H, _ptr(m3), _ptr(shc),
+                gcb, None, bcb, None, icb, None, P, int(degree), M, _ptr(bg), W, H, _ptr(m3), _ptr(shc),
                 _ptr(col), _ptr(opa), _ptr(sca), float(scale_modifier), _ptr(rot), _ptr(cov), _ptr(view), _ptr(proj),
                 _ptr(cam), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(out_color), _ptr(radii),
                 _stream(dev), C.byref(n))

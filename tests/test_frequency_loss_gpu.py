@@ -83,15 +83,16 @@ def _check_against_float64(img, gt, lam, scales, val, got):
     return ties, taken
 
 
-@pytest.mark.parametrize("size", [(680, 1200), (1080, 1920), (480, 640), (187, 333), (170, 300), (64, 72)])
-@pytest.mark.parametrize("multi", [True, False])
-@pytest.mark.parametrize("torch_fft", [False, True])
+_SIZES = [(680, 1200), (1080, 1920), (480, 640), (187, 333), (170, 300), (64, 72)]
+# (the piecewise torch.fft form is covered at every size but the largest)
+_CASES = [(sz, multi, tf) for tf in (False, True) for multi in (True, False) for sz in _SIZES if not (tf and sz[0] * sz[1] > 700 * 1300)]
+
+
+@pytest.mark.parametrize("size,multi,torch_fft", _CASES)
 def test_fused_frequency_loss_matches_float64_mirror_at_step_sizes(size, multi, torch_fft):
     from segs_slam_amd.frequency_loss import FusedFrequencyLoss
     dev = torch.device("cuda:0")
     H, W = size
-    if torch_fft and H * W > 700 * 1300:
-        pytest.skip("the piecewise torch.fft form is covered at the smaller sizes")
     img, gt = _images(H, W, dev, 11 + H)
     lam = 0.01
     scales = (1.0, 0.5, 0.25) if multi else (1.0,)
