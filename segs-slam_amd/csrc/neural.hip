@@ -40,6 +40,13 @@ constexpr int R_X = 0;     // x[36] in lane order: position 18 h + s holds input
 constexpr int R_H = 64;    // + 32*m : hidden activations, m = 0 opacity, 1 cov, 2 colour, 3 feature bank
 constexpr int R_DH = 192;  // + 32*m : dL/d(hidden pre-activation)
 constexpr int R_DF = 440;  // dL/d(feature-bank logits) [3]
+// Compact row of the pair backward's feature-bank path (round 4): only what the bank's two Linears need, 512 B per anchor,
+// contiguous -- the weight-gradient kernel streams it (the 2-KB rows above cost it a separate DRAM burst per 128-B field).
+constexpr int BROW = 128;
+constexpr int RB_H = 0;     // bank hidden activations [32]
+constexpr int RB_DH = 32;   // dL/d(bank hidden pre-activation) [32]
+constexpr int RB_X = 64;    // x[36] in lane order (the bank's Linear(4 -> 32) reads view, dist: inputs 32..35)
+constexpr int RB_DF = 100;  // dL/d(bank logits) [3]
 constexpr int WG_WAVES = 256;  // waves per weight-gradient job
 constexpr int WG_UNROLL = 8;   // row pairs whose operand loads are in flight together
 constexpr int WG_JOBS = 8;
@@ -286,6 +293,9 @@ __device__ __forceinline__ void load_feat(const float* __restrict__ anchor_feat,
 
 // feature-bank hidden units are split between the lane halves (16 each); returns this half's partial logits
 __device__ __forceinline__ void bank_logits_partial(const Small& S, int h, const float* cat4, float* lg) {
+  // (opaque to the optimiser: the 48 LDS addresses of this half's weights are otherwise formed once per kernel, kept across the
+  // slab loop and spilled; formed here they are one base register and immediate offsets)
+  asm volatile("" : "+v"(h));
   lg[0] = lg[1] = lg[2] = 0.f;
 #pragma unroll 4
   for (int jj = 0; jj < FD / 2; jj++) {
@@ -1026,13 +1036,19 @@ __global__ void __launch_bounds__(256, 1) neural_bwd_kernel(
 constexpr int PAIR_LDS = 4 * T_TILE + 32 * 4;   // X | H | D0 | D1 | tail(view xyz, dist), floats per pair of waves
 constexpr int PAIR_STAGE = 8 * 1024 + N_SMALL * 64;   // end of kernel: a wgrad wave's eight tiles and its scalar sums
 
+// BANK (round 4): the feature-bank model (the Replica configurations) takes the same pairs.  Its chain wave mixes the features
+// at the top of the slab (anchor_lane<true>) and, in its epilogue, takes dL/d(mixed features) back through the mixing and the
+// softmax to the bank's two small Linears 4 -> 32 -> 3; only THEIR weight gradients still go through per-anchor scratch rows
+// (103 of the row's 512 floats) to wgrad_mfma_kernel.  Until round 4 this model ran the one-kernel form: 240 + 91 us at 200 k
+// anchors against 153 us for the plain model's pairs.
+template <bool BANK>
 __global__ void __launch_bounds__(512, 1) neural_bwd_pair_kernel(
     Layout L, const uint32_t* __restrict__ count, const uint32_t* __restrict__ vis, const float* __restrict__ anchor,
     const float* __restrict__ offset, const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
     const float* __restrict__ g_img, const Small* __restrict__ g_small, const float* __restrict__ campos,
     const float* __restrict__ g_means, const float* __restrict__ g_colors, const float* __restrict__ g_opacity,
     const float* __restrict__ g_scales, const float* __restrict__ g_rot, float* __restrict__ d_anchor,
-    float* __restrict__ d_offset, float* __restrict__ d_feat, float* __restrict__ d_scaling_log,
+    float* __restrict__ d_offset, float* __restrict__ d_feat, float* __restrict__ d_scaling_log, float* __restrict__ rows,
     float* __restrict__ partial, float reg_weight, float* __restrict__ reg_sum) {
   extern __shared__ __align__(16) float lds_dyn[];
   float* img = lds_dyn;
@@ -1067,7 +1083,10 @@ __global__ void __launch_bounds__(512, 1) neural_bwd_pair_kernel(
       const bool valid = t < n;   // a pair's last round may be empty: it runs on a copy of the last anchor and stores nothing
       const uint32_t a = a_nx;
       AnchorLane st;
-      anchor_lane<false>(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
+      if (BANK) asm volatile("" ::: "memory");   // the bank's weights are re-read from LDS per slab: hoisted out of the loop they cost 45 spilled registers
+      anchor_lane<BANK>(S, L, a, h, anchor, anchor_feat, scaling_log, campos, st);
+      float* const row = rows + (valid ? t : 0u) * BROW;
+      if (BANK && valid) stn<L1_STEPS>(row + RB_X + L1_STEPS * h, st.xo);   // the feature bank's Linear(4 -> 32) reads view, dist
       const uint32_t c0 = a * NO + 5 * h;   // 32-bit element offsets (the entry points bound A): one SGPR base + one VGPR offset per access
       float in_op[5], in_col[15];
       ldn<5>(g_opacity + c0, in_op);
@@ -1249,13 +1268,93 @@ __global__ void __launch_bounds__(512, 1) neural_bwd_pair_kernel(
         for (int c = 0; c < 6; c++) v[c] = acc_scl[c] + dgs[c] * st.gs[c];   // through exp()
         stn<6>(d_scaling_log + a * 6, v);
       }
-      if (valid) {   // dL/dfeat: each half adds its own 16 features: float4 group 2g + h is rows rho(4g + q, h), this half's registers 4g + q
+      if (!BANK) {
+        if (valid) {   // dL/dfeat: each half adds its own 16 features: float4 group 2g + h is rows rho(4g + q, h), this half's registers 4g + q
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          float4 v = acc_feat[g];
-          v.x += dx[4 * g]; v.y += dx[4 * g + 1]; v.z += dx[4 * g + 2]; v.w += dx[4 * g + 3];
-          dfo[2 * g + h] = v;
+          for (int g = 0; g < 4; g++) {
+            float4 v = acc_feat[g];
+            v.x += dx[4 * g]; v.y += dx[4 * g + 1]; v.z += dx[4 * g + 2]; v.w += dx[4 * g + 3];
+            dfo[2 * g + h] = v;
+          }
         }
+      } else {
+        // dL/dfeat' for all 32 mixed features (mine = rows rho(r,h), the other half's = rows rho(r,1-h)) back through the mixing
+        // feat'[k] = feat[4 (k%8)] bw0 + feat[2 (k%16)] bw1 + feat[k] bw2 and the softmax to the bank's Linears.  Written to keep
+        // few values alive at once (the chain wave has 256 registers; the straightforward form spilled 96 of them): the features
+        // come back one float4 at a time, the transposed mixing is formed from partial sums of dxf, and every lane only forms the
+        // 16 entries of dL/dfeat it stores.
+        float dxf[FD];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float mine = dx[r], oth = other_half(dx[r]);
+          dxf[rho(r, 0)] = h ? oth : mine;
+          dxf[rho(r, 1)] = h ? mine : oth;
+        }
+        float s2[16], s4[8];   // s2[m] = dxf[m] + dxf[m + 16]  (what feat[2m] sees through bw1);  s4[k] = sum_{j % 8 == k} dxf[j]  (feat[4k], bw0)
+#pragma unroll
+        for (int m2 = 0; m2 < 16; m2++) s2[m2] = dxf[m2] + dxf[m2 + 16];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s4[k] = s2[k] + s2[k + 8];
+        float dbw[3] = {0.f, 0.f, 0.f};
+        const float4* const fp4 = reinterpret_cast<const float4*>(anchor_feat + a * FD);
+#pragma unroll
+        for (int q = 0; q < FD / 4; q++) {
+          const float4 f = fp4[q];
+          dbw[2] += dxf[4 * q] * f.x + dxf[4 * q + 1] * f.y + dxf[4 * q + 2] * f.z + dxf[4 * q + 3] * f.w;
+          dbw[1] += s2[2 * q] * f.x + s2[2 * q + 1] * f.z;
+          dbw[0] += s4[q] * f.x;
+        }
+        float dlg[3];
+        {
+          const float sdot = st.bw[0] * dbw[0] + st.bw[1] * dbw[1] + st.bw[2] * dbw[2];
+#pragma unroll
+          for (int c = 0; c < 3; c++) dlg[c] = st.bw[c] * (dbw[c] - sdot);
+        }
+        if (valid && h == 0) stn<3>(row + RB_DF, dlg);
+        if (valid) {   // each half adds its own 16 features: float4 groups 2g + h = features 8g + 4h .. + 3
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            float4 v = acc_feat[g];
+            float add[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              // feature index i = 8g + 4h + q: df[i] = bw2 dxf[i] + (i % 2 == 0) bw1 s2[i / 2] + (i % 4 == 0) bw0 s4[i / 4]
+              const int i0 = 8 * g + q, i1 = 8 * g + 4 + q;
+              float a0 = st.bw[2] * dxf[i0], a1 = st.bw[2] * dxf[i1];
+              if (q % 2 == 0) { a0 += st.bw[1] * s2[i0 / 2]; a1 += st.bw[1] * s2[i1 / 2]; }
+              if (q == 0) { a0 += st.bw[0] * s4[i0 / 4]; a1 += st.bw[0] * s4[i1 / 4]; }
+              add[q] = h ? a1 : a0;
+            }
+            v.x += add[0]; v.y += add[1]; v.z += add[2]; v.w += add[3];
+            dfo[2 * g + h] = v;
+          }
+        }
+        // feature-bank hidden layer: this half's 16 units, four at a time
+        const float cat4[4] = {st.view[0], st.view[1], st.view[2], st.dist};
+        float dv[4] = {0.f, 0.f, 0.f, 0.f};
+        int hb = h;
+        asm volatile("" : "+v"(hb));   // see bank_logits_partial
+#pragma unroll
+        for (int g4 = 0; g4 < FD / 8; g4++) {
+          float hq[4], dq[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int j = 16 * hb + 4 * g4 + q;
+            const float4 w = *reinterpret_cast<const float4*>(S.fw1[j]);
+            const float sj = S.fb1[j] + w.x * cat4[0] + w.y * cat4[1] + w.z * cat4[2] + w.w * cat4[3];
+            const float4 u = *reinterpret_cast<const float4*>(S.fw2[j]);
+            float d = u.x * dlg[0] + u.y * dlg[1] + u.z * dlg[2];
+            d = sj > 0.f ? d : 0.f;
+            hq[q] = fmaxf(sj, 0.f); dq[q] = d;
+            dv[0] += w.x * d; dv[1] += w.y * d; dv[2] += w.z * d; dv[3] += w.w * d;
+          }
+          if (valid) {
+            *reinterpret_cast<float4*>(row + RB_H + 16 * h + 4 * g4) = make_float4(hq[0], hq[1], hq[2], hq[3]);
+            *reinterpret_cast<float4*>(row + RB_DH + 16 * h + 4 * g4) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) dtail[c] += dv[c] + other_half(dv[c]);
       }
       // view = ob / |ob|, dist = |ob|:  d ob = (dview - view (view . dview)) / dist + ddist * view
       if (valid && h == 0) {
@@ -1348,78 +1447,66 @@ struct WJob {
 };
 struct WJobs { WJob j[WG_JOBS]; };
 
-// One wave per (job, slice).  MFMA operands are read straight from the scratch rows in lane order: lane l supplies
-// act[row k0 + (l>>5)][column l&31] as A[i][k] and dpre[row][column l&31] as B[k][j]; both are 128-B contiguous per
-// row.  C[i][j] accumulates dW^T.
-__global__ void __launch_bounds__(64) wgrad_mfma_kernel(WJobs jobs, const uint32_t* __restrict__ count,
-                                                        const float* __restrict__ rows, float* __restrict__ partial) {
+// Weight gradients of the jobs that still go through the scratch rows: the feature bank's two small Linears (one 32 x 32 tile
+// each: M, N <= 32).  One workgroup of WGM_WAVES waves per (job, slot); MFMA operands are read straight from the scratch rows in
+// lane order: lane l supplies act[row k0 + (l>>5)][column l&31] as A[i][k] and dpre[row][column l&31] as B[k][j]; both are 128-B
+// contiguous per row.  C[i][j] accumulates dW^T; the waves' tiles are summed through LDS in a fixed order into the slot's partial
+// tile.  (Until round 4: one wave per slot, 256 waves per job -- at 200 k anchors each walked 780 rows in 49 dependent rounds of
+// loads, 91 us for 100 MB; eight waves per slot: 6 rounds.)
+constexpr int WGM_WAVES = 8;
+__global__ void __launch_bounds__(WGM_WAVES * 64) wgrad_mfma_kernel(WJobs jobs, const uint32_t* __restrict__ count,
+                                                                   const float* __restrict__ rows, float* __restrict__ partial,
+                                                                   int row_stride /* floats per anchor row: ROW or BROW */) {
+  __shared__ float stage[WGM_WAVES][1024 + 64];
   const WJob job = jobs.j[blockIdx.y];
   if (!job.active || !job.via_rows) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int c = lane & 31, half = lane >> 5;
   const uint32_t n = *count;
-  const int nit = (job.M + 31) / 32, njt = (job.N + 31) / 32;   // <= 2, <= 3
-  f32x16 acc[2][3];
+  f32x16 acc;
 #pragma unroll
-  for (int it = 0; it < 2; it++)
-#pragma unroll
-    for (int jt = 0; jt < 3; jt++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[it][jt][r] = 0.f;
-  float bsum[3] = {0.f, 0.f, 0.f};
-  // rows are dealt to the WG_WAVES waves of this job in interleaved pairs; WG_UNROLL pairs are loaded before their
-  // MFMAs are issued (the loop is load-latency bound otherwise: one dependent L2 round trip per row pair)
-  for (uint32_t k0 = 2u * blockIdx.x; k0 < n; k0 += 2u * WG_WAVES * WG_UNROLL) {
-    float av[WG_UNROLL][2], bv[WG_UNROLL][3];
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+  float bsum = 0.f;
+  const int kx = job.a_x0 + c;
+  const int apos = job.a_x0 >= 0 ? 18 * (kx & 1) + (kx >> 1) : c;
+  // rows are dealt to the waves of this job in interleaved pairs; WG_UNROLL pairs are loaded before their MFMAs are issued
+  for (uint32_t k0 = 2u * (blockIdx.x * WGM_WAVES + wv); k0 < n; k0 += 2u * WG_WAVES * WGM_WAVES * WG_UNROLL) {
+    float av[WG_UNROLL], bv[WG_UNROLL];
 #pragma unroll
     for (int u = 0; u < WG_UNROLL; u++) {
-      const uint32_t k = k0 + 2u * WG_WAVES * u + (uint32_t)half;
+      const uint32_t k = k0 + 2u * WG_WAVES * WGM_WAVES * u + (uint32_t)half;
       const bool live = k < n;
-      const float* row = rows + (size_t)k * ROW;
-#pragma unroll
-      for (int it = 0; it < 2; it++) {
-        const int i = it * 32 + c;
-        const int kx = job.a_x0 + i;
-        const int apos = job.a_x0 >= 0 ? 18 * (kx & 1) + (kx >> 1) : i;
-        av[u][it] = (live && i < job.M) ? row[job.a_off + apos] : 0.f;
-      }
-#pragma unroll
-      for (int jt = 0; jt < 3; jt++) {
-        const int j = jt * 32 + c;
-        bv[u][jt] = (live && j < job.N) ? row[job.b_off + j] : 0.f;
-      }
+      const float* row = rows + (size_t)k * row_stride;
+      av[u] = (live && c < job.M) ? row[job.a_off + apos] : 0.f;
+      bv[u] = (live && c < job.N) ? row[job.b_off + c] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < WG_UNROLL; u++) {
-#pragma unroll
-      for (int jt = 0; jt < 3; jt++) bsum[jt] += bv[u][jt];
-#pragma unroll
-      for (int it = 0; it < 2; it++)
-#pragma unroll
-        for (int jt = 0; jt < 3; jt++)
-          if (it < nit && jt < njt)
-            acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][it], bv[u][jt], acc[it][jt], 0, 0, 0);
+      bsum += bv[u];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
     }
   }
+#pragma unroll
+  for (int r = 0; r < 16; r++) stage[wv][r * 64 + lane] = acc[r];
+  stage[wv][1024 + lane] = bsum;
+  __syncthreads();
   float* out = partial + ((size_t)blockIdx.y * WG_WAVES + blockIdx.x) * WG_TILE;
-  // partial tile layout: [it][jt][i_local 0..31][j_local 0..31]; C/D map: col = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5).
-  // Only rows i < M are stored; the bias partial of column tile jt goes to row 31 of tile (1, jt), which no job's
-  // weight rows reach (two-i-tile jobs have M <= 36, i.e. local rows 0..3 of tile (1, *)).
+  // partial tile layout: [it][jt][i_local 0..31][j_local 0..31] with it = jt = 0 here; C/D map: col = lane&31,
+  // row = (r&3) + 8 (r>>2) + 4 (lane>>5).  Only rows i < M are stored; the bias partial goes to row 31 of tile (1, 0), which
+  // no job's weight rows reach.
+  for (int e = threadIdx.x; e < 1024; e += WGM_WAVES * 64) {
+    float sum = 0.f;
 #pragma unroll
-  for (int it = 0; it < 2; it++)
+    for (int w = 0; w < WGM_WAVES; w++) sum += stage[w][e];
+    const int r = e >> 6, l = e & 63;
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    if (i < job.M) out[i * 32 + (l & 31)] = sum;
+  }
+  if (threadIdx.x < 32) {
+    float sum = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < 3; jt++)
-      if (it < nit && jt < njt) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (it * 32 + i < job.M) out[((it * 3 + jt) * 32 + i) * 32 + c] = acc[it][jt][r];
-        }
-      }
-#pragma unroll
-  for (int jt = 0; jt < 3; jt++) {
-    const float other = __shfl_xor(bsum[jt], 32, 64);   // the two lane halves summed different rows of one column
-    if (half == 0 && jt < njt) out[((1 * 3 + jt) * 32 + 31) * 32 + c] = bsum[jt] + other;
+    for (int w = 0; w < WGM_WAVES; w++) sum += stage[w][1024 + threadIdx.x] + stage[w][1024 + 32 + threadIdx.x];   // both lane halves
+    out[((1 * 3 + 0) * 32 + 31) * 32 + threadIdx.x] = sum;
   }
 }
 
@@ -1513,15 +1600,20 @@ __global__ void reg_finish_kernel(const uint32_t* count, float* reg_sum, float w
   *reg_sum = 0.f;                                      // a second backward on the same forward state starts from zero again
 }
 
-WJobs make_jobs(const Layout& L) {
+WJobs make_jobs(const Layout& L, bool compact_rows /* the pair backward's 512-B rows (BROW) instead of the one-kernel form's */) {
   WJobs J;
   const int nout[3] = {NO, 7 * NO, 3 * NO};
   for (int m = 0; m < 3; m++) {   // accumulated inside neural_bwd_kernel: only the shapes and destinations matter here
     J.j[m] = WJob{0, FD + 3 + L.dist[m], 0, 0, FD, 0, 0, L.w1[m], L.in[m], L.b1[m], 1, 0};
     J.j[3 + m] = WJob{0, FD, -1, 0, nout[m], 0, 0, L.w2[m], FD, L.b2[m], 1, 0};
   }
-  J.j[6] = WJob{R_X, 4, FD, R_DH + FD * 3, FD, 0, 0, L.fw1, 4, L.fb1, L.bank, 1};
-  J.j[7] = WJob{R_H + FD * 3, FD, -1, R_DF, 3, 0, 0, L.fw2, FD, L.fb2, L.bank, 1};
+  if (compact_rows) {
+    J.j[6] = WJob{RB_X, 4, FD, RB_DH, FD, 0, 0, L.fw1, 4, L.fb1, L.bank, 1};
+    J.j[7] = WJob{RB_H, FD, -1, RB_DF, 3, 0, 0, L.fw2, FD, L.fb2, L.bank, 1};
+  } else {
+    J.j[6] = WJob{R_X, 4, FD, R_DH + FD * 3, FD, 0, 0, L.fw1, 4, L.fb1, L.bank, 1};
+    J.j[7] = WJob{R_H + FD * 3, FD, -1, R_DF, 3, 0, 0, L.fw2, FD, L.fb2, L.bank, 1};
+  }
   return J;
 }
 
@@ -1605,9 +1697,10 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   constexpr size_t pair_lds = pair_run > pair_end ? pair_run : pair_end;
   static_assert(bwd_lds <= 160 * 1024 && pair_lds <= 160 * 1024, "one workgroup per CU");
   auto allow_lds = [](const void* kernel, size_t bytes) { return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
-  const hipError_t attr_rc[3] = {allow_lds(reinterpret_cast<const void*>(neural_bwd_kernel<false>), bwd_lds),
-                                        allow_lds(reinterpret_cast<const void*>(neural_bwd_kernel<true>), bwd_lds),
-                                        allow_lds(reinterpret_cast<const void*>(neural_bwd_pair_kernel), pair_lds)};
+  const hipError_t attr_rc[4] = {allow_lds(reinterpret_cast<const void*>(neural_bwd_kernel<false>), bwd_lds),
+                                 allow_lds(reinterpret_cast<const void*>(neural_bwd_kernel<true>), bwd_lds),
+                                 allow_lds(reinterpret_cast<const void*>(neural_bwd_pair_kernel<false>), pair_lds),
+                                 allow_lds(reinterpret_cast<const void*>(neural_bwd_pair_kernel<true>), pair_lds)};
   for (const hipError_t rc_attr : attr_rc)
     if (rc_attr != hipSuccess) return segs::set_hip_error(rc_attr, __func__);
   // the regulariser sum was cleared by the forward (pack_tables_kernel) and is cleared again by reg_finish_kernel; it is
@@ -1617,10 +1710,10 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   // and works through the scratch rows: the one-kernel form.  SEGS_NEURAL_BWD_ONE_ROLE=1 runs the plain model through that form
   // too (SEGS_NEURAL_ONE_KERNEL_BACKWARD, segs_neural.h: the A/B of profiles/ and tests/test_neural_gpu.py).
   const bool one_role = (g_neural_flags & SEGS_NEURAL_ONE_KERNEL_BACKWARD) != 0u;
-  if (!L.bank && !one_role)
-    neural_bwd_pair_kernel<<<BWD_GRID, 512, pair_lds, st>>>(
+  if (!one_role)
+    (L.bank ? neural_bwd_pair_kernel<true> : neural_bwd_pair_kernel<false>)<<<BWD_GRID, 512, pair_lds, st>>>(
         L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small, camera_center, dL_dmeans3D,
-        dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor, dL_doffset, dL_dfeat, dL_dscaling_log, T.partial,
+        dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor, dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, T.partial,
         scaling_reg_weight, reg_sum);
   else
     (L.bank ? neural_bwd_kernel<true> : neural_bwd_kernel<false>)<<<BWD_GRID, 256, bwd_lds, st>>>(
@@ -1628,8 +1721,8 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
         dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_danchor, dL_doffset, dL_dfeat, dL_dscaling_log, T.rows, T.partial,
         scaling_reg_weight, reg_sum);
   if (scaling_reg_out && L.app == 0) reg_finish_kernel<<<1, 1, 0, st>>>(T.count, reg_sum, scaling_reg_weight, scaling_reg_out);
-  const WJobs J = make_jobs(L);
-  if (L.bank) wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), 64, 0, st>>>(J, T.count, T.rows, T.partial);   // the feature bank's two small Linears
+  const WJobs J = make_jobs(L, !one_role);
+  if (L.bank) wgrad_mfma_kernel<<<dim3(WG_WAVES, WG_JOBS), WGM_WAVES * 64, 0, st>>>(J, T.count, T.rows, T.partial, one_role ? ROW : BROW);   // the feature bank's two small Linears
   wgrad_reduce_kernel<<<dim3((37 * 72 + 15) / 16, WG_JOBS), 256, 0, st>>>(J, T.count, T.partial, T.gsum, dL_dmlp_params);
   if (L.app > 0) appearance_finish_kernel<<<1, 1024, 0, st>>>(L, mlp_params, pose7, T.gsum, dL_dmlp_params, T.count, reg_sum,
                                                               scaling_reg_weight, scaling_reg_out);

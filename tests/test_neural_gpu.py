@@ -269,13 +269,15 @@ def test_second_slab_of_persistent_workgroups_is_consistent(case):
     assert float((big.mlp_grads - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
-def test_wave_pair_backward_equals_the_one_kernel_backward():
-    """The plain model's backward runs as pairs of chain / weight-gradient waves (neural_bwd_pair_kernel); the one-kernel form
-    it replaced (still the feature-bank model's) takes the plain model too under SEGS_NEURAL_ONE_KERNEL_BACKWARD
-    (include/segs_neural.h).  The arithmetic of an anchor is the same in both: per-anchor gradients must be bit-identical."""
+@pytest.mark.parametrize("case", [1, 0])        # plain model (ScanNet dimensions), feature-bank model (Replica dimensions)
+def test_wave_pair_backward_equals_the_one_kernel_backward(case):
+    """The backward runs as pairs of chain / weight-gradient waves (neural_bwd_pair_kernel; since round 4 for the feature-bank
+    model too); the one-kernel form it replaced stays reachable under SEGS_NEURAL_ONE_KERNEL_BACKWARD (include/segs_neural.h).
+    The arithmetic of an anchor is the same in both for the plain model: per-anchor gradients must be bit-identical.  The
+    feature-bank pairs form dL/dfeat through partial sums (register pressure): equal to rounding there."""
     from segs_slam_amd import _capi, neural_gaussians as ng
     dev = torch.device("cuda:0")
-    kw, A = CASES[1], 40001
+    kw, A = CASES[case], 40001
     rd, md = neural_ref.NeuralDims(**kw), ng.ModelDims(**kw)
     anchor, offset, feat, scaling_log, mlp = neural_ref.random_model(rd, A, 91)
     g = torch.Generator().manual_seed(5)
@@ -297,7 +299,11 @@ def test_wave_pair_backward_equals_the_one_kernel_backward():
         outs.append(m.grads.cpu().numpy().copy())
     assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
     n_anchor = A * (3 + 30 + 32 + 6)   # the four per-anchor segments of the bucket; the MLP block follows
-    assert np.array_equal(outs[0][:n_anchor], outs[1][:n_anchor])
+    if not kw["use_feat_bank"]:
+        assert np.array_equal(outs[0][:n_anchor], outs[1][:n_anchor])
+    else:
+        a, b = outs[0][:n_anchor], outs[1][:n_anchor]
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max() and np.mean(a != b) < 0.5
     # the visible-anchor list is compacted with one atomic per 2048 anchors, so its block order -- and with it the order in which
     # the MLP weight gradients are summed -- differs from run to run: same bound as the split-model test above
     a, b = outs[0][n_anchor:], outs[1][n_anchor:]
