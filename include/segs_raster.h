@@ -121,6 +121,13 @@ int segs_visible_filter(int P, int M, int width, int height, const float* means3
                         const float* viewmatrix, const float* projmatrix, float tan_fovx, float tan_fovy,
                         int prefiltered, int* radii, void* stream);
 
+/* The same with the scales given as the model stores them: `scaling_log` holds rows of `stride` floats whose first three are
+ * log-scales (GaussianModel::_scaling, exp applied as get_scaling does, src/gaussian_renderer.cpp:150-152), rotations already
+ * normalised, scale_modifier 1 -- prefilter_voxel's call without the intermediate exp(...)[:, :3] tensor and its kernels. */
+int segs_visible_filter_log_scales(int P, int width, int height, const float* means3D, const float* scaling_log, int stride,
+                                   const float* rotations, const float* viewmatrix, const float* projmatrix, float tan_fovx,
+                                   float tan_fovy, int* radii, void* stream);
+
 /* CudaRasterizer::Rasterizer::markVisible (cuda_rasterizer/rasterizer.h:29-34, rasterizer_impl.cu:141-153).
  * `present` is P bytes (bool). */
 int segs_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -56,6 +56,7 @@ SYMBOLS = {
     "segs_rasterize_backward_resident": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp,
                                                _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "segs_visible_filter": (_i, [_i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),
+    "segs_visible_filter_log_scales": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     "segs_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "segs_project2_image": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i,
                                   _vp, _vp, _vp, _vp]),

@@ -499,10 +499,29 @@ int segs_rasterize_backward(int P, int D, int M, int R, const float* background,
                                  dL_dscale, dL_drot, stream, false, P);
 }
 
+static int visible_filter_impl(int P, int width, int height, const float* means3D, const float* scales, int log_scale_stride,
+                               float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                               const float* projmatrix, float tan_fovx, float tan_fovy, int* radii, void* stream);
+
 int segs_visible_filter(int P, int M, int width, int height, const float* means3D, const float* scales,
                         float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                         const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered, int* radii, void* stream) {
   (void)M; (void)prefiltered;
+  return visible_filter_impl(P, width, height, means3D, scales, 0, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                             tan_fovx, tan_fovy, radii, stream);
+}
+
+int segs_visible_filter_log_scales(int P, int width, int height, const float* means3D, const float* scaling_log, int stride,
+                                   const float* rotations, const float* viewmatrix, const float* projmatrix, float tan_fovx,
+                                   float tan_fovy, int* radii, void* stream) {
+  if (stride < 3 || !scaling_log || !rotations) return fail(SEGS_ERR_INVALID_ARGUMENT, "need log-scales (stride >= 3) and rotations");
+  return visible_filter_impl(P, width, height, means3D, scaling_log, stride, 1.0f, rotations, nullptr, viewmatrix, projmatrix, tan_fovx,
+                             tan_fovy, radii, stream);
+}
+
+static int visible_filter_impl(int P, int width, int height, const float* means3D, const float* scales, int log_scale_stride,
+                               float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                               const float* projmatrix, float tan_fovx, float tan_fovy, int* radii, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (P < 0 || width <= 0 || height <= 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad sizes");
   if (P == 0) return SEGS_OK;
@@ -512,7 +531,7 @@ int segs_visible_filter(int P, int M, int width, int height, const float* means3
   const uint32_t gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
   visible_filter_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, means3D, cov3D_precomp ? nullptr : scales, scale_modifier, rotations,
                                                          cov3D_precomp, viewmatrix, projmatrix, width, height, tan_fovx, tan_fovy,
-                                                         focal_x, focal_y, gx, gy, radii);
+                                                         focal_x, focal_y, gx, gy, radii, log_scale_stride);
   LAUNCH_TRY("visible_filter_kernel");
   return SEGS_OK;
 }

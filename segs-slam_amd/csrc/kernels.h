@@ -30,7 +30,8 @@ __global__ void visible_filter_kernel(
     int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, int W, int H,
-    float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy, int* __restrict__ radii);
+    float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy, int* __restrict__ radii,
+    int log_scale_stride);
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ viewmatrix,
                                     uint8_t* __restrict__ present);

@@ -348,14 +348,23 @@ __global__ void __launch_bounds__(256) visible_filter_kernel(
     int P, const float* __restrict__ means3D, const float* __restrict__ scales, float mod,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, int W, int H,
-    float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy, int* __restrict__ radii) {
+    float tan_fovx, float tan_fovy, float focal_x, float focal_y, uint32_t gx, uint32_t gy, int* __restrict__ radii,
+    int log_scale_stride /* > 0: `scales` holds LOG-scales in rows of this many floats and the first three are used through
+    exp(): prefilter_voxel's get_scaling()[:, :3] (src/gaussian_renderer.cpp:150-152) without the intermediate tensor */) {
   __shared__ float lds[768];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const float3 p = load_row3(means3D, P, lds);
   float3 sc = make_float3(0, 0, 0);
   float4 rot = make_float4(0, 0, 0, 0);
   if (scales) {
-    sc = load_row3(scales, P, lds);
+    if (log_scale_stride > 0) {
+      if (idx < P) {
+        const float* r = scales + (size_t)idx * log_scale_stride;
+        sc = make_float3(expf(r[0]), expf(r[1]), expf(r[2]));
+      }
+    } else {
+      sc = load_row3(scales, P, lds);
+    }
     if (idx < P) rot = reinterpret_cast<const float4*>(rotations)[idx];
   }
   if (idx >= P) return;

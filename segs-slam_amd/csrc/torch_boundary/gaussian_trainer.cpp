@@ -226,15 +226,16 @@ void GaussianTrainerStep::learning_rates(int64_t it, std::vector<double>& lr) co
 
 // prefilter_voxel (src/gaussian_renderer.cpp:131-199): radii of the anchors drawn as Gaussians with exp(scaling[:, :3])
 void GaussianTrainerStep::prefilter(const KeyframeView& kf) {
-  auto scales = torch::exp(model_.param("scaling").slice(1, 0, 3)).contiguous();
   // _rotation is never trained: normalise it again only when densification rewrote rows
   if (rot_rows_ != model_.A || !rot_normalized_.defined()) {
     rot_normalized_ = torch::nn::functional::normalize(model_.rotation.slice(0, 0, model_.A)).contiguous();
     rot_rows_ = model_.A;
   }
-  check(segs_visible_filter((int)model_.A, 0, W_, H_, fp(model_.param("anchor")), fp(scales), 1.0f, fp(rot_normalized_), nullptr,
-                            fp(kf.view), fp(kf.proj), kf.tanfovx, kf.tanfovy, 0, visible_radii_.data_ptr<int>(), cur_stream(dev_)),
-        "segs_visible_filter");
+  // (exp(_scaling[:, :3]) is formed inside the kernel from the rows of 6 log-scales: no intermediate tensor)
+  check(segs_visible_filter_log_scales((int)model_.A, W_, H_, fp(model_.param("anchor")), model_.seg_ptr(model_.params, "scaling"), 6,
+                                       fp(rot_normalized_), fp(kf.view), fp(kf.proj), kf.tanfovx, kf.tanfovy,
+                                       visible_radii_.data_ptr<int>(), cur_stream(dev_)),
+        "segs_visible_filter_log_scales");
 }
 
 // the asynchronous status read-back of the previous resident forward: an overflow sends the next pass through the

@@ -469,16 +469,16 @@ class ScaffoldTrainerStep:
         """radii of the anchors drawn as Gaussians with exp(scaling[:, :3]) and normalize(rotation)
         (src/gaussian_renderer.cpp:131-199); the result stays on the device."""
         m = self.model
-        scales = torch.exp(m.param("scaling")[:, :3]).contiguous()
         # _rotation is never trained (src/gaussian_model.cpp:372): normalise it again only when densification rewrote rows
         key = (m.A, m.rotation._version, m.rotation.data_ptr())
         if getattr(self, "_rot_key", None) != key:
             self._rot_key, self._rot_normalized = key, torch.nn.functional.normalize(m.rotation[:m.A]).contiguous()
         rots = self._rot_normalized
-        st = self._lib.segs_visible_filter(m.A, 0, self.W, self.H, _p(m.param("anchor")), _p(scales), 1.0, _p(rots), None,
-                                           _p(kf.view), _p(kf.proj), float(kf.tanfovx), float(kf.tanfovy), 0,
-                                           _p(self.visible_radii), self._stream())
-        _capi.check(st, "segs_visible_filter")
+        # get_scaling()[:, :3] = exp(_scaling[:, :3]) is formed inside the kernel (rows of 6 log-scales): no intermediate tensor
+        st = self._lib.segs_visible_filter_log_scales(m.A, self.W, self.H, _p(m.param("anchor")), _p(m.param("scaling")), 6, _p(rots),
+                                                      _p(kf.view), _p(kf.proj), float(kf.tanfovx), float(kf.tanfovy),
+                                                      _p(self.visible_radii), self._stream())
+        _capi.check(st, "segs_visible_filter_log_scales")
         return self.visible_radii
 
     def use_level(self, width: int, height: int):

@@ -24,7 +24,7 @@ def test_trainer_twin_is_built_and_links_the_c_abi():
     for cls in ("segs_host::AnchorDensifier::adjust_anchor(", "segs_host::AnchorDensifier::training_statis(",
                 "segs_host::KeyframeExchange::reduce_gradients(", "segs_host::KeyframeExchange::gather("):
         assert any(cls in l and " T " in l for l in out.splitlines()), cls
-    for sym in ("segs_visible_filter", "segs_neural_forward", "segs_rasterize_forward_resident", "segs_l1_ssim_loss",
+    for sym in ("segs_visible_filter_log_scales", "segs_neural_forward", "segs_rasterize_forward_resident", "segs_l1_ssim_loss",
                 "segs_rasterize_backward_resident", "segs_neural_backward", "segs_adam_step_device", "segs_training_statis_guarded",
                 "segs_anchor_growing_level"):
         assert any(l.strip().endswith("U " + sym) for l in out.splitlines()), sym      # resolved from libsegs_raster.so
