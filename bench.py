@@ -82,6 +82,7 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (exercises the RCCL calls on a one-GPU box)")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel table to stderr")
+    ap.add_argument("--fuse-projection", type=int, default=1, help="scaffold mode: 1 = the neural forward runs the rasterizer's per-Gaussian stage itself (SURVEY 8f n3)")
     ap.add_argument("--neural-flags", type=int, default=0, help="segs_neural_set_flags bits for A/B profiles (1 = SEGS_NEURAL_ONE_KERNEL_BACKWARD)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra blocks of the line (mapper_step, config3, render_only_ms): A/B runs and profiles")
@@ -182,6 +183,7 @@ def main():
         dims = ng.ModelDims(appearance_dim=args.appearance_dim, use_feat_bank=not args.no_feat_bank)
         model = ng.synthetic_model(args.anchors, dims, cam, dev, seed=0)   # replicas must be identical; the keyframe differs per rank
         tstep = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
+        tstep.fuse_projection = bool(args.fuse_projection)
         tstep.sharded_optimizer = sharded_opt
         tstep.single_rank_collectives = args.force_dist
         eng = tstep.engine

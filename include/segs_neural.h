@@ -69,6 +69,23 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
                         float* colors, float* opacity, float* scales, float* rotations, float* neural_opacity,
                         char* temp, void* stream);
 
+/* Forward that also runs the rasterizer's per-Gaussian stage (K1) on the candidates it generates and writes K1's outputs
+ * into the resident rasterizer buffers `targets` describes (segs_raster.h: segs_resident_projection_targets); follow it with
+ * segs_rasterize_forward_resident_projected.  The candidate's colour and opacity then exist only inside its 64-byte record:
+ * there are no `colors` / `opacity` outputs.  means3D, scales, rotations (what the rasterizer backward re-reads) and
+ * neural_opacity are written as by segs_neural_forward; rows of candidates with neural opacity <= 0 and of invisible anchors
+ * get radius 0 (src/gaussian_renderer.cpp:279,320: the reference compacts them away).  viewmatrix / projmatrix (4x4,
+ * column-major as the rasterizer takes them) are DEVICE arrays.  Image, radii and every gradient equal those of
+ * segs_neural_forward + segs_rasterize_forward_resident bit for bit. */
+struct segs_projection_targets;
+int segs_neural_forward_projected(const segs_neural_dims* dims, int A, const float* anchor, const float* offset,
+                                  const float* anchor_feat, const float* scaling_log, const int* visible_radii,
+                                  const float* mlp_params, const float* camera_center, const float* pose7, float* means3D,
+                                  float* scales, float* rotations, float* neural_opacity,
+                                  const struct segs_projection_targets* targets, const float* viewmatrix,
+                                  const float* projmatrix, int width, int height, float tan_fovx, float tan_fovy,
+                                  float scale_modifier, char* temp, void* stream);
+
 /* Backward of the above for the same inputs and the same `temp` (the visible list of the forward call is reused).
  * dL_d{means3D,colors,opacity,scales,rotations}: candidate-domain gradients as produced by the rasterizer backward;
  * slots with neural opacity <= 0 are ignored (the reference's mask index passes no gradient to them).

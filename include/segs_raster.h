@@ -199,6 +199,32 @@ int segs_rasterize_backward_resident(char* geom_buffer, char* binning_buffer, ch
                                      float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                                      float* dL_dsh, float* dL_dscale, float* dL_drot, void* stream);
 
+/* ---- A producer that projects its own Gaussians (segs_neural_forward_projected, segs_neural.h).
+ * The resident forward is K1 (per-Gaussian projection, cuda_rasterizer/forward.cu:155-256) + binning + tile kernel.  A
+ * kernel that GENERATES the Gaussians can run K1's arithmetic on them while they are in registers and leave K1's outputs
+ * where the rest of the forward expects them; segs_resident_projection_targets says where that is for one set of resident
+ * buffers (same arguments as segs_rasterize_forward_resident; `radii` NULL = the buffer's internal array), and
+ * segs_rasterize_forward_resident_projected is the forward without K1: binning and tile kernel over what the producer left.
+ * Per Gaussian row i < P the producer writes  radii[i] (0 = culled),  tiles_touched[i],  depth_keys[i] (bits of the view
+ * depth, 0xFFFFFFFF when no tile is touched)  and, for radii[i] > 0, the 64-byte record records[16 i ..] -- all exactly as
+ * preprocess_fwd_kernel would; it resets tile_ranges[t] = {0xFFFFFFFF, 0} for t < num_tiles and sets *depth_overflow = 1
+ * when a binned depth leaves the sort's key range.  `flags` carries the tight-rectangle switch for the record builder. */
+typedef struct segs_projection_targets {
+  float* records;
+  int* radii;
+  uint32_t* tiles_touched;
+  uint32_t* depth_keys;
+  uint32_t* tile_ranges;      /* num_tiles x {start, end} */
+  uint32_t* depth_overflow;
+  int num_tiles;
+  uint32_t flags;
+} segs_projection_targets;
+int segs_resident_projection_targets(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity, int geom_rows,
+                                     int P, int width, int height, int* radii, uint32_t* status, segs_projection_targets* out);
+int segs_rasterize_forward_resident_projected(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity,
+                                              int geom_rows, int P, const float* background, int width, int height,
+                                              float* out_color, uint32_t* status, void* stream);
+
 /* ---- Measurement support (bench.py): per-kernel timing with HIP events recorded on the launch stream.
  * kernel_mask bit i selects kernel id i (ids 0..segs_profile_kernel_count()-1, names via
  * segs_profile_kernel_name).  segs_profile_end() synchronises the recorded events and accumulates;

@@ -24,6 +24,12 @@ class NeuralDims(C.Structure):
                 ("add_opacity_dist", C.c_int), ("add_cov_dist", C.c_int), ("add_color_dist", C.c_int)]
 
 
+class ProjectionTargets(C.Structure):
+    """segs_projection_targets (include/segs_raster.h)."""
+    _fields_ = [("records", C.c_void_p), ("radii", C.c_void_p), ("tiles_touched", C.c_void_p), ("depth_keys", C.c_void_p),
+                ("tile_ranges", C.c_void_p), ("depth_overflow", C.c_void_p), ("num_tiles", C.c_int), ("flags", C.c_uint32)]
+
+
 class AdamSegment(C.Structure):
     """segs_adam_segment (include/segs_train.h)."""
     _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("lr", C.c_double)]
@@ -42,6 +48,7 @@ SYMBOLS = {
     "segs_neural_param_layout": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "segs_neural_temp_bytes": (_sz, [_vp, _i]),
     "segs_neural_forward": (_i, [_vp, _i] + [_vp] * 16),
+    "segs_neural_forward_projected": (_i, [_vp, _i] + [_vp] * 15 + [_i, _i, _f, _f, _f, _vp, _vp]),
     "segs_neural_backward": (_i, [_vp, _i] + [_vp] * 17 + [_f, _vp, _vp, _vp]),
     "segs_geometry_bytes": (_sz, [_i]),
     "segs_image_bytes": (_sz, [_i, _i]),
@@ -53,6 +60,8 @@ SYMBOLS = {
     "segs_resident_binning_bytes": (_sz, [_i, _i]),
     "segs_rasterize_forward_resident": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp,
                                               _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "segs_resident_projection_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "segs_rasterize_forward_resident_projected": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "segs_rasterize_backward_resident": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp,
                                                _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "segs_visible_filter": (_i, [_i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),

@@ -735,6 +735,59 @@ int segs_rasterize_forward_resident(char* geom_buffer, char* binning_buffer, cha
   return SEGS_OK;
 }
 
+// ---- K1 done by the producer of the Gaussians (segs_neural_forward_projected): where its outputs go, and the forward without K1.
+int segs_resident_projection_targets(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity, int geom_rows, int P,
+                                     int width, int height, int* radii, uint32_t* status, segs_projection_targets* out) {
+  if (P <= 0 || capacity <= 0 || width <= 0 || height <= 0 || !out) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (geom_rows < P) return fail(SEGS_ERR_INVALID_ARGUMENT, "geom_rows (rows the geometry buffer was sized for) must be >= P");
+  if (geom_rows > MAX_GAUSSIANS) return fail(SEGS_ERR_INVALID_ARGUMENT, "P exceeds 2^28 Gaussians");
+  if (!geom_buffer || !binning_buffer || !image_buffer || !status) return fail(SEGS_ERR_INVALID_ARGUMENT, "null required pointer");
+  const uint32_t gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+  if (gx > 0xFFFFu || gy > 0xFFFFu) return fail(SEGS_ERR_INVALID_ARGUMENT, "image too large for 16-bit tile coordinates");
+  Geom G = geom_at(geom_buffer, P, geom_rows);
+  const ImageLayout IL = image_layout(width, height);
+  const GaussSortLayout GS = gauss_sort_layout(capacity, P);
+  const int gside = (3 & 1);   // as in segs_rasterize_forward_resident: three 9-bit depth passes start from side 1
+  out->records = G.rec();
+  out->radii = radii ? radii : G.radii_internal();
+  out->tiles_touched = G.touched();
+  out->depth_keys = (uint32_t*)(align_ptr(binning_buffer) + GS.base + GS.inner.keys[gside]);
+  out->tile_ranges = (uint32_t*)(align_ptr(image_buffer) + IL.ranges);
+  out->depth_overflow = status + 2;
+  out->num_tiles = (int)(gx * gy);
+  out->flags = (g_flags & SEGS_RASTER_KEEP_DEAD_INSTANCES) ? 0u : PREPROCESS_TIGHT_RECT;
+  return SEGS_OK;
+}
+
+int segs_rasterize_forward_resident_projected(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity, int geom_rows, int P,
+                                              const float* background, int width, int height, float* out_color, uint32_t* status,
+                                              void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (P <= 0 || capacity <= 0 || width <= 0 || height <= 0) return fail(SEGS_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (geom_rows < P) return fail(SEGS_ERR_INVALID_ARGUMENT, "geom_rows (rows the geometry buffer was sized for) must be >= P");
+  if (geom_rows > MAX_GAUSSIANS) return fail(SEGS_ERR_INVALID_ARGUMENT, "P exceeds 2^28 Gaussians");
+  if (!geom_buffer || !binning_buffer || !image_buffer || !status || !background || !out_color)
+    return fail(SEGS_ERR_INVALID_ARGUMENT, "null required pointer");
+  const uint32_t gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+  if (gx > 0xFFFFu || gy > 0xFFFFu) return fail(SEGS_ERR_INVALID_ARGUMENT, "image too large for 16-bit tile coordinates");
+  Geom G = geom_at(geom_buffer, P, geom_rows);
+  char* img = align_ptr(image_buffer);
+  char* bin = align_ptr(binning_buffer);
+  const ImageLayout IL = image_layout(width, height);
+  const BinningLayout BL = binning_layout(capacity);
+  const GaussSortLayout GS = gauss_sort_layout(capacity, P);
+  uint2* ranges = (uint2*)(img + IL.ranges);
+  int rc = run_binning(G, bin, BL, GS, ranges, P, capacity, status, DEPTH_KEY_MIN, DEPTH_KEY_BITS, 0xFFFFFFFFu, gx, gy, status, st, true,
+                       (g_flags & SEGS_RASTER_KEEP_DEAD_INSTANCES) == 0u, true);
+  if (rc) return rc;
+  { PROF(K_RENDER_FWD);
+  render_fwd_kernel<<<gx * gy, 256, 0, st>>>(ranges, (const uint32_t*)(bin + BL.vals[0]), width, height, G.rec(), background,
+                                                  (float*)(img + IL.final_T), (uint32_t*)(img + IL.n_contrib), out_color);
+  }
+  LAUNCH_TRY("render_fwd_kernel");
+  return SEGS_OK;
+}
+
 int segs_rasterize_backward_resident(char* geom_buffer, char* binning_buffer, char* image_buffer, int capacity, int geom_rows, int P, int D, int M,
                                      const float* background, int width, int height, const float* means3D, const float* shs,
                                      const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,

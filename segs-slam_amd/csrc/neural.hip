@@ -27,6 +27,8 @@
 #include "../../include/segs_neural.h"
 #include "../../include/segs_raster.h"
 #include "kernels.h"
+#include "project_gaussian.h"
+#pragma clang fp contract(fast)   // (project_gaussian.h switches contraction off for its own functions; the MLPs may contract)
 
 namespace {
 
@@ -400,15 +402,34 @@ constexpr int FWD_WAVES = 8;
 constexpr int STG_ROW = 100;                       // floats per anchor of the covariance phase: rotations 0..39 | scales 40..69 | means 70..99
 constexpr int STG_WAVE = 32 * STG_ROW + 32;        // + the slab's anchor indices
 constexpr size_t FWD_LDS = (N_IMG_FWD * 64 + FWD_WAVES * STG_WAVE) * sizeof(float) + sizeof(Small);
-static_assert(FWD_LDS <= 160 * 1024, "one forward workgroup per CU");
+// The projecting forward adds 32 records x 16 dwords per wave behind the anchor indices: the 64-byte records leave
+// through it half a wave at a time (as in preprocess_fwd_kernel), the slab's neural opacities before that.
+constexpr int STG_SPARE = 32 * segs::REC_DWORDS;
+static_assert(32 * NO + 32 * NO / 2 <= STG_SPARE, "the slab's opacities + the dense list of its live candidates (u16) share that space");
+constexpr int STG_WAVE_PROJ = STG_WAVE + STG_SPARE;
+constexpr size_t FWD_LDS_PROJ = (N_IMG_FWD * 64 + FWD_WAVES * STG_WAVE_PROJ) * sizeof(float) + sizeof(Small);
+static_assert(FWD_LDS <= 160 * 1024 && FWD_LDS_PROJ <= 160 * 1024, "one forward workgroup per CU");
+
+// What the projecting forward needs of the rasterizer's resident state (segs_projection_targets) and of the camera.
+struct Proj {
+  float* rec; int* radii; uint32_t* touched; uint32_t* keys; uint32_t* overflow;
+  const float* view; const float* proj;
+  int W, H;
+  float tanx, tany, fx, fy, mod;
+  uint32_t gx, gy, flags;
+};
 
 // 2048 anchors per workgroup (eight rounds of 256) and ONE returning atomic on the list's count per workgroup: the count is a
 // single word, which takes about 12 ns per returning atomic whatever the parallelism -- with one per 256 anchors this kernel
 // spent 14 of its 17 us at 300 k anchors queueing on it.
 constexpr int CV_ROUNDS = 8;
+// proj_radii != null (projecting forward): the candidates of invisible anchors get what K1 would have left for them -- radius 0,
+// no tiles, the culled depth key -- instead of a zero opacity for K1 to find, and the tile range table is reset here.
 __global__ void __launch_bounds__(256) compact_visible_kernel(int A, const int* __restrict__ radii, uint32_t* __restrict__ count,
                                                               uint32_t* __restrict__ vis, float* __restrict__ opacity,
-                                                              float* __restrict__ neural_opacity) {
+                                                              float* __restrict__ neural_opacity, int* __restrict__ proj_radii,
+                                                              uint32_t* __restrict__ proj_touched, uint32_t* __restrict__ proj_keys,
+                                                              uint2* __restrict__ ranges, int num_tiles) {
   __shared__ uint32_t wave_n[CV_ROUNDS][4], block_base;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int a0 = blockIdx.x * (256 * CV_ROUNDS) + threadIdx.x;
@@ -439,19 +460,36 @@ __global__ void __launch_bounds__(256) compact_visible_kernel(int A, const int* 
     const bool v = (mine >> r) & 1u;
     if (v) vis[mybase + below[r]] = (uint32_t)a;
     if (a < A && !v) {
+      if (proj_radii) {
 #pragma unroll
-      for (int k = 0; k < NO; k++) { opacity[(size_t)a * NO + k] = 0.f; neural_opacity[(size_t)a * NO + k] = 0.f; }
+        for (int k = 0; k < NO; k++) {
+          neural_opacity[(size_t)a * NO + k] = 0.f;
+          proj_radii[(size_t)a * NO + k] = 0; proj_touched[(size_t)a * NO + k] = 0u; proj_keys[(size_t)a * NO + k] = 0xFFFFFFFFu;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NO; k++) { opacity[(size_t)a * NO + k] = 0.f; neural_opacity[(size_t)a * NO + k] = 0.f; }
+      }
     }
     base += wave_n[r][0] + wave_n[r][1] + wave_n[r][2] + wave_n[r][3];
   }
+  if (ranges)
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(segs::RANGE_EMPTY_START, 0u);
 }
 
+// PROJECT (src/gaussian_renderer.cpp:299-333 feeding cuda_rasterizer/forward.cu:155-256): the wave also runs K1 on the
+// candidates it generates -- project_gaussian with contraction off, bit for bit what preprocess_fwd_kernel computes from the arrays
+// this kernel would have written -- and leaves the 64-byte record, radius, tile count and depth key in the rasterizer's resident
+// buffers.  Colours and opacities then live only in the records; means / scales / rotations are still written (the rasterizer's
+// backward re-reads them), and neural_opacity (densification statistics).  The tiles run covariance first, so that a candidate's
+// opacity and colour are in registers when its geometry is read back from the staging rows.
+template <bool PROJECT>
 __global__ void __launch_bounds__(FWD_WAVES * 64, 1) neural_fwd_kernel(
     Layout L, const uint32_t* __restrict__ count, const uint32_t* __restrict__ vis, const float* __restrict__ anchor,
     const float* __restrict__ offset, const float* __restrict__ anchor_feat, const float* __restrict__ scaling_log,
     const float* __restrict__ g_img, const Small* __restrict__ g_small, const float* __restrict__ campos,
     float* __restrict__ means3D, float* __restrict__ colors, float* __restrict__ opacity, float* __restrict__ scales,
-    float* __restrict__ rotations, float* __restrict__ neural_opacity, uint32_t* __restrict__ n_kept) {
+    float* __restrict__ rotations, float* __restrict__ neural_opacity, uint32_t* __restrict__ n_kept, Proj pj) {
   extern __shared__ __align__(16) float lds_dyn[];
   float* img = lds_dyn;
   Small& S = *reinterpret_cast<Small*>(lds_dyn + N_IMG_FWD * 64);
@@ -468,8 +506,16 @@ __global__ void __launch_bounds__(FWD_WAVES * 64, 1) neural_fwd_kernel(
   // The anchor INDEX runs two slabs ahead: the data request of slab k + 1 then starts from an index that arrived a slab ago, not
   // from one it has to wait for (index -> data was one exposed round trip per slab, behind the previous slab's stores).
   const uint32_t stride = gridDim.x * (FWD_WAVES * 32u);
-  float* const stg = lds_dyn + N_IMG_FWD * 64 + sizeof(Small) / 4 + wv * STG_WAVE;
+  float* const stg = lds_dyn + N_IMG_FWD * 64 + sizeof(Small) / 4 + wv * (PROJECT ? STG_WAVE_PROJ : STG_WAVE);
   uint32_t* const stg_a = reinterpret_cast<uint32_t*>(stg + 32 * STG_ROW);
+  float* const spare = stg + STG_WAVE;   // PROJECT only
+  // the camera, read once (uniform: scalar registers) -- left behind pj.view / pj.proj every candidate would re-read the 32 floats
+  // after each store, which the compiler cannot tell apart from them
+  float cam_view[16], cam_proj[16];
+  if (PROJECT) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) { cam_view[i] = pj.view[i]; cam_proj[i] = pj.proj[i]; }
+  }
   auto index_of = [&](uint32_t g) { const uint32_t t = g + col; return vis[t < n ? t : n - 1]; };
   RawAnchor raw_nx;
   float off_nx[15];
@@ -489,7 +535,10 @@ __global__ void __launch_bounds__(FWD_WAVES * 64, 1) neural_fwd_kernel(
     float off_q[15];   // offsets of the candidates still to come, the next covariance tile's two in front
 #pragma unroll
     for (int q = 0; q < 15; q++) off_q[q] = off_nx[q];
-    if (g0 + stride < n) request(a_next);
+    // (PROJECT: the request goes out after the covariance tiles, which run first there and are where the registers are scarcest --
+    // the 56 registers it lands in are then not held through them; the opacity / projection / colour phases still cover its latency)
+    const bool more = g0 + stride < n;
+    if (!PROJECT && more) request(a_next);
     a_cur = a_next;
     a_next = index_of(g0 + 2u * stride);
     AnchorLane st;
@@ -501,43 +550,167 @@ __global__ void __launch_bounds__(FWD_WAVES * 64, 1) neural_fwd_kernel(
     if (h == 0) stg_a[col] = a;
     // runs of RUN elements (float2, or float4 for the rotations) per anchor, staged at stg + slot * ROW + OFF, to dst + anchor * RUN
     // (all of a field's LDS reads are issued before its first store: a rolled loop pays an LDS round trip per iteration)
+    // PROJECT: the lane number the output staging indexes with is made opaque once per slab -- left visible, the dozens of LDS
+    // addresses derived from it are hoisted out of the slab loop, and with the projection's registers on top the kernel spills
+    // (46 registers; a reload of one waits for every output store issued before it: vmcnt counts in order).
+    uint32_t fl = (uint32_t)lane;
+    if (PROJECT) asm volatile("" : "+v"(fl));
+    const int pc = (int)(fl & 31u), ph = (int)(fl >> 5);   // col, h for the projecting branches
     auto flush2 = [&](float* __restrict__ dst, int row, int off, auto run_c /* float2 per anchor */) {
       constexpr uint32_t run = decltype(run_c)::value, ITER = (32u * run + 63u) / 64u;
       float2 v[ITER];
       uint32_t at[ITER];
 #pragma unroll
       for (uint32_t i = 0; i < ITER; i++) {
-        const uint32_t e = lane + 64u * i, s = min(e / run, 31u), k = e - (e / run) * run;
+        const uint32_t e = fl + 64u * i, s = min(e / run, 31u), k = e - (e / run) * run;
         v[i] = *reinterpret_cast<const float2*>(stg + s * row + off + 2 * k);
         at[i] = stg_a[s] * run + k;
       }
 #pragma unroll
       for (uint32_t i = 0; i < ITER; i++)
-        if (lane + 64u * i < nv * run) reinterpret_cast<float2*>(dst)[at[i]] = v[i];
+        if (fl + 64u * i < nv * run) reinterpret_cast<float2*>(dst)[at[i]] = v[i];
     };
     using R5 = std::integral_constant<uint32_t, 5u>;
     using R15 = std::integral_constant<uint32_t, 15u>;
-#pragma unroll 1
-    for (int tile = 0; tile < N_TILES; tile++) {
+    auto do_tile = [&](const int tile) __attribute__((always_inline)) {
       if (tile <= 2) hp = layer1(img, S, tile_mlp(tile), lane, h, st.xo);
       const f32x16 o = layer2(img, S, tile, lane, h, hp);
       if (tile == 0) {
-        if (valid) {
+        float* const ostg = PROJECT ? spare : stg;   // (PROJECT: the rows still hold the slab's geometry)
+        bool live[5];
 #pragma unroll
-          for (int r = 0; r < 5; r++) { const float op = fast_tanh(o[r]); kept += op > 0.f ? 1u : 0u; stg[col * 10 + 5 * h + r] = op; }
+        for (int r = 0; r < 5; r++) {
+          const float op = fast_tanh(o[r]);
+          live[r] = valid && op > 0.f;
+          if (valid) { kept += op > 0.f ? 1u : 0u; ostg[col * 10 + 5 * h + r] = op; }
         }
         asm volatile("" ::: "memory");   // (a wave's LDS instructions complete in order)
-        flush2(neural_opacity, 10, 0, R5());
-        flush2(opacity, 10, 0, R5());
+        flush2(neural_opacity, 10, PROJECT ? STG_WAVE : 0, R5());
+        if (!PROJECT) flush2(opacity, 10, 0, R5());
         asm volatile("" ::: "memory");
-      } else if (tile == 1) {
-        if (valid) {
+        if (PROJECT) {
+          // K1 on the slab's LIVE candidates (neural opacity > 0: the ones the reference's mask keeps, src/gaussian_renderer.cpp:279,320
+          // -- SEGS_RASTER_SKIP_NONPOSITIVE_OPACITY in K1), packed: typically a third of the 320, so two passes of 64 lanes where a
+          // pass per own candidate takes five, and the ~750 instructions of the projection are what a pass costs.  Dense order:
+          // candidate cc of any lane before candidate cc' > cc; `list` maps a dense index to the candidate slot * 10 + k, whose
+          // opacity sits at spare[slot * 10 + k].  A pass rewrites its candidates' row slots IN PLACE with what the record needs:
+          //   rotation slot (row + 4k): radius | rect_min | rect_max | opacity     scale slot (row + 40 + 3k): x | y | depth
+          //   mean slot (row + 70 + 3k): conic A | B | C
+          // (tile count and depth key follow from rect and depth); the colour tile below assembles the 64-byte records from them.
+          float* const row = stg + pc * STG_ROW;
+          uint16_t* const list = reinterpret_cast<uint16_t*>(spare + 32 * NO);
+          uint32_t n_live = 0u;
+          const uint64_t lt_mask = (1ull << fl) - 1ull;
 #pragma unroll
-          for (int r = 0; r < 15; r++) stg[col * 30 + 15 * h + r] = sigmoidf(o[r]);
+          for (int cc = 0; cc < 5; cc++) {
+            const uint64_t m = __ballot(live[cc]);
+            const int k = 5 * ph + cc;
+            if (live[cc]) list[n_live + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)(pc * NO + k);
+            else if (valid) *reinterpret_cast<float4*>(row + 4 * k) = make_float4(0.f, 0.f, 0.f, 0.f);   // radius 0, empty rectangle
+            n_live += (uint32_t)__popcll(m);
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll 1
+          for (uint32_t j0 = 0; j0 < n_live; j0 += 64u) {
+            if (j0 + fl < n_live) {
+              const uint32_t cand = list[j0 + fl];
+              const uint32_t cs = cand / 10u, ck = cand - cs * 10u;
+              float* const crow = stg + cs * STG_ROW;
+              const float op = spare[cand];
+              const float4 quat = *reinterpret_cast<const float4*>(crow + 4 * ck);
+              const float3 sc = make_float3(crow[40 + 3 * ck], crow[41 + 3 * ck], crow[42 + 3 * ck]);
+              const float3 mean = make_float3(crow[70 + 3 * ck], crow[71 + 3 * ck], crow[72 + 3 * ck]);
+              segs::Projected g = segs::project_gaussian(mean, sc, pj.mod, quat, nullptr, cam_view, cam_proj, pj.W, pj.H, pj.tanx, pj.tany,
+                                                         pj.fx, pj.fy, pj.gx, pj.gy);
+              float4 head = make_float4(0.f, 0.f, 0.f, op);
+              if (g.radius > 0) {
+                const segs::BinnedRecord br = segs::make_record(g, op, make_float3(0.f, 0.f, 0.f), pj.flags);
+                head = make_float4(__int_as_float(g.radius), __uint_as_float(br.rect_min), __uint_as_float(br.rect_max), op);
+                crow[40 + 3 * ck] = br.q0.x; crow[41 + 3 * ck] = br.q0.y; crow[42 + 3 * ck] = br.q2.y;
+                crow[70 + 3 * ck] = br.q3.x; crow[71 + 3 * ck] = br.q3.y; crow[72 + 3 * ck] = br.q3.z;
+                if (br.touched && (br.depth_bits - segs::DEPTH_KEY_MIN) >= ((1u << segs::DEPTH_KEY_BITS) - 1u)) *pj.overflow = 1u;
+              }
+              *reinterpret_cast<float4*>(crow + 4 * ck) = head;
+            }
+            asm volatile("" ::: "memory");
+          }
         }
-        asm volatile("" ::: "memory");
-        flush2(colors, 30, 0, R15());
-        asm volatile("" ::: "memory");
+      } else if (tile == 1) {
+        if (PROJECT) {
+          // the colours arrive: every lane assembles the records of its own candidates (radius > 0) from the row slots the passes
+          // above left, 32 records at a time through the staging buffer, four lanes storing a record (as preprocess_fwd_kernel)
+          const float* const row = stg + pc * STG_ROW;
+#pragma unroll
+          for (int cc = 0; cc < 5; cc++) {
+            const int k = 5 * ph + cc;
+            const float4 head = *reinterpret_cast<const float4*>(row + 4 * k);
+            const bool has_record = valid && __float_as_int(head.x) > 0;
+            const float x = row[40 + 3 * k], y = row[41 + 3 * k], depth = row[42 + 3 * k];
+            const float cA = row[70 + 3 * k], cB = row[71 + 3 * k], cC = row[72 + 3 * k];
+            const float4 sq = segs::scaled_conic(cA, cB, cC);
+            const uint64_t recs = __ballot(has_record);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+              if (ph == half) {
+                float4* mine = reinterpret_cast<float4*>(spare + pc * segs::REC_DWORDS);
+                mine[0] = make_float4(x, y, sq.x, sq.y);
+                mine[1] = make_float4(sq.z, head.w, sigmoidf(o[3 * cc]), sigmoidf(o[3 * cc + 1]));
+                mine[2] = make_float4(sigmoidf(o[3 * cc + 2]), depth, head.y, head.z);
+                mine[3] = make_float4(cA, cB, cC, 0.f);
+              }
+              asm volatile("" ::: "memory");
+#pragma unroll
+              for (int j = 0; j < 2; j++) {
+                const uint32_t r = 16u * j + (fl >> 2);        // anchor slot whose record (candidate 5 * half + cc) this lane carries a quarter of
+                if ((recs >> (32 * half + r)) & 1ull) {
+                  const size_t gidx = (size_t)stg_a[r] * NO + 5 * half + cc;
+                  reinterpret_cast<float4*>(pj.rec + gidx * segs::REC_DWORDS)[fl & 3u] = reinterpret_cast<const float4*>(spare + r * segs::REC_DWORDS)[fl & 3u];
+                }
+              }
+              asm volatile("" ::: "memory");
+            }
+          }
+          {   // ten radii / tile counts / depth keys per anchor, as five 8-byte pairs each
+            uint2 v[3][3];
+            uint32_t at[3];
+#pragma unroll
+            for (uint32_t i = 0; i < 3; i++) {
+              const uint32_t e = fl + 64u * i, s = min(e / 5u, 31u), k2 = e - (e / 5u) * 5u;
+              const float* const r0 = stg + s * STG_ROW;
+              uint32_t w[3][2];
+#pragma unroll
+              for (int c = 0; c < 2; c++) {
+                const uint32_t k = 2u * k2 + c;
+                const float4 head = *reinterpret_cast<const float4*>(r0 + 4 * k);
+                const uint32_t rmin = __float_as_uint(head.y), rmax = __float_as_uint(head.z);
+                const uint32_t touched = ((rmax >> 16) - (rmin >> 16)) * ((rmax & 0xFFFFu) - (rmin & 0xFFFFu));
+                w[0][c] = __float_as_uint(head.x);
+                w[1][c] = touched;
+                w[2][c] = touched ? __float_as_uint(r0[42 + 3 * k]) : 0xFFFFFFFFu;
+              }
+#pragma unroll
+              for (int q = 0; q < 3; q++) v[q][i] = make_uint2(w[q][0], w[q][1]);
+              at[i] = stg_a[s] * 5u + k2;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 3; i++)
+              if (fl + 64u * i < nv * 5u) {
+                reinterpret_cast<uint2*>(pj.radii)[at[i]] = v[0][i];
+                reinterpret_cast<uint2*>(pj.touched)[at[i]] = v[1][i];
+                reinterpret_cast<uint2*>(pj.keys)[at[i]] = v[2][i];
+              }
+            asm volatile("" ::: "memory");
+          }
+        } else {
+          if (valid) {
+#pragma unroll
+            for (int r = 0; r < 15; r++) stg[col * 30 + 15 * h + r] = sigmoidf(o[r]);
+          }
+          asm volatile("" ::: "memory");
+          flush2(colors, 30, 0, R15());
+          asm volatile("" ::: "memory");
+        }
       } else {
         if (valid) {
 #pragma unroll
@@ -566,19 +739,31 @@ __global__ void __launch_bounds__(FWD_WAVES * 64, 1) neural_fwd_kernel(
             uint32_t at[5];
 #pragma unroll
             for (uint32_t i = 0; i < 5; i++) {
-              const uint32_t e = lane + 64u * i, s = e / 10u, k = e - s * 10u;
+              const uint32_t e = fl + 64u * i, s = e / 10u, k = e - s * 10u;
               v[i] = *reinterpret_cast<const float4*>(stg + s * STG_ROW + 4 * k);
               at[i] = stg_a[s] * 10u + k;
             }
 #pragma unroll
             for (uint32_t i = 0; i < 5; i++)
-              if (lane + 64u * i < nv * 10u) reinterpret_cast<float4*>(rotations)[at[i]] = v[i];
+              if (fl + 64u * i < nv * 10u) reinterpret_cast<float4*>(rotations)[at[i]] = v[i];
           }
           flush2(scales, STG_ROW, 40, R15());
           flush2(means3D, STG_ROW, 70, R15());
           asm volatile("" ::: "memory");
         }
       }
+    };
+    if (PROJECT) {
+      // covariance first (the projection needs the geometry in the rows when the opacities arrive), then the request for the next
+      // slab, then opacity + projection, then colour + records
+#pragma unroll 1
+      for (int tile = 2; tile < N_TILES; tile++) do_tile(tile);
+      if (more) request(a_cur);
+      do_tile(0);
+      do_tile(1);
+    } else {
+#pragma unroll 1
+      for (int tile = 0; tile < N_TILES; tile++) do_tile(tile);
     }
     kept_total += valid ? kept : 0u;
   }
@@ -1643,10 +1828,10 @@ size_t segs_neural_temp_bytes(const segs_neural_dims* dims, int A) {
   return temp_carve(A, L.total, L.bank, nullptr, nullptr);
 }
 
-int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor, const float* offset, const float* anchor_feat,
-                        const float* scaling_log, const int* visible_radii, const float* mlp_params, const float* camera_center,
-                        const float* pose7, float* means3D, float* colors, float* opacity, float* scales, float* rotations,
-                        float* neural_opacity, char* temp, void* stream) {
+static int neural_forward_impl(const segs_neural_dims* dims, int A, const float* anchor, const float* offset, const float* anchor_feat,
+                               const float* scaling_log, const int* visible_radii, const float* mlp_params, const float* camera_center,
+                               const float* pose7, float* means3D, float* colors, float* opacity, float* scales, float* rotations,
+                               float* neural_opacity, char* temp, void* stream, const segs_projection_targets* tg, const Proj* pj) {
   hipStream_t st = (hipStream_t)stream;
   Layout L;
   int rc = make_layout(dims, &L, nullptr, nullptr, nullptr);
@@ -1654,7 +1839,7 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
   if (A < 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   if (A > MAX_ANCHORS) return segs::set_error(SEGS_ERR_UNSUPPORTED, "more than 8 M anchors (the kernels index with 32-bit element offsets)");
   if (A == 0) return SEGS_OK;
-  if (!anchor || !offset || !anchor_feat || !scaling_log || !mlp_params || !camera_center || !means3D || !colors || !opacity ||
+  if (!anchor || !offset || !anchor_feat || !scaling_log || !mlp_params || !camera_center || !means3D || (!pj && (!colors || !opacity)) ||
       !scales || !rotations || !neural_opacity || !temp || (L.app > 0 && !pose7))
     return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   Temp T;
@@ -1663,14 +1848,54 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
   // T.count: [0] visible anchors, [1] kept candidates; cleared (with the regulariser sum) by pack_tables_kernel
   pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small, T.count, T.gsum + L.total + 8);
   const int nb = (A + 256 * CV_ROUNDS - 1) / (256 * CV_ROUNDS);
-  compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity);
+  if (pj)
+    compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, nullptr, neural_opacity, tg->radii, tg->tiles_touched,
+                                               tg->depth_keys, reinterpret_cast<uint2*>(tg->tile_ranges), tg->num_tiles);
+  else
+    compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity, nullptr, nullptr, nullptr, nullptr, 0);
   // (a per-device attribute: set on every call -- it is cheap -- so that a process driving several GPUs gets it on each)
-  const hipError_t fwd_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(neural_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS);
+  const hipError_t fwd_attr = pj ? hipFuncSetAttribute(reinterpret_cast<const void*>(neural_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS_PROJ)
+                                 : hipFuncSetAttribute(reinterpret_cast<const void*>(neural_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS);
   if (fwd_attr != hipSuccess) return segs::set_hip_error(fwd_attr, __func__);
-  neural_fwd_kernel<<<NEURAL_GRID, FWD_WAVES * 64, FWD_LDS, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
-                                        camera_center, means3D, colors, opacity, scales, rotations, neural_opacity, T.count + 1);
+  if (pj)
+    neural_fwd_kernel<true><<<NEURAL_GRID, FWD_WAVES * 64, FWD_LDS_PROJ, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
+                                          camera_center, means3D, nullptr, nullptr, scales, rotations, neural_opacity, T.count + 1, *pj);
+  else
+    neural_fwd_kernel<false><<<NEURAL_GRID, FWD_WAVES * 64, FWD_LDS, st>>>(L, T.count, T.vis, anchor, offset, anchor_feat, scaling_log, T.images, (const Small*)T.small,
+                                          camera_center, means3D, colors, opacity, scales, rotations, neural_opacity, T.count + 1, Proj{});
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
+}
+
+int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor, const float* offset, const float* anchor_feat,
+                        const float* scaling_log, const int* visible_radii, const float* mlp_params, const float* camera_center,
+                        const float* pose7, float* means3D, float* colors, float* opacity, float* scales, float* rotations,
+                        float* neural_opacity, char* temp, void* stream) {
+  return neural_forward_impl(dims, A, anchor, offset, anchor_feat, scaling_log, visible_radii, mlp_params, camera_center, pose7, means3D,
+                             colors, opacity, scales, rotations, neural_opacity, temp, stream, nullptr, nullptr);
+}
+
+int segs_neural_forward_projected(const segs_neural_dims* dims, int A, const float* anchor, const float* offset, const float* anchor_feat,
+                                  const float* scaling_log, const int* visible_radii, const float* mlp_params, const float* camera_center,
+                                  const float* pose7, float* means3D, float* scales, float* rotations, float* neural_opacity,
+                                  const segs_projection_targets* tg, const float* viewmatrix, const float* projmatrix, int width,
+                                  int height, float tan_fovx, float tan_fovy, float scale_modifier, char* temp, void* stream) {
+  if (!tg || !tg->records || !tg->radii || !tg->tiles_touched || !tg->depth_keys || !tg->tile_ranges || !tg->depth_overflow ||
+      !viewmatrix || !projmatrix || width <= 0 || height <= 0)
+    return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
+  Proj pj;
+  pj.rec = tg->records; pj.radii = tg->radii; pj.touched = tg->tiles_touched; pj.keys = tg->depth_keys; pj.overflow = tg->depth_overflow;
+  pj.view = viewmatrix; pj.proj = projmatrix;
+  pj.W = width; pj.H = height;
+  pj.tanx = tan_fovx; pj.tany = tan_fovy;
+  pj.fy = height / (2.0f * tan_fovy);   // rasterizer_impl.cu:221-222
+  pj.fx = width / (2.0f * tan_fovx);
+  pj.mod = scale_modifier;
+  pj.gx = (uint32_t)((width + segs::TILE_X - 1) / segs::TILE_X); pj.gy = (uint32_t)((height + segs::TILE_Y - 1) / segs::TILE_Y);
+  pj.flags = tg->flags;
+  if ((int)(pj.gx * pj.gy) != tg->num_tiles) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "projection targets were made for another image size");
+  return neural_forward_impl(dims, A, anchor, offset, anchor_feat, scaling_log, visible_radii, mlp_params, camera_center, pose7, means3D,
+                             nullptr, nullptr, scales, rotations, neural_opacity, temp, stream, tg, &pj);
 }
 
 int segs_neural_backward(const segs_neural_dims* dims, int A, const float* anchor, const float* offset, const float* anchor_feat,

@@ -257,6 +257,22 @@ class NeuralGaussians:
         self._last = (camera_center, pose7)
         return self.means3D, self.colors, self.opacity, self.scales, self.rotations
 
+    def forward_projected(self, kf: "Keyframe", visible_radii: Optional[torch.Tensor], engine, scale_modifier: float = 1.0):
+        """segs_neural_forward_projected: the forward that also runs the rasterizer's per-Gaussian stage on the candidates it
+        generates and leaves the records / radii / depth keys in `engine`'s resident buffers.  self.colors and
+        self.opacity are NOT written (they exist only inside the records)."""
+        m = self.model
+        self._ensure()
+        tg = engine.projection_targets()
+        st = self._lib.segs_neural_forward_projected(
+            C.byref(m._cdims), m.A, _p(m.param("anchor")), _p(m.param("offset")), _p(m.param("anchor_feat")),
+            _p(m.param("scaling")), _p(visible_radii), _p(m.mlp_params), _p(kf.campos), _p(kf.pose7), _p(self.means3D),
+            _p(self.scales), _p(self.rotations), _p(self.neural_opacity), C.byref(tg), _p(kf.view), _p(kf.proj), engine.W, engine.H,
+            float(kf.tanfovx), float(kf.tanfovy), float(scale_modifier), _p(self.temp), self._stream())
+        _capi.check(st, "segs_neural_forward_projected")
+        self._last = (kf.campos, kf.pose7)
+        return self.means3D, self.scales, self.rotations
+
     def mask(self):
         """The reference's `mask` (neural_opacity > 0, src/gaussian_renderer.cpp:279) in the candidate domain."""
         return self.neural_opacity.view(-1)[:self.P] > 0
@@ -367,6 +383,10 @@ class ScaffoldTrainerStep:
         # Whole-iteration hipGraph (enable_graph): the iterations between two adjust_anchor calls issue a fixed launch sequence
         # over fixed addresses once the per-iteration values (keyframe matrices, target image, learning rates, the frequency
         # regulariser's target tables) sit in staging buffers refreshed before each replay.
+        # let the neural forward run the rasterizer's per-Gaussian stage on the candidates while it has them in
+        # registers (segs_neural_forward_projected) once the resident buffers are calibrated.  Same image, radii, gradients bit
+        # for bit; neural.colors / neural.opacity are then not materialised (set False before render() to have them).
+        self.fuse_projection = True
         self.use_graph = False
         self._graphs = {}
         self._graph_stage = {}
@@ -503,8 +523,15 @@ class ScaffoldTrainerStep:
                                        resident=True, skip_nonpositive_opacity=True)
             self._levels = {(self.W, self.H): (self.engine, self.loss_fn)}   # the other levels' engines are re-made on use
             self.visible_radii = torch.zeros(self.model.capacity, dtype=torch.int32, device=self.model.device)
-        ng.forward(kf.campos, kf.pose7, self.prefilter_voxel(kf))
         self.engine.set_active(ng.P)
+        if self.fuse_projection:
+            self.engine.check(raise_on_overflow=False)   # an overflow of the previous step sends this one through the calibrating path
+        if self.fuse_projection and self.engine.can_take_projected():
+            # the neural forward projects the candidates itself; the rasterizer starts at the binning
+            ng.forward_projected(kf, self.prefilter_voxel(kf), self.engine)
+            return self.engine.forward_projected(self.bg, ng.means3D, ng.scales, ng.rotations, kf.view, kf.proj, kf.campos,
+                                                 kf.tanfovx, kf.tanfovy)
+        ng.forward(kf.campos, kf.pose7, self.prefilter_voxel(kf))
         return self.engine.forward(self.bg, ng.means3D, ng.colors, ng.opacity, ng.scales, ng.rotations, kf.view, kf.proj,
                                    kf.campos, kf.tanfovx, kf.tanfovy)
 
@@ -681,7 +708,7 @@ class ScaffoldTrainerStep:
         groups = m.adam_groups(lrs)
         split = self._anchor_count is not None
         key = (self.W, self.H, m.A, m.capacity, id(eng), eng.capacity, eng._bin_r.data_ptr(), float(kf.tanfovx), float(kf.tanfovy),
-               bool(in_stat_window), fl is not None, split, len(groups), m.params.data_ptr())
+               bool(in_stat_window), fl is not None, split, len(groups), m.params.data_ptr(), bool(self.fuse_projection))
         # ---- refresh the staging buffers (ordinary stream work in front of the replay)
         st["packed"].copy_(kf.packed())
         st["gt"].copy_(gt)
@@ -759,11 +786,20 @@ class ScaffoldTrainerStep:
             ev[0].record()
             radii = self.prefilter_voxel(kf)
             ev[1].record()
-            ng.forward(kf.campos, kf.pose7, radii)
-            ev[2].record()
             self.engine.set_active(ng.P)
-            image = self.engine.forward(self.bg, ng.means3D, ng.colors, ng.opacity, ng.scales, ng.rotations, kf.view, kf.proj,
-                                        kf.campos, kf.tanfovx, kf.tanfovy)
+            if self.fuse_projection:
+                self.engine.check(raise_on_overflow=False)
+            if self.fuse_projection and self.engine.can_take_projected():
+                # (the per-Gaussian projection then counts as neural_forward: it runs inside that kernel)
+                ng.forward_projected(kf, radii, self.engine)
+                ev[2].record()
+                image = self.engine.forward_projected(self.bg, ng.means3D, ng.scales, ng.rotations, kf.view, kf.proj, kf.campos,
+                                                      kf.tanfovx, kf.tanfovy)
+            else:
+                ng.forward(kf.campos, kf.pose7, radii)
+                ev[2].record()
+                image = self.engine.forward(self.bg, ng.means3D, ng.colors, ng.opacity, ng.scales, ng.rotations, kf.view, kf.proj,
+                                            kf.campos, kf.tanfovx, kf.tanfovy)
             ev[3].record()
             loss, dL = self.loss_fn(image, gt)
             ev[4].record()

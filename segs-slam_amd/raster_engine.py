@@ -188,6 +188,48 @@ class RasterEngine:
             self._setup_resident(self.R)  # calibrated: later forwards take the no-sync path
         return self.out_color
 
+    def can_take_projected(self) -> bool:
+        """The resident buffers are calibrated: a producer may run K1 itself (projection_targets / forward_projected)."""
+        return bool(self.resident and self.capacity > 0)
+
+    def projection_targets(self) -> "_capi.ProjectionTargets":
+        """Where a producer that projects its own Gaussians leaves K1's outputs for the next forward_projected call
+        (segs_resident_projection_targets); made under this engine's flags."""
+        assert self.can_take_projected()
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        tg = _capi.ProjectionTargets()
+        old_flags = self._lib.segs_raster_set_flags(self.flags)
+        try:
+            st = self._lib.segs_resident_projection_targets(p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P,
+                                                            self.P_active, self.W, self.H, p(self.radii), p(self._status), C.byref(tg))
+        finally:
+            self._lib.segs_raster_set_flags(old_flags)
+        _capi.check(st, "segs_resident_projection_targets")
+        return tg
+
+    def forward_projected(self, bg, means3D, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+                          scale_modifier: float = 1.0) -> torch.Tensor:
+        """The resident forward WITHOUT its per-Gaussian stage: the producer has written records, radii, tile counts and depth
+        keys into projection_targets().  means3D / scales / rotations are what the backward will re-read."""
+        assert self.can_take_projected()   # (the caller resolved the previous step's status before it asked for the targets)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        old_flags = self._lib.segs_raster_set_flags(self.flags)
+        try:
+            self._lib.segs_raster_set_status_mirror(C.c_void_p(self._status_host.data_ptr()))
+            st = self._lib.segs_rasterize_forward_resident_projected(p(self._geom_r), p(self._bin_r), p(self._img_r), self.capacity, self.P,
+                                                                     self.P_active, p(bg), self.W, self.H, p(self.out_color),
+                                                                     p(self._status), self._stream())
+            _capi.check(st, "segs_rasterize_forward_resident_projected")
+        finally:
+            self._lib.segs_raster_set_flags(old_flags)
+            self._lib.segs_raster_set_status_mirror(None)
+        if not torch.cuda.is_current_stream_capturing():
+            self._status_event.record(torch.cuda.current_stream(self.device))
+            self._status_pending = True
+        self._last = (bg, means3D, None, None, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy, scale_modifier)
+        self._last_resident = True
+        return self.out_color
+
     def backward(self, dL_dout_color: torch.Tensor):
         """Gradients land in self.grads (views of self.grads_flat), dL_dmean2D, dL_dcov3D."""
         (bg, means3D, colors, opacity, scales, rotations, viewmatrix, projmatrix, campos, tanfovx, tanfovy,

@@ -45,8 +45,11 @@ def test_config3_growth_run_to_two_million_gaussians():
             assert float(r.densifier.stat("anchor_demon")[hi - 1]) == 0.0
         # resident render == synchronising render of the same neural Gaussians
         kf = r.keyframes[it % len(r.keyframes)]
+        st.fuse_projection = False   # the comparison below reads the candidate arrays the unfused forward writes
         for _ in range(2):      # (the first forward after a re-size calibrates through the synchronising path)
             img = st.render(kf).clone()
+        st.fuse_projection = True
+        assert torch.equal(st.render(kf), img), it
         assert st.engine.check() and st.engine._last_resident
         ng = st.neural
         ref = RasterEngine(ng.P_capacity, r.cam.width, r.cam.height, DEV, resident=False, skip_nonpositive_opacity=True)

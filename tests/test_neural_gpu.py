@@ -341,7 +341,10 @@ def test_scaffold_step_alternates_pyramid_levels_on_one_step_object():
             assert loss == loss_alone
         # the image this iteration rendered (from the parameters BEFORE its update): re-render now-current parameters instead and
         # compare with the reference-shaped path at the same size
-        img = step.render(kf).clone()
+        img = step.render(kf).clone()              # (the projecting forward once the level's engine is calibrated)
+        step.fuse_projection = False               # the reference-shaped render below reads the candidate colours / opacities
+        assert torch.equal(step.render(kf), img)
+        step.fuse_projection = True
         ngs = step.neural
         ref = RasterEngine(ngs.P_capacity, sz[0], sz[1], dev, resident=False, skip_nonpositive_opacity=True)
         ref.set_active(ngs.P)
@@ -353,3 +356,89 @@ def test_scaffold_step_alternates_pyramid_levels_on_one_step_object():
     for sz in sizes:
         assert losses[sz][-1] < losses[sz][0], (sz, losses[sz])
     assert len(step._levels) == 2
+
+
+def _projecting_pair(case, A, seed, W, H, keep_dead, z_shift=0.0):
+    """Two step objects over identical models: `a` renders with segs_neural_forward + the resident rasterizer (K1 included),
+    `b` with segs_neural_forward_projected + the rasterizer without K1."""
+    from segs_slam_amd import neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    steps = []
+    for fuse in (False, True):
+        rd, model, _ = _setup(CASES[case], A, seed, dev)
+        if z_shift:
+            model.param("anchor")[:, 2] += z_shift
+        cam = scenes.make_camera(W, H, 0.9 * W, 0.9 * W, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+        step = ng.ScaffoldTrainerStep(model, cam.width, cam.height)
+        step.fuse_projection = fuse
+        if keep_dead:
+            step.engine.flags |= 2       # SEGS_RASTER_KEEP_DEAD_INSTANCES: the reference's rectangles, nothing dropped
+        steps.append(step)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.1, 0.2, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    return steps[0], steps[1], kf, cam
+
+
+@pytest.mark.parametrize("case,A,size,keep_dead", [(1, 4000, (320, 240), False), (0, 4001, (333, 187), False), (2, 37, (64, 72), False),
+                                                  (3, 9000, (640, 480), True), (1, 70_000, (1200, 680), False)])
+def test_projecting_forward_equals_forward_plus_k1(case, A, size, keep_dead):
+    """SURVEY 8f n3 (src/gaussian_renderer.cpp:299-333 -> cuda_rasterizer/forward.cu:155-256): the neural forward that runs the
+    rasterizer's per-Gaussian stage itself leaves, bit for bit, what the two separate kernels leave -- candidate geometry, radii,
+    instance counts, image -- and the same gradients (up to the summation order of the tile backward's atomics)."""
+    a, b, kf, cam = _projecting_pair(case, A, 40 + case, size[0], size[1], keep_dead)
+    dL = torch.randn(3, cam.height, cam.width, device="cuda:0") / (3 * cam.height * cam.width)
+    for it in range(3):                 # the first render calibrates (unfused on both sides), the others are resident
+        ia, ib = a.render(kf), b.render(kf)
+        torch.cuda.synchronize()
+        assert a.engine.check() and b.engine.check()
+        assert b.engine._last_resident == (it > 0)
+        P = a.neural.P
+        assert torch.equal(ia, ib), it
+        assert torch.equal(a.engine.radii[:P], b.engine.radii[:P]), it
+        assert (a.engine.R, a.engine.R_live) == (b.engine.R, b.engine.R_live), it
+        for name in ("means3D", "scales", "rotations", "neural_opacity"):
+            xa, xb = getattr(a.neural, name)[:P], getattr(b.neural, name)[:P]
+            rows = (a.visible_radii[:a.model.A] > 0).repeat_interleave(10)       # rows of invisible anchors are not written
+            assert torch.equal(xa[rows], xb[rows]), (it, name)
+        ga = {k: v.clone() for k, v in a.engine.backward(dL).items()}
+        gb = b.engine.backward(dL)
+        for k in ga:
+            scale = max(float(ga[k].abs().max()), 1e-20)
+            assert float((ga[k][:P] - gb[k][:P]).abs().max()) <= 1e-5 * scale, (it, k)
+        a.neural.backward(ga["means3D"], ga["colors"], ga["opacity"], ga["scales"], ga["rotations"], 0.0)
+        b.neural.backward(gb["means3D"], gb["colors"], gb["opacity"], gb["scales"], gb["rotations"], 0.0)
+        torch.cuda.synchronize()
+        scale = float(a.model.grads.abs().max())
+        assert scale > 0 and float((a.model.grads - b.model.grads).abs().max()) <= 1e-4 * scale
+        a.model.grads.zero_(); b.model.grads.zero_()
+    assert int((a.visible_radii[:a.model.A] > 0).sum()) > 0 and int((b.engine.radii[:P] > 0).sum()) > 0
+    if A > 1000:
+        assert int((a.visible_radii[:a.model.A] == 0).sum()) > 0        # some anchors are outside the frustum: their rows get radius 0
+        inv = (b.visible_radii[:b.model.A] == 0).repeat_interleave(10)
+        assert not bool(b.engine.radii[:P][inv].any())
+
+
+def test_projecting_forward_flags_a_depth_beyond_the_sort_key_range():
+    """A binned Gaussian deeper than the resident sort's 27-bit key range (13 107 m) must flag the step exactly as K1 does: the
+    engine then drops it and re-calibrates through the exact-range path, and training goes on."""
+    a, b, kf, cam = _projecting_pair(1, 3000, 77, 320, 240, False, z_shift=20_000.0)
+    gt = torch.rand(3, cam.height, cam.width, device="cuda:0")
+    for s in (a, b):
+        s.opt.position_lr_init = s.opt.position_lr_final = 0.0
+    la = [float(a.training_once([kf], [gt])) for _ in range(4)]
+    lb = [float(b.training_once([kf], [gt])) for _ in range(4)]
+    torch.cuda.synchronize()
+    assert int((a.engine.radii > 0).sum()) > 0          # (something is rendered out there)
+    assert a.dropped_steps() == b.dropped_steps() and a.dropped_steps() >= 1
+    np.testing.assert_allclose(lb, la, rtol=1e-5)
+
+
+def test_scaffold_step_with_projecting_forward_trains_like_the_unfused_step():
+    a, b, kf, cam = _projecting_pair(0, 6000, 21, 320, 240, False)
+    gt = torch.full((3, cam.height, cam.width), 0.4, device="cuda:0")
+    la = [float(a.training_once([kf], [gt])) for _ in range(30)]
+    lb = [float(b.training_once([kf], [gt])) for _ in range(30)]
+    np.testing.assert_allclose(lb[:3], la[:3], rtol=1e-5)
+    np.testing.assert_allclose(lb, la, rtol=2e-3)       # (the trajectories drift by the atomics' noise through Adam)
+    assert lb[-1] < 0.85 * lb[0]
