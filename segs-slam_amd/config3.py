@@ -75,7 +75,8 @@ class Config3Run:
         while it < max_iters and m.A < target_anchors:
             loss = st.training_once(self.keyframes, self.targets)
             it += 1
-            if it > p.update_from and it % p.update_interval == 0:
+            # (the step's own iteration count decides when adjust_anchor runs: a caller may have stepped it before this loop)
+            if st.iteration > p.update_from and st.iteration % p.update_interval == 0:
                 if after_adjust is not None:
                     after_adjust(self, it)
                 self.history.append({"iteration": it, "anchors": m.A, "s": time.perf_counter() - t0})
