@@ -76,12 +76,16 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
  * neural_opacity are written as by segs_neural_forward; rows of candidates with neural opacity <= 0 and of invisible anchors
  * get radius 0 (src/gaussian_renderer.cpp:279,320: the reference compacts them away).  viewmatrix / projmatrix (4x4,
  * column-major as the rasterizer takes them) are DEVICE arrays.  Image, radii and every gradient equal those of
- * segs_neural_forward + segs_rasterize_forward_resident bit for bit. */
+ * segs_neural_forward + segs_rasterize_forward_resident bit for bit.
+ * anchor_rotations (A,4; normalised) non-NULL: prefilter_voxel (src/gaussian_renderer.cpp:131-199) is folded in as well --
+ * visible_radii (A) is then an OUTPUT, filled with what segs_visible_filter_log_scales(anchor, scaling_log, 6,
+ * anchor_rotations, ...) gives for this camera, and anchor a is used iff that radius is > 0.  NULL: visible_radii is the
+ * input segs_neural_forward takes (or NULL for "every anchor"). */
 struct segs_projection_targets;
 int segs_neural_forward_projected(const segs_neural_dims* dims, int A, const float* anchor, const float* offset,
-                                  const float* anchor_feat, const float* scaling_log, const int* visible_radii,
-                                  const float* mlp_params, const float* camera_center, const float* pose7, float* means3D,
-                                  float* scales, float* rotations, float* neural_opacity,
+                                  const float* anchor_feat, const float* scaling_log, int* visible_radii,
+                                  const float* anchor_rotations, const float* mlp_params, const float* camera_center,
+                                  const float* pose7, float* means3D, float* scales, float* rotations, float* neural_opacity,
                                   const struct segs_projection_targets* targets, const float* viewmatrix,
                                   const float* projmatrix, int width, int height, float tan_fovx, float tan_fovy,
                                   float scale_modifier, char* temp, void* stream);

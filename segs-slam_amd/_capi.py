@@ -48,7 +48,7 @@ SYMBOLS = {
     "segs_neural_param_layout": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "segs_neural_temp_bytes": (_sz, [_vp, _i]),
     "segs_neural_forward": (_i, [_vp, _i] + [_vp] * 16),
-    "segs_neural_forward_projected": (_i, [_vp, _i] + [_vp] * 15 + [_i, _i, _f, _f, _f, _vp, _vp]),
+    "segs_neural_forward_projected": (_i, [_vp, _i] + [_vp] * 16 + [_i, _i, _f, _f, _f, _vp, _vp]),
     "segs_neural_backward": (_i, [_vp, _i] + [_vp] * 17 + [_f, _vp, _vp, _vp]),
     "segs_geometry_bytes": (_sz, [_i]),
     "segs_image_bytes": (_sz, [_i, _i]),

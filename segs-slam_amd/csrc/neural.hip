@@ -419,25 +419,49 @@ struct Proj {
   uint32_t gx, gy, flags;
 };
 
-// 2048 anchors per workgroup (eight rounds of 256) and ONE returning atomic on the list's count per workgroup: the count is a
+// 2048 anchors per workgroup (two rounds of 1024 threads; eight rounds of 256 until round 4) and ONE returning atomic on the list's count per workgroup: the count is a
 // single word, which takes about 12 ns per returning atomic whatever the parallelism -- with one per 256 anchors this kernel
 // spent 14 of its 17 us at 300 k anchors queueing on it.
-constexpr int CV_ROUNDS = 8;
+constexpr int CV_ROUNDS = 2, CV_THREADS = 1024, CV_WAVES = CV_THREADS / 64;   // (2048 anchors per workgroup; sixteen waves: the folded prefilter is ~450 instructions per anchor)
 // proj_radii != null (projecting forward): the candidates of invisible anchors get what K1 would have left for them -- radius 0,
 // no tiles, the culled depth key -- instead of a zero opacity for K1 to find, and the tile range table is reset here.
-__global__ void __launch_bounds__(256) compact_visible_kernel(int A, const int* __restrict__ radii, uint32_t* __restrict__ count,
-                                                              uint32_t* __restrict__ vis, float* __restrict__ opacity,
-                                                              float* __restrict__ neural_opacity, int* __restrict__ proj_radii,
-                                                              uint32_t* __restrict__ proj_touched, uint32_t* __restrict__ proj_keys,
-                                                              uint2* __restrict__ ranges, int num_tiles) {
-  __shared__ uint32_t wave_n[CV_ROUNDS][4], block_base;
+// pf.rot != null: the anchors' visibility (prefilter_voxel, src/gaussian_renderer.cpp:131-199: the anchors drawn as Gaussians with
+// exp(scaling[:, :3]) and their stored rotation -- filter_preprocessCUDA, cuda_rasterizer/forward.cu:259-334) is worked out right
+// here with the arithmetic of visible_filter_kernel and written to radii_out; `radii` is then not read.
+struct Prefilter {
+  const float* anchor; const float* scaling_log; const float* rot; const float* view; const float* proj;
+  int W, H;
+  float tanx, tany, fx, fy;
+  uint32_t gx, gy;
+};
+__global__ void __launch_bounds__(CV_THREADS) compact_visible_kernel(int A, const int* __restrict__ radii, uint32_t* __restrict__ count,
+                                                                     uint32_t* __restrict__ vis, float* __restrict__ opacity,
+                                                                     float* __restrict__ neural_opacity, int* __restrict__ proj_radii,
+                                                                     uint32_t* __restrict__ proj_touched, uint32_t* __restrict__ proj_keys,
+                                                                     uint2* __restrict__ ranges, int num_tiles, Prefilter pf,
+                                                                     int* __restrict__ radii_out) {
+  __shared__ uint32_t wave_n[CV_ROUNDS][CV_WAVES], block_base;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int a0 = blockIdx.x * (256 * CV_ROUNDS) + threadIdx.x;
+  const int a0 = blockIdx.x * (CV_THREADS * CV_ROUNDS) + threadIdx.x;
   uint32_t mine = 0u, below[CV_ROUNDS];
 #pragma unroll
   for (int r = 0; r < CV_ROUNDS; r++) {
-    const int a = a0 + r * 256;
-    const bool v = a < A && (radii == nullptr || radii[a] > 0);
+    const int a = a0 + r * CV_THREADS;
+    bool v;
+    if (pf.rot) {
+      int rad = 0;
+      if (a < A) {
+        const float* const sl = pf.scaling_log + (size_t)a * 6;
+        const float3 p = make_float3(pf.anchor[(size_t)a * 3], pf.anchor[(size_t)a * 3 + 1], pf.anchor[(size_t)a * 3 + 2]);
+        const float3 sc = make_float3(expf(sl[0]), expf(sl[1]), expf(sl[2]));
+        const float4 q = reinterpret_cast<const float4*>(pf.rot)[a];
+        rad = segs::project_gaussian(p, sc, 1.0f, q, nullptr, pf.view, pf.proj, pf.W, pf.H, pf.tanx, pf.tany, pf.fx, pf.fy, pf.gx, pf.gy).radius;
+        radii_out[a] = rad;
+      }
+      v = rad > 0;
+    } else {
+      v = a < A && (radii == nullptr || radii[a] > 0);
+    }
     const uint64_t m = __ballot(v);
     if (lane == 0) wave_n[r][wv] = (uint32_t)__popcll(m);
     below[r] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -447,16 +471,23 @@ __global__ void __launch_bounds__(256) compact_visible_kernel(int A, const int* 
   if (threadIdx.x == 0) {
     uint32_t tot = 0;
 #pragma unroll
-    for (int r = 0; r < CV_ROUNDS; r++) tot += wave_n[r][0] + wave_n[r][1] + wave_n[r][2] + wave_n[r][3];
-    block_base = tot ? atomicAdd(count, tot) : 0u;
+    for (int r = 0; r < CV_ROUNDS; r++)
+#pragma unroll
+      for (int w = 0; w < CV_WAVES; w++) tot += wave_n[r][w];
+    block_base = tot ? atomicAdd(count, tot) : 0u;   // ONE returning atomic on the list's count per 2048 anchors (about 12 ns each, whatever the parallelism)
   }
   __syncthreads();
   uint32_t base = block_base;
 #pragma unroll
   for (int r = 0; r < CV_ROUNDS; r++) {
-    const int a = a0 + r * 256;
-    uint32_t mybase = base;
-    for (int w = 0; w < wv; w++) mybase += wave_n[r][w];
+    const int a = a0 + r * CV_THREADS;
+    uint32_t mybase = base, round_total = 0u;
+#pragma unroll
+    for (int w = 0; w < CV_WAVES; w++) {
+      const uint32_t c = wave_n[r][w];
+      mybase += w < wv ? c : 0u;
+      round_total += c;
+    }
     const bool v = (mine >> r) & 1u;
     if (v) vis[mybase + below[r]] = (uint32_t)a;
     if (a < A && !v) {
@@ -471,10 +502,10 @@ __global__ void __launch_bounds__(256) compact_visible_kernel(int A, const int* 
         for (int k = 0; k < NO; k++) { opacity[(size_t)a * NO + k] = 0.f; neural_opacity[(size_t)a * NO + k] = 0.f; }
       }
     }
-    base += wave_n[r][0] + wave_n[r][1] + wave_n[r][2] + wave_n[r][3];
+    base += round_total;
   }
   if (ranges)
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < num_tiles; t += gridDim.x * 256) ranges[t] = make_uint2(segs::RANGE_EMPTY_START, 0u);
+    for (int t = blockIdx.x * CV_THREADS + threadIdx.x; t < num_tiles; t += gridDim.x * CV_THREADS) ranges[t] = make_uint2(segs::RANGE_EMPTY_START, 0u);
 }
 
 // PROJECT (src/gaussian_renderer.cpp:299-333 feeding cuda_rasterizer/forward.cu:155-256): the wave also runs K1 on the
@@ -1831,7 +1862,8 @@ size_t segs_neural_temp_bytes(const segs_neural_dims* dims, int A) {
 static int neural_forward_impl(const segs_neural_dims* dims, int A, const float* anchor, const float* offset, const float* anchor_feat,
                                const float* scaling_log, const int* visible_radii, const float* mlp_params, const float* camera_center,
                                const float* pose7, float* means3D, float* colors, float* opacity, float* scales, float* rotations,
-                               float* neural_opacity, char* temp, void* stream, const segs_projection_targets* tg, const Proj* pj) {
+                               float* neural_opacity, char* temp, void* stream, const segs_projection_targets* tg, const Proj* pj,
+                               const float* anchor_rotations = nullptr, int* visible_radii_out = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   Layout L;
   int rc = make_layout(dims, &L, nullptr, nullptr, nullptr);
@@ -1847,12 +1879,18 @@ static int neural_forward_impl(const segs_neural_dims* dims, int A, const float*
   static_assert(N_IMG_BWD == 262 && sizeof(Small) <= 8192, "temp_carve sizes");
   // T.count: [0] visible anchors, [1] kept candidates; cleared (with the regulariser sum) by pack_tables_kernel
   pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small, T.count, T.gsum + L.total + 8);
-  const int nb = (A + 256 * CV_ROUNDS - 1) / (256 * CV_ROUNDS);
+  const int nb = (A + CV_THREADS * CV_ROUNDS - 1) / (CV_THREADS * CV_ROUNDS);
+  Prefilter pf{};
+  if (pj && anchor_rotations) {
+    pf.anchor = anchor; pf.scaling_log = scaling_log; pf.rot = anchor_rotations; pf.view = pj->view; pf.proj = pj->proj;
+    pf.W = pj->W; pf.H = pj->H; pf.tanx = pj->tanx; pf.tany = pj->tany; pf.fx = pj->fx; pf.fy = pj->fy; pf.gx = pj->gx; pf.gy = pj->gy;
+  }
   if (pj)
-    compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, nullptr, neural_opacity, tg->radii, tg->tiles_touched,
-                                               tg->depth_keys, reinterpret_cast<uint2*>(tg->tile_ranges), tg->num_tiles);
+    compact_visible_kernel<<<nb, CV_THREADS, 0, st>>>(A, visible_radii, T.count, T.vis, nullptr, neural_opacity, tg->radii, tg->tiles_touched,
+                                               tg->depth_keys, reinterpret_cast<uint2*>(tg->tile_ranges), tg->num_tiles, pf, visible_radii_out);
   else
-    compact_visible_kernel<<<nb, 256, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity, nullptr, nullptr, nullptr, nullptr, 0);
+    compact_visible_kernel<<<nb, CV_THREADS, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity, nullptr, nullptr, nullptr, nullptr, 0,
+                                               pf, nullptr);
   // (a per-device attribute: set on every call -- it is cheap -- so that a process driving several GPUs gets it on each)
   const hipError_t fwd_attr = pj ? hipFuncSetAttribute(reinterpret_cast<const void*>(neural_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS_PROJ)
                                  : hipFuncSetAttribute(reinterpret_cast<const void*>(neural_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS);
@@ -1876,12 +1914,12 @@ int segs_neural_forward(const segs_neural_dims* dims, int A, const float* anchor
 }
 
 int segs_neural_forward_projected(const segs_neural_dims* dims, int A, const float* anchor, const float* offset, const float* anchor_feat,
-                                  const float* scaling_log, const int* visible_radii, const float* mlp_params, const float* camera_center,
+                                  const float* scaling_log, int* visible_radii, const float* anchor_rotations, const float* mlp_params, const float* camera_center,
                                   const float* pose7, float* means3D, float* scales, float* rotations, float* neural_opacity,
                                   const segs_projection_targets* tg, const float* viewmatrix, const float* projmatrix, int width,
                                   int height, float tan_fovx, float tan_fovy, float scale_modifier, char* temp, void* stream) {
   if (!tg || !tg->records || !tg->radii || !tg->tiles_touched || !tg->depth_keys || !tg->tile_ranges || !tg->depth_overflow ||
-      !viewmatrix || !projmatrix || width <= 0 || height <= 0)
+      !viewmatrix || !projmatrix || width <= 0 || height <= 0 || (anchor_rotations && !visible_radii))
     return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
   Proj pj;
   pj.rec = tg->records; pj.radii = tg->radii; pj.touched = tg->tiles_touched; pj.keys = tg->depth_keys; pj.overflow = tg->depth_overflow;
@@ -1895,7 +1933,7 @@ int segs_neural_forward_projected(const segs_neural_dims* dims, int A, const flo
   pj.flags = tg->flags;
   if ((int)(pj.gx * pj.gy) != tg->num_tiles) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "projection targets were made for another image size");
   return neural_forward_impl(dims, A, anchor, offset, anchor_feat, scaling_log, visible_radii, mlp_params, camera_center, pose7, means3D,
-                             nullptr, nullptr, scales, rotations, neural_opacity, temp, stream, tg, &pj);
+                             nullptr, nullptr, scales, rotations, neural_opacity, temp, stream, tg, &pj, anchor_rotations, visible_radii);
 }
 
 int segs_neural_backward(const segs_neural_dims* dims, int A, const float* anchor, const float* offset, const float* anchor_feat,

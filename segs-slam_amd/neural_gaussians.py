@@ -257,17 +257,19 @@ class NeuralGaussians:
         self._last = (camera_center, pose7)
         return self.means3D, self.colors, self.opacity, self.scales, self.rotations
 
-    def forward_projected(self, kf: "Keyframe", visible_radii: Optional[torch.Tensor], engine, scale_modifier: float = 1.0):
+    def forward_projected(self, kf: "Keyframe", visible_radii: Optional[torch.Tensor], engine, scale_modifier: float = 1.0,
+                          anchor_rotations: Optional[torch.Tensor] = None):
         """segs_neural_forward_projected: the forward that also runs the rasterizer's per-Gaussian stage on the candidates it
         generates and leaves the records / radii / depth keys in `engine`'s resident buffers.  self.colors and
-        self.opacity are NOT written (they exist only inside the records)."""
+        self.opacity are NOT written (they exist only inside the records).  With `anchor_rotations` (normalised) the prefilter is
+        folded in too: visible_radii is then filled by this call instead of being read."""
         m = self.model
         self._ensure()
         tg = engine.projection_targets()
         st = self._lib.segs_neural_forward_projected(
             C.byref(m._cdims), m.A, _p(m.param("anchor")), _p(m.param("offset")), _p(m.param("anchor_feat")),
-            _p(m.param("scaling")), _p(visible_radii), _p(m.mlp_params), _p(kf.campos), _p(kf.pose7), _p(self.means3D),
-            _p(self.scales), _p(self.rotations), _p(self.neural_opacity), C.byref(tg), _p(kf.view), _p(kf.proj), engine.W, engine.H,
+            _p(m.param("scaling")), _p(visible_radii), _p(anchor_rotations), _p(m.mlp_params), _p(kf.campos), _p(kf.pose7),
+            _p(self.means3D), _p(self.scales), _p(self.rotations), _p(self.neural_opacity), C.byref(tg), _p(kf.view), _p(kf.proj), engine.W, engine.H,
             float(kf.tanfovx), float(kf.tanfovy), float(scale_modifier), _p(self.temp), self._stream())
         _capi.check(st, "segs_neural_forward_projected")
         self._last = (kf.campos, kf.pose7)
@@ -485,15 +487,20 @@ class ScaffoldTrainerStep:
             "appearance": expon_lr(it, o.appearance_lr_init, o.appearance_lr_final, o.appearance_lr_max_steps),
         }
 
+    def _anchor_rotations(self) -> torch.Tensor:
+        """normalize(_rotation) of the live anchors.  _rotation is never trained (src/gaussian_model.cpp:372): normalised again
+        only when densification rewrote rows."""
+        m = self.model
+        key = (m.A, m.rotation._version, m.rotation.data_ptr())
+        if getattr(self, "_rot_key", None) != key:
+            self._rot_key, self._rot_normalized = key, torch.nn.functional.normalize(m.rotation[:m.A]).contiguous()
+        return self._rot_normalized
+
     def prefilter_voxel(self, kf: Keyframe) -> torch.Tensor:
         """radii of the anchors drawn as Gaussians with exp(scaling[:, :3]) and normalize(rotation)
         (src/gaussian_renderer.cpp:131-199); the result stays on the device."""
         m = self.model
-        # _rotation is never trained (src/gaussian_model.cpp:372): normalise it again only when densification rewrote rows
-        key = (m.A, m.rotation._version, m.rotation.data_ptr())
-        if getattr(self, "_rot_key", None) != key:
-            self._rot_key, self._rot_normalized = key, torch.nn.functional.normalize(m.rotation[:m.A]).contiguous()
-        rots = self._rot_normalized
+        rots = self._anchor_rotations()
         # get_scaling()[:, :3] = exp(_scaling[:, :3]) is formed inside the kernel (rows of 6 log-scales): no intermediate tensor
         st = self._lib.segs_visible_filter_log_scales(m.A, self.W, self.H, _p(m.param("anchor")), _p(m.param("scaling")), 6, _p(rots),
                                                       _p(kf.view), _p(kf.proj), float(kf.tanfovx), float(kf.tanfovy),
@@ -528,7 +535,8 @@ class ScaffoldTrainerStep:
             self.engine.check(raise_on_overflow=False)   # an overflow of the previous step sends this one through the calibrating path
         if self.fuse_projection and self.engine.can_take_projected():
             # the neural forward projects the candidates itself; the rasterizer starts at the binning
-            ng.forward_projected(kf, self.prefilter_voxel(kf), self.engine)
+            # (and works out prefilter_voxel's radii on the way: self.visible_radii is filled by the same call)
+            ng.forward_projected(kf, self.visible_radii, self.engine, anchor_rotations=self._anchor_rotations())
             return self.engine.forward_projected(self.bg, ng.means3D, ng.scales, ng.rotations, kf.view, kf.proj, kf.campos,
                                                  kf.tanfovx, kf.tanfovy)
         ng.forward(kf.campos, kf.pose7, self.prefilter_voxel(kf))
@@ -783,15 +791,16 @@ class ScaffoldTrainerStep:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
             self.iteration += 1
             lrs = self.learning_rates(self.iteration)
-            ev[0].record()
-            radii = self.prefilter_voxel(kf)
-            ev[1].record()
             self.engine.set_active(ng.P)
             if self.fuse_projection:
                 self.engine.check(raise_on_overflow=False)
-            if self.fuse_projection and self.engine.can_take_projected():
-                # (the per-Gaussian projection then counts as neural_forward: it runs inside that kernel)
-                ng.forward_projected(kf, radii, self.engine)
+            fused = self.fuse_projection and self.engine.can_take_projected()
+            ev[0].record()
+            radii = None if fused else self.prefilter_voxel(kf)
+            ev[1].record()
+            if fused:
+                # (prefilter and per-Gaussian projection then count as neural_forward: they run inside its kernels)
+                ng.forward_projected(kf, self.visible_radii, self.engine, anchor_rotations=self._anchor_rotations())
                 ev[2].record()
                 image = self.engine.forward_projected(self.bg, ng.means3D, ng.scales, ng.rotations, kf.view, kf.proj, kf.campos,
                                                       kf.tanfovx, kf.tanfovy)

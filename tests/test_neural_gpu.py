@@ -396,6 +396,7 @@ def test_projecting_forward_equals_forward_plus_k1(case, A, size, keep_dead):
         P = a.neural.P
         assert torch.equal(ia, ib), it
         assert torch.equal(a.engine.radii[:P], b.engine.radii[:P]), it
+        assert torch.equal(a.visible_radii, b.visible_radii), it        # (b's were filled by the projecting forward itself once resident)
         assert (a.engine.R, a.engine.R_live) == (b.engine.R, b.engine.R_live), it
         for name in ("means3D", "scales", "rotations", "neural_opacity"):
             xa, xb = getattr(a.neural, name)[:P], getattr(b.neural, name)[:P]
