@@ -3,10 +3,14 @@
 // MLP stacks src/gaussian_model.cpp:61-98.
 //
 //   compact_visible_kernel : radii>0 -> visible-anchor list + device-side count (no host sync); clears the opacity of
-//                            the slots of invisible anchors so the rasterizer skips them
+//                            the slots of invisible anchors so the rasterizer skips them.  Projecting forward: works out the
+//                            anchors' visibility itself (prefilter_voxel) and leaves K1's "culled" outputs for those slots
 //   neural_fwd_kernel      : wave = 32 visible anchors; view direction, feature bank, three 35->32->{10,70,30} MLPs
 //                            chained on fp32 MFMA (activations stay in registers, weights as LDS operand images),
-//                            mask, xyz/scale/rot assembly, written straight into the rasterizer's input arrays
+//                            mask, xyz/scale/rot assembly, written straight into the rasterizer's input arrays.
+//                            <true> (segs_neural_forward_projected): also runs the rasterizer's per-Gaussian
+//                            stage K1 (project_gaussian.h) on the live candidates and writes its 64-byte records, radii,
+//                            tile counts and depth keys into the resident rasterizer buffers
 //   neural_bwd_kernel      : same mapping; recomputes the forward (cheaper than saving ~100 floats/anchor),
 //                            back-propagates the candidate-domain gradients to anchor/offset/feature/scaling and leaves
 //                            the per-anchor (activation, pre-activation gradient) rows in scratch
@@ -1969,9 +1973,9 @@ int segs_neural_backward(const segs_neural_dims* dims, int A, const float* ancho
   // the regulariser sum was cleared by the forward (pack_tables_kernel) and is cleared again by reg_finish_kernel; it is
   // only accumulated when somebody reads it
   float* reg_sum = scaling_reg_out ? T.gsum + L.total + 8 : nullptr;
-  // Plain model: chain waves + weight-gradient waves (neural_bwd_pair_kernel).  The feature bank's epilogue keeps the 32 features
-  // and works through the scratch rows: the one-kernel form.  SEGS_NEURAL_BWD_ONE_ROLE=1 runs the plain model through that form
-  // too (SEGS_NEURAL_ONE_KERNEL_BACKWARD, segs_neural.h: the A/B of profiles/ and tests/test_neural_gpu.py).
+  // Chain waves + weight-gradient waves (neural_bwd_pair_kernel; the feature-bank model too since round 4, its epilogue on
+  // compact rows).  SEGS_NEURAL_ONE_KERNEL_BACKWARD (segs_neural_set_flags, segs_neural.h) selects the one-kernel form: the
+  // A/B of profiles/ and tests/test_neural_gpu.py.
   const bool one_role = (g_neural_flags & SEGS_NEURAL_ONE_KERNEL_BACKWARD) != 0u;
   if (!one_role)
     (L.bank ? neural_bwd_pair_kernel<true> : neural_bwd_pair_kernel<false>)<<<BWD_GRID, 512, pair_lds, st>>>(

@@ -12,13 +12,19 @@ from collections import defaultdict
 
 
 def kernel_source_sha(root=None):
-    """sha256 over the kernel sources (segs-slam_amd/csrc/*.hip, *.h) in name order: bench.py compares it with the tree it
-    runs from and marks counter figures taken from another state of the kernels as stale."""
+    """sha256 over the CODE of the kernel sources (segs-slam_amd/csrc/*.hip, *.h; comments and white space stripped) in name
+    order: bench.py compares it with the tree it runs from and marks counter figures taken from another state of the kernels
+    as stale."""
     root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import re
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(root, "segs-slam_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "segs-slam_amd", "csrc", "*.h"))):
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        # code only: comments and white space do not make a counter file stale
+        text = open(f, "r", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
