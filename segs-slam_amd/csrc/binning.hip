@@ -209,7 +209,9 @@ __device__ __forceinline__ void emit_stage_owner(EmitLds& L, int k, uint32_t idx
   L.geo1[k] = make_float2(-e1.x, (op * 255.0f > 1.0f) ? __builtin_amdgcn_logf(255.0f * op) * 1.0001f + 1e-3f : -1.0f);
 }
 // owner k's first slot is `start`; its mark goes to the slot's position inside the sub-batch [s0, s0 + 512) (owner 0 may
-// start before s0: position 0; an owner that starts behind the sub-batch -- the next sub-batch's first -- leaves no mark)
+// start before s0: position 0; an owner that starts behind the sub-batch -- the next sub-batch's first -- leaves no mark).
+// Two owners write the same mark only when one of them owns no instance, which happens only in a launch flagged through
+// status[2] (a binned depth beyond the key range): which of them wins is then not deterministic, and that launch's output is dropped.
 __device__ __forceinline__ void emit_mark_owner(uint32_t* mark, int k, uint32_t start, uint32_t s0, uint32_t tag) {
   const uint32_t pos = start > s0 ? start - s0 : 0u;
   if (pos < (uint32_t)EMIT_SLOTS) mark[pos] = (tag << 10) | (uint32_t)k;

@@ -225,15 +225,19 @@ void GaussianTrainerStep::learning_rates(int64_t it, std::vector<double>& lr) co
 }
 
 // prefilter_voxel (src/gaussian_renderer.cpp:131-199): radii of the anchors drawn as Gaussians with exp(scaling[:, :3])
-void GaussianTrainerStep::prefilter(const KeyframeView& kf) {
+const torch::Tensor& GaussianTrainerStep::anchor_rotations() {
   // _rotation is never trained: normalise it again only when densification rewrote rows
   if (rot_rows_ != model_.A || !rot_normalized_.defined()) {
     rot_normalized_ = torch::nn::functional::normalize(model_.rotation.slice(0, 0, model_.A)).contiguous();
     rot_rows_ = model_.A;
   }
+  return rot_normalized_;
+}
+
+void GaussianTrainerStep::prefilter(const KeyframeView& kf) {
   // (exp(_scaling[:, :3]) is formed inside the kernel from the rows of 6 log-scales: no intermediate tensor)
   check(segs_visible_filter_log_scales((int)model_.A, W_, H_, fp(model_.param("anchor")), model_.seg_ptr(model_.params, "scaling"), 6,
-                                       fp(rot_normalized_), fp(kf.view), fp(kf.proj), kf.tanfovx, kf.tanfovy,
+                                       fp(anchor_rotations()), fp(kf.view), fp(kf.proj), kf.tanfovx, kf.tanfovy,
                                        visible_radii_.data_ptr<int>(), cur_stream(dev_)),
         "segs_visible_filter_log_scales");
 }
@@ -251,9 +255,38 @@ void GaussianTrainerStep::resolve_status() {
 
 void GaussianTrainerStep::render(const KeyframeView& kf) {
   if (model_.capacity > cand_capacity_) allocate_candidate_buffers();   // the map outgrew the buffers
-  prefilter(kf);
   void* st = cur_stream(dev_);
   const int64_t A = model_.A, P = A * model_.dims.n_offsets, rows = cand_capacity_ * model_.dims.n_offsets;
+  if (fuse_projection_) {
+    resolve_status();
+    if (capacity_ > 0) {
+      // prefilter, neural Gaussians and the per-Gaussian projection in the neural kernels; the rasterizer bins and renders
+      const uint32_t old = segs_raster_set_flags(FLAG_SKIP_NONPOSITIVE_OPACITY);
+      segs_projection_targets tg;
+      int rc = segs_resident_projection_targets((char*)geom_r_.data_ptr(), (char*)binning_r_.data_ptr(), (char*)img_r_.data_ptr(), capacity_,
+                                                (int)rows, (int)P, W_, H_, radii_.data_ptr<int>(), (uint32_t*)status_.data_ptr<int32_t>(), &tg);
+      if (rc == 0)
+        rc = segs_neural_forward_projected(&model_.cdims, (int)A, fp(model_.param("anchor")), fp(model_.param("offset")),
+                                           fp(model_.param("anchor_feat")), fp(model_.param("scaling")), visible_radii_.data_ptr<int>(),
+                                           fp(anchor_rotations()), fp(model_.mlp_params()), fp(kf.campos), fp(kf.pose7), fp(means3D_),
+                                           fp(scales_), fp(rotations_), fp(neural_opacity_), &tg, fp(kf.view), fp(kf.proj), W_, H_,
+                                           kf.tanfovx, kf.tanfovy, 1.0f, (char*)neural_temp_.data_ptr(), st);
+      if (rc == 0) {
+        segs_raster_set_status_mirror((uint32_t*)status_host_.data_ptr<int32_t>());
+        rc = segs_rasterize_forward_resident_projected((char*)geom_r_.data_ptr(), (char*)binning_r_.data_ptr(), (char*)img_r_.data_ptr(),
+                                                       capacity_, (int)rows, (int)P, fp(bg_), W_, H_, fp(out_color_),
+                                                       (uint32_t*)status_.data_ptr<int32_t>(), st);
+        segs_raster_set_status_mirror(nullptr);
+      }
+      segs_raster_set_flags(old);
+      check(rc, "segs_neural_forward_projected / segs_rasterize_forward_resident_projected");
+      hip_check(hipEventRecord((hipEvent_t)status_event_, (hipStream_t)st), "hipEventRecord");
+      status_pending_ = true;
+      last_resident_ = true;
+      return;
+    }
+  }
+  prefilter(kf);
   check(segs_neural_forward(&model_.cdims, (int)A, fp(model_.param("anchor")), fp(model_.param("offset")), fp(model_.param("anchor_feat")),
                             fp(model_.param("scaling")), visible_radii_.data_ptr<int>(), fp(model_.mlp_params()), fp(kf.campos), fp(kf.pose7),
                             fp(means3D_), fp(colors_), fp(opacity_), fp(scales_), fp(rotations_), fp(neural_opacity_),

@@ -133,6 +133,11 @@ class GaussianTrainerStep {
   // whose compositing decisions sit on a threshold, on both sides); and a callback that sees the gradient bucket exactly as
   // the optimizer receives it (after the exchange, before Adam clears it)
   void set_image_gradient_mask(const torch::Tensor& mask_hw) { dL_mask_ = mask_hw; }
+  // SURVEY 8f n3 (default on): once the rasterizer's resident scratch is calibrated, the neural forward runs the per-Gaussian
+  // projection (K1) and prefilter_voxel itself (segs_neural_forward_projected) and the rasterizer starts at the binning
+  // (segs_rasterize_forward_resident_projected).  Same image, radii and gradients bit for bit; colours and opacities of the
+  // candidates are then not materialised as arrays.
+  void set_fuse_projection(bool on) { fuse_projection_ = on; }
   std::function<void(const torch::Tensor&)> on_gradients;
 
   torch::Tensor image() { return out_color_; }
@@ -154,6 +159,7 @@ class GaussianTrainerStep {
   };
   void learning_rates(int64_t it, std::vector<double>& lr_of_group) const;
   void prefilter(const KeyframeView& kf);
+  const torch::Tensor& anchor_rotations();
   void render(const KeyframeView& kf);
   void resolve_status();
   void forward_backward(const KeyframeView& kf, const torch::Tensor& gt_image);
@@ -185,7 +191,7 @@ class GaussianTrainerStep {
   // rasterizer state
   torch::Tensor out_color_, radii_, bg_, geom_, binning_, img_, geom_r_, binning_r_, img_r_, status_, status_host_;
   int num_rendered_ = 0, capacity_ = 0;
-  bool last_resident_ = false, status_pending_ = false;
+  bool last_resident_ = false, status_pending_ = false, fuse_projection_ = true;
   void* status_event_ = nullptr;
   // loss
   torch::Tensor loss_temp_, loss_out_, dL_dimage_, scaling_reg_, dL_mask_, freq_value_;

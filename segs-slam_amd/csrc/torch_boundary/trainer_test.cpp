@@ -18,6 +18,7 @@
 //     a rehearsal transport for a one-GPU box, where RCCL refuses two ranks on one device); --nccl1: a ONE-rank
 //     c10d::ProcessGroupNCCL with every collective forced (reduce_scatter / all_gather through RCCL from C++).
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <string>
@@ -102,6 +103,7 @@ static int run_single(const char* in, const char* out) {
   dims.appearance_dim = hdr[3];
   dims.use_feat_bank = hdr[4] != 0;
   segs_host::GaussianTrainerStep step(A, dims, W, H, torch::Device(torch::kCUDA, 0), segs_host::ScaffoldOptimization(), tf[2]);
+  if (std::getenv("SEGS_TRAINER_TEST_UNFUSED")) step.set_fuse_projection(false);   // A/B of tests/test_cpp_trainer.py: K1 and the prefilter as kernels of their own
   step.param("anchor").copy_(rd(f, {A, 3}));
   step.param("offset").copy_(rd(f, {A, dims.n_offsets, 3}));
   step.param("anchor_feat").copy_(rd(f, {A, dims.feat_dim}));

@@ -58,6 +58,12 @@ def test_cpp_trainer_matches_python_step(tmp_path, cfg):
     assert os.path.exists(exe), "build the drop-in layer first (make -C segs-slam_amd/csrc/torch_boundary)"
     subprocess.check_call([exe, str(fin), str(fout)])
     raw = np.fromfile(fout, np.float32)
+    # the same run with the per-Gaussian projection and the prefilter as kernels of their own (SURVEY 8f n3 off): the forward
+    # is bit-identical either way, so the first losses agree to rounding of the loss reduction and the rest to the atomics' noise
+    subprocess.check_call([exe, str(fin), str(tmp_path / "out_unfused.bin")], env=dict(os.environ, SEGS_TRAINER_TEST_UNFUSED="1"))
+    raw_u = np.fromfile(tmp_path / "out_unfused.bin", np.float32)
+    assert raw[0] == raw_u[0]                                 # (iteration 1 calibrates on both sides; from iteration 2 on the forward is fused)
+    np.testing.assert_allclose(raw[:n_steps], raw_u[:n_steps], rtol=1e-4)
     losses_cpp, regs_cpp = raw[:n_steps], raw[n_steps:2 * n_steps]
     steps_taken, resident = int(raw[2 * n_steps]), int(raw[2 * n_steps + 1])
     n = model.params.numel()
