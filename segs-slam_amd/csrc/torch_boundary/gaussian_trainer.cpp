@@ -244,13 +244,15 @@ void GaussianTrainerStep::prefilter(const KeyframeView& kf) {
 
 // the asynchronous status read-back of the previous resident forward: an overflow sends the next pass through the
 // synchronising, re-sizing path (the pass that overflowed was dropped on the device by the guarded optimizer)
-void GaussianTrainerStep::resolve_status() {
-  if (!status_pending_) return;
+// Returns true when the pass it resolves had overflowed (that pass was dropped on the device).
+bool GaussianTrainerStep::resolve_status() {
+  if (!status_pending_) return false;
   hip_check(hipEventSynchronize((hipEvent_t)status_event_), "hipEventSynchronize");
   status_pending_ = false;
   const int32_t* h = status_host_.data_ptr<int32_t>();
   num_rendered_ = h[0];
-  if (h[3] != 0) capacity_ = 0;
+  if (h[3] != 0) { capacity_ = 0; return true; }
+  return false;
 }
 
 void GaussianTrainerStep::render(const KeyframeView& kf) {
@@ -405,9 +407,27 @@ void GaussianTrainerStep::adam(const std::vector<segs_adam_segment>& groups_in, 
 // whose instance count outgrew the rasterizer's resident capacity on ANY rank is dropped on the device by every rank --
 // statistics and optimizer are guarded by the all-reduced overflow word, the Adam step counts live on the device and do not
 // advance -- and the rank that overflowed re-sizes its scratch at its next forward.
+//
+// With one rank a dropped iteration is not lost (set_redo_dropped_steps, on by default): the host learns of it when it resolves
+// that forward's status word -- before anything of the next iteration is queued -- and runs the same keyframe with the same
+// iteration number again right there (its forward re-calibrates, so it cannot overflow).  Parameters, moments and step counts
+// are what the dropped pass found, so the optimizer takes every step the reference takes, in the same order.  The keyframe's
+// and the target's tensors must therefore stay unchanged until the next call.
 torch::Tensor GaussianTrainerStep::trainingOnce(const KeyframeView& kf, const torch::Tensor& gt_image) {
   TORCH_CHECK(gt_image.is_contiguous() && gt_image.sizes() == out_color_.sizes() && gt_image.device() == dev_, "gt_image must be a contiguous (3,H,W) tensor on the step's device");
+  if (redo_dropped_steps_ && have_last_ && world() == 1 && resolve_status()) {
+    have_last_ = false;
+    redone_steps_ += 1;
+    iteration_body(last_kf_, last_gt_);   // iteration_ still holds that iteration's number
+  }
   iteration_ += 1;
+  last_kf_ = kf;
+  last_gt_ = gt_image;
+  have_last_ = true;
+  return iteration_body(kf, gt_image);
+}
+
+torch::Tensor GaussianTrainerStep::iteration_body(const KeyframeView& kf, const torch::Tensor& gt_image) {
   std::vector<double> lr;
   learning_rates(iteration_, lr);
   AnchorDensifier* d = densifier_;

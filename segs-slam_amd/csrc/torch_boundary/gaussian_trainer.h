@@ -14,6 +14,7 @@
 // keyframe-parallel exchange (keyframe_exchange.h); tests/test_cpp_trainer.py runs both twins on the same model and compares
 // losses, parameters and the map after an adjust_anchor iteration, and two C++ ranks against each other.
 #pragma once
+#include <algorithm>
 #include <torch/torch.h>
 
 #include <torch/csrc/distributed/c10d/Backend.hpp>
@@ -138,6 +139,11 @@ class GaussianTrainerStep {
   // (segs_rasterize_forward_resident_projected).  Same image, radii and gradients bit for bit; colours and opacities of the
   // candidates are then not materialised as arrays.
   void set_fuse_projection(bool on) { fuse_projection_ = on; }
+  // One rank: run an iteration the device dropped (resident capacity overflow) again before the next one (trainingOnce).
+  void set_redo_dropped_steps(bool on) { redo_dropped_steps_ = on; }
+  int64_t redone_steps() const { return redone_steps_; }
+  // test support: make the next resident forward overflow (capacity = last instance count / divisor; the buffers stay as large as they are)
+  void debug_shrink_capacity(int divisor) { resolve_status(); if (capacity_ > 0) capacity_ = std::max(num_rendered_ / divisor, 1024); }
   std::function<void(const torch::Tensor&)> on_gradients;
 
   torch::Tensor image() { return out_color_; }
@@ -161,7 +167,8 @@ class GaussianTrainerStep {
   void prefilter(const KeyframeView& kf);
   const torch::Tensor& anchor_rotations();
   void render(const KeyframeView& kf);
-  void resolve_status();
+  bool resolve_status();
+  torch::Tensor iteration_body(const KeyframeView& kf, const torch::Tensor& gt_image);
   void forward_backward(const KeyframeView& kf, const torch::Tensor& gt_image);
   void adam(const std::vector<segs_adam_segment>& groups, StepCount& count, const uint32_t* guard);
   void allocate_candidate_buffers();
@@ -192,6 +199,10 @@ class GaussianTrainerStep {
   torch::Tensor out_color_, radii_, bg_, geom_, binning_, img_, geom_r_, binning_r_, img_r_, status_, status_host_;
   int num_rendered_ = 0, capacity_ = 0;
   bool last_resident_ = false, status_pending_ = false, fuse_projection_ = true;
+  bool redo_dropped_steps_ = true, have_last_ = false;
+  int64_t redone_steps_ = 0;
+  KeyframeView last_kf_;
+  torch::Tensor last_gt_;
   void* status_event_ = nullptr;
   // loss
   torch::Tensor loss_temp_, loss_out_, dL_dimage_, scaling_reg_, dL_mask_, freq_value_;

@@ -115,7 +115,12 @@ static int run_single(const char* in, const char* out) {
   auto gt = rd(f, {3, H, W});
   std::vector<float> losses, regs;
   int resident = 0;
+  // test hooks (tests/test_cpp_trainer.py): SEGS_TRAINER_TEST_OVERFLOW_AT=k shrinks the resident capacity in front of
+  // iteration k so that its forward overflows and the device drops it; SEGS_TRAINER_TEST_NO_REDO keeps it dropped
+  const int overflow_at = std::getenv("SEGS_TRAINER_TEST_OVERFLOW_AT") ? std::atoi(std::getenv("SEGS_TRAINER_TEST_OVERFLOW_AT")) : -1;
+  if (std::getenv("SEGS_TRAINER_TEST_NO_REDO")) step.set_redo_dropped_steps(false);
   for (int it = 0; it < n_steps; it++) {
+    if (it == overflow_at) step.debug_shrink_capacity(3);
     auto loss = step.trainingOnce(kf, gt);
     losses.push_back(loss.item<float>());
     regs.push_back(step.scaling_reg().item<float>());
@@ -129,7 +134,7 @@ static int run_single(const char* in, const char* out) {
   o.write(reinterpret_cast<const char*>(extra), 8);
   wr(o, step.params_flat());
   wr(o, step.image());
-  std::printf("trainer_test ok A=%d %dx%d steps=%d (resident passes %d)\n", A, W, H, n_steps, resident);
+  std::printf("trainer_test ok A=%d %dx%d steps=%d (resident passes %d) redone %d\n", A, W, H, n_steps, resident, (int)step.redone_steps());
   return 0;
 }
 

@@ -235,20 +235,34 @@ class TrainerStep:
     def training_once(self, keyframes, gt_images) -> torch.Tensor:
         """Nothing here waits for the device: a pass whose instance count outgrew some rank's resident capacity is dropped by
         every rank on the device (the optimizer is guarded by the all-reduced overflow word and its step count lives there);
-        the rank concerned re-sizes its scratch at its next forward."""
+        the rank concerned re-sizes its scratch at its next forward.  With one rank the dropped iteration is then run again
+        before the next one (`redo_dropped_steps`), so no optimizer step of the reference's sequence is lost."""
+        # One rank: an iteration the device dropped is run again -- same keyframe, same iteration number -- as soon as the host
+        # resolves that forward's status word, which is before the next iteration is queued (ScaffoldTrainerStep.training_once).
+        eng = getattr(self, "engine", None)
+        prev = getattr(self, "_last_iteration", None)
+        if (prev is not None and getattr(self, "redo_dropped_steps", True) and self.world == 1 and not getattr(self, "use_graph", False)
+                and eng is not None and eng.resident and not eng.check(raise_on_overflow=False)):
+            self._last_iteration = None
+            self.redone_steps = getattr(self, "redone_steps", 0) + 1
+            self._iteration_body(*prev)
         self.iteration += 1
-        lrs = self.learning_rates(self.iteration)
         k = self.keyframe_for(self.iteration - 1, len(keyframes))
+        self._last_iteration = (keyframes[k], gt_images[k], self.iteration)
+        return self._iteration_body(keyframes[k], gt_images[k], self.iteration)
+
+    def _iteration_body(self, keyframe, gt, it: int) -> torch.Tensor:
+        lrs = self.learning_rates(it)
         ex = self.exchange
         if getattr(self, "use_graph", False) and not ex.active:
-            loss = self._training_once_graph(keyframes[k], gt_images[k], lrs)
+            loss = self._training_once_graph(keyframe, gt, lrs)
             if loss is not None:
                 return loss
-        dL_fn = lambda im: self.loss_and_grad(im, gt_images[k])  # noqa: E731
+        dL_fn = lambda im: self.loss_and_grad(im, gt)  # noqa: E731
         if self._backend_takes_hook:
-            loss = self.render_backward(self.params, keyframes[k], dL_fn, after_forward=ex.reduce_flag_async)
+            loss = self.render_backward(self.params, keyframe, dL_fn, after_forward=ex.reduce_flag_async)
         else:
-            loss = self.render_backward(self.params, keyframes[k], dL_fn)
+            loss = self.render_backward(self.params, keyframe, dL_fn)
             ex.reduce_flag_async(None)
         flag = ex.wait_flag()
         ex.reduce_gradients(self.grads_flat)  # sum over the keyframes of this step

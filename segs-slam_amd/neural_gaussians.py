@@ -389,6 +389,11 @@ class ScaffoldTrainerStep:
         # registers (segs_neural_forward_projected) once the resident buffers are calibrated.  Same image, radii, gradients bit
         # for bit; neural.colors / neural.opacity are then not materialised (set False before render() to have them).
         self.fuse_projection = True
+        # the device drops an iteration whose forward overflowed the resident capacity; with one rank the host runs it again
+        # before the next one (training_once), so no optimizer step of the reference's sequence is lost
+        self.redo_dropped_steps = True
+        self.redone_steps = 0
+        self._last_iteration = None
         self.use_graph = False
         self._graphs = {}
         self._graph_stage = {}
@@ -601,23 +606,40 @@ class ScaffoldTrainerStep:
         sizes tensors on the host): a pass whose instance count outgrew the rasterizer's resident capacity on ANY rank is
         dropped on the device by every rank -- statistics and optimizer are guarded by the all-reduced overflow word, the Adam
         step counts live on the device and do not advance -- and the rank that overflowed re-sizes its scratch at its next
-        forward.  The loss returned for such an iteration comes from an invalid image."""
+        forward.  The loss returned for such an iteration comes from an invalid image.
+
+        With one rank (`redo_dropped_steps`, on by default) a dropped iteration is not lost: the host learns of it when it
+        resolves that forward's status word, which is before anything of the next iteration is queued, and runs the same
+        keyframe with the same iteration number again right there -- its forward re-calibrates, so it cannot overflow -- before
+        the next one.  Parameters, moments and step counts are what the dropped pass found, so the optimizer takes every step
+        the reference takes (src/gaussian_mapper.cpp:823-1032 never skips one), in the same order."""
+        prev = self._last_iteration
+        if (prev is not None and self.redo_dropped_steps and self.world == 1 and not self.use_graph and self.engine.resident
+                and not self.engine.check(raise_on_overflow=False)):
+            self._last_iteration = None
+            self.redone_steps += 1
+            self._iteration_body(*prev)
         self.iteration += 1
-        lrs = self.learning_rates(self.iteration)
         if self.keyframe_selector is not None:
             # useOneRandomSlidingWindowKeyframe (src/gaussian_mapper.cpp:827): one draw per rank, identical on every rank
             k = self.keyframe_selector.use_for_ranks(self.world)[self.rank]
         else:
             k = self.keyframe_for(self.iteration - 1, len(keyframes))
+        self._last_iteration = (keyframes[k], gt_images[k], self.iteration)
+        return self._iteration_body(keyframes[k], gt_images[k], self.iteration)
+
+    def _iteration_body(self, kf: Keyframe, gt: torch.Tensor, it: int) -> torch.Tensor:
+        """Iteration `it` on keyframe `kf` (training_once; also the re-run of an iteration the device dropped)."""
+        lrs = self.learning_rates(it)
         ex = self._exchange()
         d = self.densifier
-        in_stat_window = d is not None and self.model.A > 0 and d.p.start_stat < self.iteration < d.p.update_until  # gaussian_mapper.cpp:961-968
-        adjust_now = in_stat_window and self.iteration > d.p.update_from and self.iteration % d.p.update_interval == 0
+        in_stat_window = d is not None and self.model.A > 0 and d.p.start_stat < it < d.p.update_until  # gaussian_mapper.cpp:961-968
+        adjust_now = in_stat_window and it > d.p.update_from and it % d.p.update_interval == 0
         if self.use_graph and not adjust_now and not ex.active:
-            loss = self._training_once_graph(keyframes[k], gt_images[k], lrs, in_stat_window)
+            loss = self._training_once_graph(kf, gt, lrs, in_stat_window)
             if loss is not None:
                 return loss
-        loss = self._forward_backward(keyframes[k], gt_images[k], ex, flag_on_host=adjust_now)
+        loss = self._forward_backward(kf, gt, ex, flag_on_host=adjust_now)
         flag = ex.wait_flag()
         if adjust_now:
             # adjust_anchor reads tensor sizes on the host and must see a valid pass on every rank: resolve the summed
@@ -627,7 +649,7 @@ class ScaffoldTrainerStep:
                     break
                 self.engine.check(raise_on_overflow=False)     # the rank that overflowed re-calibrates in its next forward
                 self.model.grads.zero_()
-                loss = self._forward_backward(keyframes[k], gt_images[k], ex, flag_on_host=True)
+                loss = self._forward_backward(kf, gt, ex, flag_on_host=True)
                 flag = ex.wait_flag()
             else:
                 raise RuntimeError("resident rasterizer kept overflowing its re-sized scratch")

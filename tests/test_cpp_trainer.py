@@ -64,6 +64,17 @@ def test_cpp_trainer_matches_python_step(tmp_path, cfg):
     raw_u = np.fromfile(tmp_path / "out_unfused.bin", np.float32)
     assert raw[0] == raw_u[0]                                 # (iteration 1 calibrates on both sides; from iteration 2 on the forward is fused)
     np.testing.assert_allclose(raw[:n_steps], raw_u[:n_steps], rtol=1e-4)
+    # an iteration dropped on the device (forced: the resident capacity is shrunk in front of iteration 3) is run again by the host
+    # before the next one; with the redo switched off the optimizer has taken one step fewer
+    for env, want_steps, want_redone in ((dict(SEGS_TRAINER_TEST_OVERFLOW_AT="3"), n_steps, 1),
+                                         (dict(SEGS_TRAINER_TEST_OVERFLOW_AT="3", SEGS_TRAINER_TEST_NO_REDO="1"), n_steps - 1, 0)):
+        out = subprocess.run([exe, str(fin), str(tmp_path / "out_drop.bin")], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        raw_d = np.fromfile(tmp_path / "out_drop.bin", np.float32)
+        assert int(raw_d[2 * n_steps]) == want_steps and f"redone {want_redone}" in out.stdout, (env, out.stdout)
+        if want_redone:
+            keep = [i for i in range(n_steps) if i != 3]
+            np.testing.assert_allclose(raw_d[:n_steps][keep], raw[:n_steps][keep], rtol=2e-4)
     losses_cpp, regs_cpp = raw[:n_steps], raw[n_steps:2 * n_steps]
     steps_taken, resident = int(raw[2 * n_steps]), int(raw[2 * n_steps + 1])
     n = model.params.numel()

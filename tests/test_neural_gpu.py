@@ -443,3 +443,57 @@ def test_scaffold_step_with_projecting_forward_trains_like_the_unfused_step():
     np.testing.assert_allclose(lb[:3], la[:3], rtol=1e-5)
     np.testing.assert_allclose(lb, la, rtol=2e-3)       # (the trajectories drift by the atomics' noise through Adam)
     assert lb[-1] < 0.85 * lb[0]
+
+
+def _three_keyframe_step(seed):
+    from segs_slam_amd import mapper_config as mc, neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    cfg = mc.load_committed_config("cfg/gaussian_mapper/RGB-D/Replica/office0.yaml")
+    cfg.densify.update_until = 0
+    cam = scenes.make_camera(320, 240, 300.0, 300.0, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+    step = mc.make_mapper_step(cfg, ng.synthetic_model(4000, cfg.model, cam, dev, seed=seed), cam.width, cam.height)
+    step.keyframe_for = lambda it, n: it % n
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kfs, gts = [], []
+    g = torch.Generator().manual_seed(3)
+    for k in range(3):
+        ang = 0.05 * k
+        R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], dtype=np.float32)
+        c = scenes.make_camera(320, 240, 300.0, 300.0, R, np.array([0.03 * k, 0.0, 0.0], dtype=np.float32))
+        kfs.append(ng.Keyframe(t(c.world_view_transform), t(c.full_proj_transform), t(c.camera_center),
+                               torch.tensor([0.03 * k, 0.0, 0.0, 1.0, 0.0, ang, 0.0], device=dev), c.tanfovx, c.tanfovy))
+        gts.append(torch.rand(3, 240, 320, generator=g).to(dev))
+    return step, kfs, gts
+
+
+@pytest.mark.parametrize("redo", [True, False])
+def test_iteration_dropped_on_the_device_is_run_again_before_the_next_one(redo):
+    """A forward whose instance count outgrows the resident capacity is dropped on the device (no statistics, no optimizer
+    step).  The reference never skips an iteration (src/gaussian_mapper.cpp:823-1032): with one rank the host runs the dropped
+    iteration again -- same keyframe, same iteration number -- as soon as it resolves that forward's status word, i.e. before the
+    next iteration is queued, so the optimizer takes the reference's steps in the reference's order."""
+    a, kfs, gts = _three_keyframe_step(5)
+    b, _, _ = _three_keyframe_step(5)
+    b.redo_dropped_steps = redo
+    la, lb = [], []
+    for it in range(8):
+        if it == 4:
+            assert b.engine.check() and b.engine.capacity > 0
+            b.engine.capacity = max(b.engine.R // 3, 1024)       # the next forward overflows (its buffers stay as large as they are)
+        la.append(float(a.training_once(kfs, gts)))
+        lb.append(float(b.training_once(kfs, gts)))
+    la.append(float(a.training_once(kfs, gts)))
+    lb.append(float(b.training_once(kfs, gts)))                  # (the call that notices a drop of the last iteration, if any)
+    torch.cuda.synchronize()
+    assert a.dropped_steps() == 0 and a.redone_steps == 0 and a._mlp_count.value() == 9
+    assert b.dropped_steps() == 1
+    if redo:
+        assert b.redone_steps == 1 and b._mlp_count.value() == 9
+        keep = [i for i in range(9) if i != 4]                   # (the dropped pass returned the loss of an invalid image)
+        np.testing.assert_allclose(np.array(lb)[keep], np.array(la)[keep], rtol=2e-4)
+        pa, pb = a.model.params.cpu().numpy(), b.model.params.cpu().numpy()
+        moved = np.abs(pa - pb) > 0
+        assert np.isfinite(pb).all() and float(np.abs(pa - pb).max()) <= 2 * 9 * 0.02
+        assert float((np.abs(pa - pb) > 1e-4 + 1e-2 * np.abs(pa)).mean()) < 2e-2, float(moved.mean())
+    else:
+        assert b.redone_steps == 0 and b._mlp_count.value() == 8   # one optimizer step fewer than the reference takes

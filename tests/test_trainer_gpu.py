@@ -162,6 +162,30 @@ def test_trainer_step_reduces_loss():
     assert all(np.isfinite(losses))
 
 
+def test_trainer_step_runs_a_dropped_iteration_again():
+    """An iteration whose forward overflowed the resident capacity is dropped on the device; with one rank the host runs it again
+    before the next one (the reference's trainer never skips an iteration, src/gaussian_trainer.cpp:47-117)."""
+    from segs_slam_amd import scenes
+    from segs_slam_amd.gaussian_trainer import TrainerStep, keyframe_tensors
+    counts = {}
+    for redo in (True, False):
+        sc = scenes.make_scene(20_000, 160, 120, 130.0, 130.0, seed=5, bg=(0.0, 0.0, 0.0))
+        sc.scales *= 2.5
+        step = TrainerStep.on_gpu(sc, DEV)
+        step.redo_dropped_steps = redo
+        kf = keyframe_tensors(sc.camera, DEV)
+        gt = torch.rand(3, 120, 160, generator=torch.Generator().manual_seed(1)).to(DEV)
+        for it in range(6):
+            if it == 3:
+                assert step.engine.check() and step.engine.capacity > 0
+                step.engine.capacity = max(step.engine.R // 3, 1024)     # the next forward overflows
+            step.training_once([kf], [gt])
+        torch.cuda.synchronize()
+        counts[redo] = (step.optimizer.count.value(), step.optimizer.count.dropped(), getattr(step, "redone_steps", 0))
+    assert counts[True] == (6, 1, 1), counts
+    assert counts[False] == (5, 1, 0), counts
+
+
 @pytest.mark.parametrize("H,W", [(48, 64), (37, 53), (680, 1200)])
 def test_fused_l1_ssim_matches_loss_utils(H, W):
     """Fused HIP loss (forward value, L1, SSIM and dL/dimage) vs the reference's op chain (loss_utils mirror + autograd)."""
