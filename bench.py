@@ -617,7 +617,7 @@ def mapper_step_block(dev, steps: int = 50, warmup: int = 10):
             "iters_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "steps": steps, "warmup": warmup, "step_ms": pc,
             "phase_ms": {k: round(v, 4) for k, v in phases.items()},
             "render_only_ms": _percentiles([rev[i].elapsed_time(rev[i + 1]) for i in range(20)]),
-            "dropped_steps": tstep.dropped_steps(), "candidates": live}
+            "dropped_steps": tstep.dropped_steps(), "redone_steps": tstep.redone_steps, "candidates": live}
 
 
 def replica_step_block(dev, anchors: int = 50_000, steps: int = 50, warmup: int = 10, iteration: int = 10_000,
@@ -667,7 +667,7 @@ def replica_step_block(dev, anchors: int = 50_000, steps: int = 50, warmup: int 
         out[label] = {"iters_per_s": steps / wall, "ms_per_step": wall / steps * 1e3,
                       "step_ms": _percentiles([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]),
                       "phase_ms": {k: round(v, 4) for k, v in phases.items()}, "frequency_terms_on": {"low": low_on, "high": high_on},
-                      "dropped_steps": tstep.dropped_steps(), "instances_binned": tstep.engine.R}
+                      "dropped_steps": tstep.dropped_steps(), "redone_steps": tstep.redone_steps, "instances_binned": tstep.engine.R}
     return out
 
 

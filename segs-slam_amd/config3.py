@@ -86,5 +86,5 @@ class Config3Run:
         torch.cuda.synchronize(self.device)
         wall = time.perf_counter() - t0
         return {"iterations": it, "seconds": wall, "iters_per_s": it / wall if wall > 0 else 0.0, "anchors_start": self.anchors_start,
-                "anchors_end": m.A, "gaussians_end": m.A * m.dims.n_offsets, "dropped_steps": st.dropped_steps(),
+                "anchors_end": m.A, "gaussians_end": m.A * m.dims.n_offsets, "dropped_steps": st.dropped_steps(), "redone_steps": st.redone_steps,
                 "final_loss": float(loss) if it else None, "anchors_over_time": [(h["iteration"], h["anchors"]) for h in self.history]}

@@ -497,3 +497,39 @@ def test_iteration_dropped_on_the_device_is_run_again_before_the_next_one(redo):
         assert float((np.abs(pa - pb) > 1e-4 + 1e-2 * np.abs(pa)).mean()) < 2e-2, float(moved.mean())
     else:
         assert b.redone_steps == 0 and b._mlp_count.value() == 8   # one optimizer step fewer than the reference takes
+
+
+def test_projecting_forward_rejects_inconsistent_arguments():
+    """segs_neural_forward_projected fails loudly (status + message, nothing launched) on targets made for another image size,
+    on a prefilter request without a radii array to fill, and on missing camera matrices."""
+    import ctypes as C
+    from segs_slam_amd import _capi, neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    a, b, kf, cam = _projecting_pair(1, 2000, 3, 320, 240, False)
+    for _ in range(2):
+        b.render(kf)
+    torch.cuda.synchronize()
+    assert b.engine.check() and b.engine.can_take_projected()
+    lib, m, n = b._lib, b.model, b.neural
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+
+    def call(tg, width, height, radii, rots, view):
+        return lib.segs_neural_forward_projected(
+            C.byref(m._cdims), m.A, p(m.param("anchor")), p(m.param("offset")), p(m.param("anchor_feat")), p(m.param("scaling")),
+            p(radii), p(rots), p(m.mlp_params), p(kf.campos), p(kf.pose7), p(n.means3D), p(n.scales), p(n.rotations),
+            p(n.neural_opacity), C.byref(tg) if tg is not None else None, p(view), p(kf.proj), width, height, float(kf.tanfovx),
+            float(kf.tanfovy), 1.0, p(n.temp), None)
+
+    tg = b.engine.projection_targets()
+    rots = b._anchor_rotations()
+    assert call(tg, 320, 240, b.visible_radii, rots, kf.view) == 0
+    for bad in (call(tg, 640, 480, b.visible_radii, rots, kf.view),      # targets of a 320x240 engine
+                call(tg, 320, 240, None, rots, kf.view),                 # prefilter folded in, nowhere to put the radii
+                call(tg, 320, 240, b.visible_radii, rots, None),         # no view matrix
+                call(None, 320, 240, b.visible_radii, rots, kf.view)):   # no targets
+        assert bad != 0
+        with pytest.raises(_capi.SegsError):
+            _capi.check(bad, "segs_neural_forward_projected")
+    torch.cuda.synchronize()
+    assert torch.equal(a.render(kf), b.render(kf))             # (and the step still renders, bit for bit, afterwards)
+    assert bool(torch.isfinite(b.engine.out_color).all())
