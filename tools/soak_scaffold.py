@@ -34,6 +34,9 @@ step = ng.ScaffoldTrainerStep(model, cam.width, cam.height, scaling_reg_weight=0
 dens = densify.AnchorDensifier(model, densify.DensifyParams(voxel_size=0.01, start_stat=100, update_from=300, update_interval=100,
                                                             update_until=iters, densify_grad_threshold=thr))
 step.enable_densification(dens, seed=0)
+if os.environ.get("SOAK_FREQUENCY_REGULARIZER"):      # the Replica mapper loss: multi_scale_loss on from the first iteration, row mask on
+    step.enable_frequency_regularization(start=0)
+    step.row_mask = True
 step.keyframe_selector = SlidingWindowKeyframes(seed=0)      # the mapper's keyframe walk (src/gaussian_mapper.cpp:1459-1495)
 for _ in kfs:
     step.keyframe_selector.add_keyframe(8)                    # Mapper.new_keyframe_times_of_use
@@ -51,4 +54,4 @@ for it in range(1, iters + 1):
         if stop_at and model.A >= stop_at:
             break
 assert torch.isfinite(model.params).all()
-print("soak ok")
+print(f"soak ok (dropped {step.dropped_steps()} redone {step.redone_steps})")
