@@ -73,6 +73,29 @@ def test_camera_tensors_match_reference_logger_dump():
         assert np.allclose(center, np.array(kf["camera_center"]), atol=2e-3)
 
 
+def test_camera_tensors_match_the_second_reference_dump():
+    """Known-answer data: 30 of the 179 cameras of the reference's `check_colmap copy.md` (FoV, image size, world_view_transform,
+    full_proj_transform, camera_center printed with four decimals by the original pipeline's camera loader; extracted by
+    tests/golden/extract_check_colmap_cameras.py).  From FoV and the printed world_view_transform alone, scenes.projection_matrix
+    (znear 0.01, zfar 100: include/gaussian_keyframe.h) must give the printed full projection and camera centre -- to the print
+    precision propagated through the 4x4 product (inputs +-5e-5, entries up to 4: 1e-3)."""
+    import json
+    import numpy as np
+    from segs_slam_amd import scenes
+    data = json.load(open(os.path.join(ROOT, "tests", "golden", "check_colmap_cameras.json")))
+    assert len(data) == 30 and len({(k["image_width"], k["image_height"]) for k in data}) >= 1
+    for kf in data:
+        wvt = np.array(kf["world_view_transform"], dtype=np.float64)
+        assert np.allclose(wvt[:3, 3], 0.0) and wvt[3, 3] == 1.0          # the transposed layout: translation in the last ROW
+        proj = scenes.projection_matrix(0.01, 100.0, kf["FoVx"], kf["FoVy"]).T.astype(np.float64)
+        assert np.allclose(wvt @ proj, np.array(kf["full_proj_transform"]), atol=1e-3), kf["uid"]
+        assert np.allclose(np.linalg.inv(wvt)[3, :3], np.array(kf["camera_center"]), atol=1e-3), kf["uid"]
+        # and the tangents the rasterizer takes are those of the printed fields of view
+        cam = scenes.make_camera(kf["image_width"], kf["image_height"], kf["image_width"] / (2 * np.tan(kf["FoVx"] / 2)),
+                                 kf["image_height"] / (2 * np.tan(kf["FoVy"] / 2)), np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+        assert abs(cam.tanfovx - np.tan(kf["FoVx"] / 2)) < 1e-6 and abs(cam.tanfovy - np.tan(kf["FoVy"] / 2)) < 1e-6
+
+
 def test_neural_param_layout_matches_state_dict_order():
     """segs_neural_param_layout (host-only) lists the MLP tensors in the order and sizes of the reference's Sequential
     stacks (src/gaussian_model.cpp:61-98), as restated in oracle/neural_ref.py."""
