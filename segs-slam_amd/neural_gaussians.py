@@ -608,7 +608,8 @@ class ScaffoldTrainerStep:
         step counts live on the device and do not advance -- and the rank that overflowed re-sizes its scratch at its next
         forward.  The loss returned for such an iteration comes from an invalid image.
 
-        With one rank (`redo_dropped_steps`, on by default) a dropped iteration is not lost: the host learns of it when it
+        With one rank and eager launches (`redo_dropped_steps`, on by default; not under `enable_graph`, whose replay loop polls
+        the status word instead of waiting for it) a dropped iteration is not lost: the host learns of it when it
         resolves that forward's status word, which is before anything of the next iteration is queued, and runs the same
         keyframe with the same iteration number again right there -- its forward re-calibrates, so it cannot overflow -- before
         the next one.  Parameters, moments and step counts are what the dropped pass found, so the optimizer takes every step
