@@ -426,7 +426,8 @@ struct Proj {
 // 2048 anchors per workgroup (two rounds of 1024 threads; eight rounds of 256 until round 4) and ONE returning atomic on the list's count per workgroup: the count is a
 // single word, which takes about 12 ns per returning atomic whatever the parallelism -- with one per 256 anchors this kernel
 // spent 14 of its 17 us at 300 k anchors queueing on it.
-constexpr int CV_ROUNDS = 2, CV_THREADS = 1024, CV_WAVES = CV_THREADS / 64;   // (2048 anchors per workgroup; sixteen waves: the folded prefilter is ~450 instructions per anchor)
+// Shape by size: <1024 threads, 2 rounds> = 2048 anchors per workgroup for large maps (the atomic), <256, 1> below 131 072
+// anchors, where 2048 per workgroup would leave most CUs without one (50 k anchors: 25 workgroups; 12.7 us against ~7).
 // proj_radii != null (projecting forward): the candidates of invisible anchors get what K1 would have left for them -- radius 0,
 // no tiles, the culled depth key -- instead of a zero opacity for K1 to find, and the tile range table is reset here.
 // pf.rot != null: the anchors' visibility (prefilter_voxel, src/gaussian_renderer.cpp:131-199: the anchors drawn as Gaussians with
@@ -438,12 +439,14 @@ struct Prefilter {
   float tanx, tany, fx, fy;
   uint32_t gx, gy;
 };
+template <int CV_THREADS, int CV_ROUNDS>
 __global__ void __launch_bounds__(CV_THREADS) compact_visible_kernel(int A, const int* __restrict__ radii, uint32_t* __restrict__ count,
                                                                      uint32_t* __restrict__ vis, float* __restrict__ opacity,
                                                                      float* __restrict__ neural_opacity, int* __restrict__ proj_radii,
                                                                      uint32_t* __restrict__ proj_touched, uint32_t* __restrict__ proj_keys,
                                                                      uint2* __restrict__ ranges, int num_tiles, Prefilter pf,
                                                                      int* __restrict__ radii_out) {
+  constexpr int CV_WAVES = CV_THREADS / 64;
   __shared__ uint32_t wave_n[CV_ROUNDS][CV_WAVES], block_base;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int a0 = blockIdx.x * (CV_THREADS * CV_ROUNDS) + threadIdx.x;
@@ -1883,18 +1886,23 @@ static int neural_forward_impl(const segs_neural_dims* dims, int A, const float*
   static_assert(N_IMG_BWD == 262 && sizeof(Small) <= 8192, "temp_carve sizes");
   // T.count: [0] visible anchors, [1] kept candidates; cleared (with the regulariser sum) by pack_tables_kernel
   pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small, T.count, T.gsum + L.total + 8);
-  const int nb = (A + CV_THREADS * CV_ROUNDS - 1) / (CV_THREADS * CV_ROUNDS);
+  const bool small_map = A < 131072;
+  const int per_wg = small_map ? 256 : 2048;
+  const int nb = (A + per_wg - 1) / per_wg;
   Prefilter pf{};
   if (pj && anchor_rotations) {
     pf.anchor = anchor; pf.scaling_log = scaling_log; pf.rot = anchor_rotations; pf.view = pj->view; pf.proj = pj->proj;
     pf.W = pj->W; pf.H = pj->H; pf.tanx = pj->tanx; pf.tany = pj->tany; pf.fx = pj->fx; pf.fy = pj->fy; pf.gx = pj->gx; pf.gy = pj->gy;
   }
-  if (pj)
-    compact_visible_kernel<<<nb, CV_THREADS, 0, st>>>(A, visible_radii, T.count, T.vis, nullptr, neural_opacity, tg->radii, tg->tiles_touched,
-                                               tg->depth_keys, reinterpret_cast<uint2*>(tg->tile_ranges), tg->num_tiles, pf, visible_radii_out);
-  else
-    compact_visible_kernel<<<nb, CV_THREADS, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity, nullptr, nullptr, nullptr, nullptr, 0,
-                                               pf, nullptr);
+  auto launch_compact = [&](auto kernel, int threads) {
+    if (pj)
+      kernel<<<nb, threads, 0, st>>>(A, visible_radii, T.count, T.vis, nullptr, neural_opacity, tg->radii, tg->tiles_touched, tg->depth_keys,
+                                     reinterpret_cast<uint2*>(tg->tile_ranges), tg->num_tiles, pf, visible_radii_out);
+    else
+      kernel<<<nb, threads, 0, st>>>(A, visible_radii, T.count, T.vis, opacity, neural_opacity, nullptr, nullptr, nullptr, nullptr, 0, pf, nullptr);
+  };
+  if (small_map) launch_compact(compact_visible_kernel<256, 1>, 256);
+  else launch_compact(compact_visible_kernel<1024, 2>, 1024);
   // (a per-device attribute: set on every call -- it is cheap -- so that a process driving several GPUs gets it on each)
   const hipError_t fwd_attr = pj ? hipFuncSetAttribute(reinterpret_cast<const void*>(neural_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS_PROJ)
                                  : hipFuncSetAttribute(reinterpret_cast<const void*>(neural_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS);

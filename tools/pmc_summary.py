@@ -12,13 +12,15 @@ from collections import defaultdict
 
 
 def kernel_source_sha(root=None):
-    """sha256 over the CODE of the kernel sources (segs-slam_amd/csrc/*.hip, *.h; comments and white space stripped) in name
-    order: bench.py compares it with the tree it runs from and marks counter figures taken from another state of the kernels
+    """sha256 over the CODE of the rasterizer's kernel sources (comments and white space stripped): bench.py compares it with the tree it runs from and marks counter figures taken from another state of the kernels
     as stale."""
     root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import re
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(root, "segs-slam_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "segs-slam_amd", "csrc", "*.h"))):
+    # the rasterizer's sources: the counter figures bench.py reads are those of its tile backward (the headline's dominant kernel);
+    # the neural / loss / optimizer / densify kernels are not on that path
+    names = ("preprocess.hip", "binning.hip", "render.hip", "capi.hip", "gs_layout.h", "kernels.h", "project_gaussian.h", "sh_color.h")
+    for f in [os.path.join(root, "segs-slam_amd", "csrc", n) for n in names]:
         h.update(os.path.basename(f).encode())
         # code only: comments and white space do not make a counter file stale
         text = open(f, "r", errors="replace").read()
