@@ -174,7 +174,8 @@ template <int TY>
 __global__ void __launch_bounds__(256) ssim_bwd_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
                                                        Win win, const float* __restrict__ Dm, const float* __restrict__ D11,
                                                        const float* __restrict__ D12, float w_l1, float w_ssim,
-                                                       float* __restrict__ dL) {
+                                                       float* __restrict__ dL, const float2* __restrict__ partial, int n_partial,
+                                                       float inv_n, float lambda_dssim, float* __restrict__ loss_out) {
   constexpr int IH = TY + 2 * HALO;
   constexpr int RPT = TY / 8;
   __shared__ __attribute__((aligned(16))) float s[3][IH][SP];
@@ -234,26 +235,27 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(const float* __restrict__
       dL[o] = w_l1 * sgn - w_ssim * (acc[0][e] + 2.f * u * acc[1][e] + v * acc[2][e]);
     }
   }
-}
-
-__global__ void __launch_bounds__(1024) finish_loss_kernel(const float2* __restrict__ partial, int n, float inv_n,
-                                                            float lambda_dssim, float* __restrict__ out) {
-  __shared__ float r1[16], r2[16];
-  float a = 0.f, b = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) { const float2 v = partial[i]; a += v.x; b += v.y; }
+  // The loss value itself: the forward kernel's per-tile sums, folded by ONE workgroup of this kernel in a fixed order (a
+  // launch of its own, finish_loss_kernel, cost 5 us of latency per step for 20 KB of reads; nothing on the device waits for
+  // the value, and here it rides under thousands of other workgroups).
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    __shared__ float r1[4], r2[4];
+    float a = 0.f, b = 0.f;
+    for (int i = tid; i < n_partial; i += 256) { const float2 v = partial[i]; a += v.x; b += v.y; }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
-  if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = a; r2[threadIdx.x >> 6] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int w = 0; w < 16; w++) { s1 += r1[w]; s2 += r2[w]; }
-    const float l1 = s1 * inv_n, ssim = s2 * inv_n;
-    out[0] = (1.f - lambda_dssim) * l1 + lambda_dssim * (1.f - ssim);
-    out[1] = l1;
-    out[2] = ssim;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    __syncthreads();
+    if ((tid & 63) == 0) { r1[tid >> 6] = a; r2[tid >> 6] = b; }
+    __syncthreads();
+    if (tid == 0) {
+      const float l1 = ((r1[0] + r1[1]) + (r1[2] + r1[3])) * inv_n, ssim = ((r2[0] + r2[1]) + (r2[2] + r2[3])) * inv_n;
+      loss_out[0] = (1.f - lambda_dssim) * l1 + lambda_dssim * (1.f - ssim);
+      loss_out[1] = l1;
+      loss_out[2] = ssim;
+    }
   }
 }
+
 }  // namespace
 
 extern "C" {
@@ -289,9 +291,11 @@ int segs_l1_ssim_loss(const float* img1, const float* img2, int H, int W, float 
   if (ty == 32) ssim_fwd_kernel<32><<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, partial);
   else ssim_fwd_kernel<16><<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, partial);
   const float inv_n = 1.0f / (float)plane3;
-  finish_loss_kernel<<<1, 1024, 0, st>>>(partial, (int)(grid.x * grid.y * grid.z), inv_n, lambda_dssim, loss_out);
-  if (ty == 32) ssim_bwd_kernel<32><<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, (1.f - lambda_dssim) * inv_n, lambda_dssim * inv_n, dL_dimg1);
-  else ssim_bwd_kernel<16><<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, (1.f - lambda_dssim) * inv_n, lambda_dssim * inv_n, dL_dimg1);
+  const int n_partial = (int)(grid.x * grid.y * grid.z);
+  if (ty == 32) ssim_bwd_kernel<32><<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, (1.f - lambda_dssim) * inv_n, lambda_dssim * inv_n, dL_dimg1,
+                                                            partial, n_partial, inv_n, lambda_dssim, loss_out);
+  else ssim_bwd_kernel<16><<<grid, block, 0, st>>>(img1, img2, H, W, win, Dm, D11, D12, (1.f - lambda_dssim) * inv_n, lambda_dssim * inv_n, dL_dimg1,
+                                                   partial, n_partial, inv_n, lambda_dssim, loss_out);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SEGS_OK : segs::set_hip_error(e, __func__);
 }
