@@ -27,30 +27,47 @@ __device__ __forceinline__ uint64_t pack_key(int x, int y, int z) {
   return ((uint64_t)(x + KEY_BIAS) << 42) | ((uint64_t)(y + KEY_BIAS) << 21) | (uint64_t)(z + KEY_BIAS);
 }
 
+// thread = candidate slot (coalesced accesses: with a thread per anchor every load instruction of a wave touched 64-120
+// separate sectors and the kernel was bound by that, 15 us at 50 k anchors), 256 / no anchors per workgroup; the per-anchor sum of
+// the clamped opacities goes through LDS.  ONE memory round trip deep: the guard word, the visibility and everything a candidate
+// may need are requested together and unconditionally, the conditions only gate the stores.
 __global__ void __launch_bounds__(256) stats_kernel(int A, int no, const float* __restrict__ nop, const int* __restrict__ vis,
                                                     const int* __restrict__ radii, const float* __restrict__ g2d,
                                                     float* __restrict__ opacity_accum, float* __restrict__ anchor_demon,
                                                     float* __restrict__ grad_accum, float* __restrict__ denom,
                                                     const uint32_t* __restrict__ skip_flag) {
+  __shared__ float clamped[256];
+  const int apw = 256 / no;                             // anchors per workgroup
+  const int tid = threadIdx.x;
+  const int la = tid / no;                              // local anchor of this thread's candidate
+  const int a = blockIdx.x * apw + la;
+  const bool in = la < apw && a < A;
+  const size_t c = (size_t)blockIdx.x * apw * no + tid; // = a * no + k
   // guarded form: a pass the resident rasterizer flagged as overflowed must not enter the statistics (its radii and
   // gradients are meaningless); dropped here on the device, like the optimizer step (segs_adam_step_guarded)
-  if (skip_flag != nullptr && *skip_flag != 0u) return;
-  const int a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= A) return;
-  if (vis && vis[a] <= 0) return;                       // anchor_visible_mask (:1471-1478)
-  float s = 0.f;
-  for (int k = 0; k < no; k++) {
-    const size_t c = (size_t)a * no + k;
-    const float op = nop[c];
-    s += op < 0.f ? 0.f : op;                           // :1467
-    if (op > 0.f && radii[c] > 0) {                     // offset_selection_mask && update_filter (:1481-1484)
-      const float gx = g2d[c * 3], gy = g2d[c * 3 + 1];
-      grad_accum[c] += sqrtf(gx * gx + gy * gy);        // :1494-1499
-      denom[c] += 1.f;
-    }
+  const uint32_t skip = skip_flag != nullptr ? *skip_flag : 0u;
+  const int visible = in ? (vis ? vis[a] : 1) : 0;
+  const float op = in ? nop[c] : 0.f;
+  const int rad = in ? radii[c] : 0;
+  const float gx = in ? g2d[c * 3] : 0.f, gy = in ? g2d[c * 3 + 1] : 0.f;
+  const float ga = in ? grad_accum[c] : 0.f, dn = in ? denom[c] : 0.f;
+  const int a2 = blockIdx.x * apw + tid;                // the anchor whose sums this thread writes (tid < apw)
+  const bool owner = tid < apw && a2 < A;
+  const float oa = owner ? opacity_accum[a2] : 0.f, ad = owner ? anchor_demon[a2] : 0.f;
+  const int vis2 = owner ? (vis ? vis[a2] : 1) : 0;
+  clamped[tid] = op < 0.f ? 0.f : op;                   // :1467
+  __syncthreads();
+  if (skip != 0u) return;
+  if (in && visible > 0 && op > 0.f && rad > 0) {       // anchor_visible_mask (:1471-1478), offset_selection_mask && update_filter (:1481-1484)
+    grad_accum[c] = ga + sqrtf(gx * gx + gy * gy);      // :1494-1499
+    denom[c] = dn + 1.f;
   }
-  opacity_accum[a] += s;
-  anchor_demon[a] += 1.f;
+  if (owner && vis2 > 0) {
+    float s = 0.f;
+    for (int k = 0; k < no; k++) s += clamped[tid * no + k];   // in candidate order, like the reference's sum over dim 1
+    opacity_accum[a2] = oa + s;
+    anchor_demon[a2] = ad + 1.f;
+  }
 }
 
 __global__ void __launch_bounds__(256) select_candidates_kernel(int n_slots, int no, const float* __restrict__ anchor,
@@ -234,11 +251,12 @@ extern "C" {
 int segs_training_statis_guarded(int A, int n_offsets, const float* neural_opacity, const int* visible_radii, const int* radii,
                                  const float* dL_dmean2D, float* opacity_accum, float* anchor_demon, float* offset_gradient_accum,
                                  float* offset_denom, const uint32_t* skip_flag, void* stream) {
-  if (A < 0 || n_offsets <= 0) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
+  if (A < 0 || n_offsets <= 0 || n_offsets > 16) return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size; n_offsets <= 16)");
   if (A == 0) return SEGS_OK;
   if (!neural_opacity || !radii || !dL_dmean2D || !opacity_accum || !anchor_demon || !offset_gradient_accum || !offset_denom)
     return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "invalid argument (null pointer or bad size)");
-  stats_kernel<<<(A + 255) / 256, 256, 0, (hipStream_t)stream>>>(A, n_offsets, neural_opacity, visible_radii, radii, dL_dmean2D,
+  const int apw = 256 / n_offsets;
+  stats_kernel<<<(A + apw - 1) / apw, 256, 0, (hipStream_t)stream>>>(A, n_offsets, neural_opacity, visible_radii, radii, dL_dmean2D,
                                                                  opacity_accum, anchor_demon, offset_gradient_accum, offset_denom,
                                                                  skip_flag);
   const hipError_t e = hipGetLastError();
