@@ -176,19 +176,13 @@ __global__ void __launch_bounds__(256) pack_tables_kernel(Layout L, const float*
                                                           uint32_t* __restrict__ count, float* __restrict__ reg_sum) {
   // first kernel of the forward: also clears the two counters and the regulariser sum (a hipMemsetAsync of 8 bytes is a
   // 5 us kernel of its own)
-  if (blockIdx.x == 0 && threadIdx.x == 0) { count[0] = 0u; count[1] = 0u; *reg_sum = 0.f; }
-  __shared__ float app[MAX_APP];
+  // The LAST workgroup builds the small tables (two dependent levels: appearance vector, then the colour bias that folds it in);
+  // the others build the operand images, one element per thread and one level deep.  (Sixteen workgroups that all formed the
+  // appearance vector first, the first of them also the small tables: 8.9 us, all of it latency.)
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int a = tid; a < MAX_APP; a += nt) {
-    float s = 0.f;
-    if (a < L.app) {
-      s = P[L.ab + a];
-      for (int q = 0; q < 7; q++) s += P[L.aw + a * 7 + q] * pose7[q];
-    }
-    app[a] = s;
-  }
-  __syncthreads();
-  for (int e = blockIdx.x * nt + tid; e < N_IMG_BWD * 64; e += gridDim.x * nt) {
+  const int img_blocks = (int)gridDim.x - 1;
+  if ((int)blockIdx.x < img_blocks)
+  for (int e = blockIdx.x * nt + tid; e < N_IMG_BWD * 64; e += img_blocks * nt) {
     const int im = e >> 6, l = e & 63, i = l & 31, hA = l >> 5;
     float v = 0.f;
     if (im < I_L2) {                     // layer 1: A[i = hidden][k = 2s + hA]
@@ -208,7 +202,18 @@ __global__ void __launch_bounds__(256) pack_tables_kernel(Layout L, const float*
     }
     img[e] = v;
   }
-  if (blockIdx.x != 0) return;
+  if ((int)blockIdx.x != img_blocks) return;
+  if (tid == 0) { count[0] = 0u; count[1] = 0u; *reg_sum = 0.f; }
+  __shared__ float app[MAX_APP];
+  for (int a = tid; a < MAX_APP; a += nt) {
+    float s = 0.f;
+    if (a < L.app) {
+      s = P[L.ab + a];
+      for (int q = 0; q < 7; q++) s += P[L.aw + a * 7 + q] * pose7[q];
+    }
+    app[a] = s;
+  }
+  __syncthreads();
   Small& S = *Sg;
   for (int e = tid; e < 3 * FD; e += nt) {
     const int m = e / FD, j = e - m * FD;
@@ -1885,7 +1890,7 @@ static int neural_forward_impl(const segs_neural_dims* dims, int A, const float*
   temp_carve(A, L.total, L.bank, temp, &T);
   static_assert(N_IMG_BWD == 262 && sizeof(Small) <= 8192, "temp_carve sizes");
   // T.count: [0] visible anchors, [1] kept candidates; cleared (with the regulariser sum) by pack_tables_kernel
-  pack_tables_kernel<<<16, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small, T.count, T.gsum + L.total + 8);
+  pack_tables_kernel<<<(N_IMG_BWD * 64 + 255) / 256 + 1, 256, 0, st>>>(L, mlp_params, pose7, T.images, (Small*)T.small, T.count, T.gsum + L.total + 8);
   const bool small_map = A < 131072;
   const int per_wg = small_map ? 256 : 2048;
   const int nb = (A + per_wg - 1) / per_wg;
