@@ -67,6 +67,11 @@ const char* segs_last_error(void);
  * forward and backward (src/rasterize_points.cu:28-34; rasterizer_impl.h:22-73) and R is only ever handed back to backward
  * (src/gaussian_rasterizer.cpp:60-88,120-141).  The segs_debug_unpack_* helpers describe default-mode scratch only. */
 #define SEGS_RASTER_TIGHT_BINNING 32u
+/* SEGS_RASTER_MFMA_MOMENTS (A/B measurements and tests; backward entry points): the tile backward forms its nine per-Gaussian sums
+ * with v_mfma_f32_16x16x4_f32 (moments about the quadrant centre) instead of vector FMAs.  Same results inside the gradient
+ * tolerance; slower on MI355X, where an f32 MFMA takes its cycles out of the SIMD's vector issue (DESIGN.md section 7.0,
+ * tools/ubench_mfma_valu_overlap.hip).  Also switched on by the environment variable SEGS_RENDER_BWD_MFMA=1. */
+#define SEGS_RASTER_MFMA_MOMENTS 64u
 uint32_t segs_raster_set_flags(uint32_t flags);
 
 /* Resident mode only, per host thread; returns the previous pointer.  When set, segs_rasterize_forward_resident also

@@ -465,7 +465,8 @@ static int rasterize_backward_impl(int P, int D, int M, int R, const float* back
   }
   if (R > 0) {
     { PROF(K_RENDER_BWD);
-    render_bwd_kernel<<<(gx * gy + 7) / 8 * 32, 64, 0, st>>>((const uint2*)(img + IL.ranges), (const uint32_t*)(bin + BL.vals[0]), width,
+    static const bool mfma_env = [] { const char* e = getenv("SEGS_RENDER_BWD_MFMA"); return e && e[0] == '1'; }();   // measurement A/B only
+    ((mfma_env || (g_flags & SEGS_RASTER_MFMA_MOMENTS)) ? render_bwd_mfma_kernel : render_bwd_kernel)<<<(gx * gy + 7) / 8 * 32, 64, 0, st>>>((const uint2*)(img + IL.ranges), (const uint32_t*)(bin + BL.vals[0]), width,
                                                     height, G.rec(), background, (const float*)(img + IL.final_T),
                                                     (const uint32_t*)(img + IL.n_contrib), dL_dpix, G.gacc(), gx * gy);
     }

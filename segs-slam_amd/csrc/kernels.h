@@ -93,6 +93,11 @@ __global__ void render_bwd_kernel(const uint2* __restrict__ ranges, const uint32
                                   const float* __restrict__ rec, const float* __restrict__ bg,
                                   const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
                                   const float* __restrict__ dL_dpix, float* __restrict__ gacc, uint32_t num_tiles);
+// A/B partner of render_bwd_kernel: the Gaussian role's sums as v_mfma_f32_16x16x4_f32 instead of VALU FMAs (SEGS_RENDER_BWD_MFMA=1)
+__global__ void render_bwd_mfma_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
+                                       const float* __restrict__ rec, const float* __restrict__ bg,
+                                       const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+                                       const float* __restrict__ dL_dpix, float* __restrict__ gacc, uint32_t num_tiles);
 
 // ---- debug / test support (binning.hip)
 __global__ void unpack_geometry_kernel(int P, const float* __restrict__ rec, const BinInfo* __restrict__ bin,

@@ -272,7 +272,10 @@ __device__ __forceinline__ void pixel_role(BwdLds& L, int nb, int lane, float px
   }
 }
 
-__global__ void __launch_bounds__(64) render_bwd_kernel(
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool MFMA>
+__device__ __forceinline__ void render_bwd_body(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
     const float* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ gacc, uint32_t num_tiles) {
@@ -319,6 +322,36 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
   const int gs = lane & 15, part = lane >> 4;
   const float pyl0 = (float)(part * 2), pyl1 = pyl0 + 1.0f;
   const float qx0f = (float)qx0, qy0f = (float)qy0;
+
+  // Matrix-pipe form of the Gaussian role (MFMA = true): the batch's nine sums per slot are ONE product
+  //   D[16 slots x 16] = [W | A](16 x 128) . [[F1, 0], [0, F2]](128 x 16),   W, A = the (w, alpha T) tiles in LDS,
+  // F1[pixel] = (1, x, y, x^2, x y, y^2) about the quadrant centre (3.5, 3.5), F2[pixel] = dL/dpixel rgb -- both the same for
+  // every batch of the wave, so the 2 x 16 B operands of v_mfma_f32_16x16x4_f32 are built once.  Step t contracts the four
+  // pixels 16 g + t (g = lane / 16 = the instruction's k index): lane (j, g) holds column j of F at that pixel.
+  float bmono[16], bcol[16];
+  if (MFMA) {
+    float* dps = reinterpret_cast<float*>(&L.wa[0][0]);   // [3][64] staging of dL/dpixel, free before the first batch
+    dps[lane] = dp0; dps[64 + lane] = dp1; dps[128 + lane] = dp2;
+    wave_lds_fence();
+    const float j1 = gs == 1 ? 1.f : 0.f, j3 = gs == 3 ? 1.f : 0.f, j4 = gs == 4 ? 1.f : 0.f;
+    const bool colour = gs >= 6 && gs < 9;
+    const int crow = colour ? (gs - 6) * 64 + part * 16 : 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const float y = (float)(2 * part + h) - 3.5f;
+      // column j at (x, y): c0 + x (c1 + x c2);  j: 0 -> 1, 1 -> x, 2 -> y, 3 -> x^2, 4 -> x y, 5 -> y^2, others 0
+      const float c0 = gs == 0 ? 1.f : gs == 2 ? y : gs == 5 ? y * y : 0.f;
+      const float c1 = j1 + j4 * y;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float x = (float)c - 3.5f;
+        bmono[8 * h + c] = c0 + x * (c1 + x * j3);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; t++) { const float v = dps[crow + t]; bcol[t] = colour ? v : 0.f; }
+    wave_lds_fence();
+  }
 
   const int32_t cfirst = (int32_t)((wave_last - 1u) & ~63u);
   uint32_t v_nxt = 0u;
@@ -377,12 +410,37 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
       continue;   // (the do-while's condition is evaluated)
 #endif
       // ---------------- (2) Gaussian role: lane = (part, gs): slot gs, pixels part*16 .. part*16+15
+      const float2 gxy = *reinterpret_cast<const float2*>(&L.rec[gs][0]);
+      const float gxr = gxy.x - qx0f, gyr = gxy.y - qy0f;
+      float cx, cy;
+      if (MFMA) {
+        // One dependent chain per operand tile (the instruction's dependent latency is 40 cycles against 32 of issue: two
+        // independent accumulators keep the pipe full).  A operand: lane (gs, part) reads slot gs, pixel 16 part + t.
+        cx = 3.5f; cy = 3.5f;
+        f32x4 dw = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+        const float2* warow = &L.wa[gs][part * 16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+          const float2 wa_t = warow[t];
+#ifdef SEGS_MFMA_ONE_CHAIN
+          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_t.x, bmono[t], dw, 0, 0, 0);
+          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_t.y, bcol[t], dw, 0, 0, 0);
+#else
+          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_t.x, bmono[t], dw, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_t.y, bcol[t], da, 0, 0, 0);
+#endif
+        }
+        // D: lane (j = gs, g = part) holds column j of slots 4 g .. 4 g + 3; columns 0-5 come from dw, 6-8 from da (the other
+        // tile's columns are exact zeros there)
+        if (gs < 9) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) mom[4 * part + r][gs] = dw[r] + da[r];
+        }
+      } else {
       // Moments are taken about the quadrant pixel NEAREST to the Gaussian's centre (cx, cy in 0..7), not about the
       // quadrant corner: for a centre inside the quadrant |gxr - cx| <= 0.5, so the later shift to centre-relative
       // moments (Mxx = g'^2 S0 - 2 g' S1x + Sxx) subtracts nothing large even for sub-pixel Gaussians.
-      const float2 gxy = *reinterpret_cast<const float2*>(&L.rec[gs][0]);
-      const float gxr = gxy.x - qx0f, gyr = gxy.y - qy0f;
-      const float cx = fminf(7.f, fmaxf(0.f, rintf(gxr))), cy = fminf(7.f, fmaxf(0.f, rintf(gyr)));
+      cx = fminf(7.f, fmaxf(0.f, rintf(gxr))); cy = fminf(7.f, fmaxf(0.f, rintf(gyr)));
       // The six w-moments are separable over the lane's two pixel rows (8 pixels each): per pixel only the row sums
       // R0 = sum w, R1 = sum w x, R2 = sum w x^2 (3 ops), per row six more; the colour sums need dL/dpixel per pixel.
       float px8[8], px8q[8];
@@ -414,6 +472,7 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
       mom[gs][part] = g1;
       mom[gs][4 + part] = g2;
       if (part == 0) mom[gs][8] = g3;
+      }
       wave_lds_fence();
       {
         // every lane of column gs shifts slot gs from quadrant-local moments to Gaussian-relative ones
@@ -452,6 +511,20 @@ __global__ void __launch_bounds__(64) render_bwd_kernel(
     } while (taken < n);
     if (tail) break;
   }
+}
+
+__global__ void __launch_bounds__(64) render_bwd_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
+    const float* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ gacc, uint32_t num_tiles) {
+  render_bwd_body<false>(ranges, point_list, W, H, rec, bg, final_T, n_contrib, dL_dpix, gacc, num_tiles);
+}
+// The Gaussian role's sums on the matrix pipe: the measured A/B partner (SEGS_RENDER_BWD_MFMA=1, capi.hip).
+__global__ void __launch_bounds__(64) render_bwd_mfma_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H,
+    const float* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ gacc, uint32_t num_tiles) {
+  render_bwd_body<true>(ranges, point_list, W, H, rec, bg, final_T, n_contrib, dL_dpix, gacc, num_tiles);
 }
 
 }  // namespace segs

@@ -216,6 +216,23 @@ def test_small_scenes(P, W, H, bg):
     run_parity(sc)
 
 
+def test_matrix_pipe_gaussian_role_matches_oracle():
+    """render_bwd_mfma_kernel (SEGS_RASTER_MFMA_MOMENTS): the tile backward's nine sums per Gaussian as v_mfma_f32_16x16x4_f32
+    products with moments about the quadrant centre -- the measured A/B partner of the default kernel -- held
+    to the same gradient bar, unchanged, on a deep small scene and on BASELINE config 1."""
+    from segs_slam_amd import _capi
+    lib = _capi.lib()
+    old = lib.segs_raster_set_flags(64)
+    try:
+        sc = scenes.make_scene(5000, 200, 120, 180.0, 180.0, seed=9005, bg=(0.1, 0.0, 0.2))
+        sc.scales *= 3.0
+        sc.dL_dout_color[:] = (scenes.uniform01(sc.dL_dout_color.size, 56, 5000).reshape(sc.dL_dout_color.shape) * 2 - 1)
+        run_parity(sc)
+        run_parity(scenes.make_config_scene("c1"))
+    finally:
+        lib.segs_raster_set_flags(old)
+
+
 def test_config1_50k_640x480():
     """BASELINE.json configs[0]: 50k Gaussians, 640x480 (forward + backward here)."""
     sc = scenes.make_config_scene("c1")
