@@ -354,14 +354,18 @@ void GaussianTrainerStep::forward_backward(const KeyframeView& kf, const torch::
                           (char*)loss_temp_.data_ptr(), st),
         "segs_l1_ssim_loss");
   if (freq_.on && iteration_ > freq_.start && iteration_ < freq_.until) {   // src/gaussian_mapper.cpp:938
-    auto hit = freq_.targets.find(gt_image.data_ptr());
+    const uint32_t version = gt_image._version();
+    auto hit = freq_.targets.begin();
+    while (hit != freq_.targets.end() && !(hit->gt.data_ptr() == gt_image.data_ptr() && hit->version == version)) ++hit;
     if (hit == freq_.targets.end()) {
-      if (freq_.targets.size() >= 1024) freq_.targets.clear();
+      while (freq_.targets.size() >= freq_.max_targets) freq_.targets.pop_back();
       auto tab = torch::empty({(int64_t)segs_freq_target_floats(freq_.plan)}, torch::TensorOptions().dtype(torch::kFloat32).device(dev_));
       check(segs_freq_target(freq_.plan, fp(gt_image), fp(tab), st), "segs_freq_target");
-      hit = freq_.targets.emplace(gt_image.data_ptr(), tab).first;
+      freq_.targets.push_front({gt_image, tab, version});
+    } else if (hit != freq_.targets.begin()) {
+      freq_.targets.splice(freq_.targets.begin(), freq_.targets, hit);
     }
-    check(segs_freq_loss(freq_.plan, fp(out_color_), fp(hit->second), fp(dL_dimage_), fp(freq_value_), fp(loss_out_), st), "segs_freq_loss");
+    check(segs_freq_loss(freq_.plan, fp(out_color_), fp(freq_.targets.front().table), fp(dL_dimage_), fp(freq_value_), fp(loss_out_), st), "segs_freq_loss");
   }
   if (dL_mask_.defined()) dL_dimage_.mul_(dL_mask_);
   if (last_resident_) {

@@ -20,6 +20,7 @@
 #include <torch/csrc/distributed/c10d/Backend.hpp>
 
 #include <functional>
+#include <list>
 #include <map>
 #include <memory>
 #include <string>
@@ -129,6 +130,9 @@ class GaussianTrainerStep {
   void enable_frequency_regularization(float lambda_high, const std::vector<float>& scales, int64_t start, int64_t until,
                                        bool multi_resolution = true);
   torch::Tensor frequency_loss() { return freq_value_; }   // value of the regulariser in the last iteration (1 device float)
+  // how many targets' |FFT| tables (and the targets themselves) the step keeps: 6.5 + 9.8 MB each at 1200x680
+  void set_frequency_target_cache(size_t max_targets) { freq_.max_targets = max_targets ? max_targets : 1; }
+  size_t frequency_targets_cached() const { return freq_.targets.size(); }
 
   // test support: dL/dimage is multiplied by this (H,W) mask before the raster backward (the parity tests blank the pixels
   // whose compositing decisions sit on a threshold, on both sides); and a callback that sees the gradient bucket exactly as
@@ -212,7 +216,13 @@ class GaussianTrainerStep {
     std::vector<float> scales;
     int64_t start = 0, until = 0;
     segs_freq_plan* plan = nullptr;
-    std::map<const void*, torch::Tensor> targets;   // |FFT(gt)| tables per target tensor (a keyframe's image does not change)
+    // |FFT(gt)| tables per target tensor (a keyframe's image does not change).  An entry is keyed on the target's address AND
+    // its version counter and KEEPS THE TARGET ALIVE: the caching allocator hands a freed image's address to the next one (the
+    // reference's mapper makes a fresh `gt_image * mask_rgb` every iteration, src/gaussian_mapper.cpp:921), and an in-place
+    // refresh of a staging buffer bumps the version.  Least recently used entries go first (set_frequency_target_cache).
+    struct Target { torch::Tensor gt, table; uint32_t version; };
+    std::list<Target> targets;       // most recently used first
+    size_t max_targets = 64;
   } freq_;
 };
 

@@ -31,6 +31,7 @@
 
 #include "anchor_densifier.h"
 #include "gaussian_trainer.h"
+#include "../../../include/segs_raster.h"
 #include "keyframe_exchange.h"
 
 static torch::Tensor rd(std::ifstream& f, std::vector<int64_t> shape) {
@@ -189,6 +190,72 @@ static int run_chain(const char* in, const char* out) {
   return 0;
 }
 
+// trainer_test --freq-cache <in.bin> <out.bin>: the |FFT(target)| cache of the frequency regulariser against the host pattern of
+// the reference's mapper (src/gaussian_mapper.cpp:845,921: a FRESH target tensor every iteration, the previous one freed).  Three
+// iterations: target A; A freed and target B allocated (the caching allocator would hand B the address of A); B refreshed IN PLACE
+// with image A.  After each, the regulariser is re-evaluated here with a table made from the target the step was given -- on the
+// image the step rendered in that iteration -- and must equal the step's value bit for bit.  out.bin: 3 x (step value, direct value).
+static int run_freq_cache(const char* in, const char* out) {
+  std::ifstream f(in, std::ios::binary);
+  int32_t hdr[6]; float tf[3];
+  f.read(reinterpret_cast<char*>(hdr), sizeof(hdr));
+  f.read(reinterpret_cast<char*>(tf), sizeof(tf));
+  const int A = hdr[0], W = hdr[1], H = hdr[2];
+  segs_host::ScaffoldDims dims;
+  dims.appearance_dim = hdr[3];
+  dims.use_feat_bank = hdr[4] != 0;
+  segs_host::GaussianTrainerStep step(A, dims, W, H, torch::Device(torch::kCUDA, 0), segs_host::ScaffoldOptimization(), tf[2]);
+  step.param("anchor").copy_(rd(f, {A, 3}));
+  step.param("offset").copy_(rd(f, {A, dims.n_offsets, 3}));
+  step.param("anchor_feat").copy_(rd(f, {A, dims.feat_dim}));
+  step.param("scaling").copy_(rd(f, {A, 6}));
+  step.mlp_params().copy_(rd(f, {step.mlp_params().numel()}));
+  segs_host::KeyframeView kf;
+  kf.view = rd(f, {4, 4}); kf.proj = rd(f, {4, 4}); kf.campos = rd(f, {3}); kf.pose7 = rd(f, {7});
+  kf.tanfovx = tf[0]; kf.tanfovy = tf[1];
+  auto img_a = rd(f, {3, H, W}).cpu();
+  auto img_b = img_a.flip({2}).mul(0.5f).add(0.25f).contiguous();          // another image of the same size
+  const std::vector<float> scales{1.0f, 0.5f, 0.25f};
+  const float lam = 0.01f;
+  step.enable_frequency_regularization(lam, scales, -1, 1 << 30, true);
+  step.set_frequency_target_cache(2);
+  segs_freq_plan* plan = nullptr;
+  if (segs_freq_plan_create(H, W, 3, scales.data(), lam, &plan) != 0) { std::fprintf(stderr, "segs_freq_plan_create: %s\n", segs_last_error()); return 1; }
+  auto fopt = torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA);
+  auto table = torch::empty({(int64_t)segs_freq_target_floats(plan)}, fopt);
+  auto direct = torch::zeros({1}, fopt), scratch = torch::zeros({3, H, W}, fopt);
+  void* st = (void*)c10::hip::getCurrentHIPStream().stream();
+  std::vector<float> vals;
+  const void* addr_a = nullptr;
+  int same_address = 0;
+  auto once = [&](const torch::Tensor& gt) {
+    step.trainingOnce(kf, gt);
+    if (segs_freq_target(plan, gt.data_ptr<float>(), table.data_ptr<float>(), st) != 0 ||
+        segs_freq_loss(plan, step.image().data_ptr<float>(), table.data_ptr<float>(), scratch.data_ptr<float>(), direct.data_ptr<float>(), nullptr, st) != 0) {
+      std::fprintf(stderr, "direct evaluation: %s\n", segs_last_error());
+      std::exit(1);
+    }
+    vals.push_back(step.frequency_loss().item<float>());
+    vals.push_back(direct.item<float>());
+  };
+  {
+    auto gt = img_a.to(torch::kCUDA);
+    addr_a = gt.data_ptr();
+    once(gt);
+  }                                            // the host's handle on target A is gone
+  auto gt2 = img_b.to(torch::kCUDA);           // without an owning cache entry this lands on A's address
+  same_address = gt2.data_ptr() == addr_a;
+  once(gt2);
+  gt2.copy_(img_a.to(torch::kCUDA));           // same tensor, same address, new contents
+  once(gt2);
+  torch::cuda::synchronize();
+  segs_freq_plan_destroy(plan);
+  std::ofstream o(out, std::ios::binary);
+  o.write(reinterpret_cast<const char*>(vals.data()), vals.size() * 4);
+  std::printf("trainer_test --freq-cache ok second target at the first one's address: %d, cached %d\n", same_address, (int)step.frequency_targets_cached());
+  return 0;
+}
+
 static int run_mapper(int argc, char** argv) {
   const char* in = argv[2];
   const char* out = argv[3];
@@ -272,6 +339,7 @@ static int run_mapper(int argc, char** argv) {
 int main(int argc, char** argv) {
   if (argc >= 4 && std::string(argv[1]) == "--mapper") return run_mapper(argc, argv);
   if (argc >= 4 && std::string(argv[1]) == "--chain") return run_chain(argv[2], argv[3]);
+  if (argc >= 4 && std::string(argv[1]) == "--freq-cache") return run_freq_cache(argv[2], argv[3]);
   if (argc < 3) { std::fprintf(stderr, "usage: trainer_test in.bin out.bin | trainer_test --mapper in.bin out.bin [...]\n"); return 2; }
   return run_single(argv[1], argv[2]);
 }

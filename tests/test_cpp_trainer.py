@@ -348,3 +348,34 @@ def test_cpp_trainer_matches_the_oracle_chain_directly(tmp_path, cfg, freq):
             raise AssertionError((it, int(off.sum()), seg, float(upd_cpp[worst]), float(upd_ref[worst])))
         assert float((upd_ref != 0).mean()) > 0.7
         p_before = p_cpp[it].copy()
+
+
+@pytest.mark.gpu
+def test_cpp_frequency_target_cache_survives_recycled_addresses_and_in_place_refreshes(tmp_path):
+    """The C++ host's |FFT(target)| cache under the reference mapper's host pattern (src/gaussian_mapper.cpp:845,921: a fresh
+    target tensor per iteration): a freed target whose address the allocator hands to the next image, and a staging tensor
+    refreshed in place, must both get their OWN tables.  trainer_test --freq-cache re-evaluates the regulariser after every
+    iteration with a table made from the target it handed over; the step's value must be that value bit for bit."""
+    from segs_slam_amd import neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    W, H, A = 320, 240, 2000
+    cam = scenes.make_camera(W, H, 300.0, 300.0, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+    dims = ng.ModelDims(appearance_dim=32, use_feat_bank=True)
+    model = ng.synthetic_model(A, dims, cam, dev, seed=33)
+    pose7 = np.array([0.1, -0.05, 0.02, 0.98, 0.05, -0.1, 0.15], dtype=np.float32)
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(14))
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        np.array([A, W, H, dims.appearance_dim, int(dims.use_feat_bank), 3], np.int32).tofile(f)
+        np.array([cam.tanfovx, cam.tanfovy, 0.01], np.float32).tofile(f)
+        for name in ("anchor", "offset", "anchor_feat", "scaling"):
+            model.param(name).cpu().numpy().astype(np.float32).tofile(f)
+        model.mlp_params.cpu().numpy().astype(np.float32).tofile(f)
+        for a in (cam.world_view_transform, cam.full_proj_transform, cam.camera_center, pose7, gt.numpy()):
+            np.ascontiguousarray(a, np.float32).tofile(f)
+    out = subprocess.check_output([os.path.join(TB, "trainer_test"), "--freq-cache", str(fin), str(fout)], text=True)
+    assert "second target at the first one's address: 0" in out, out    # the cache entry owns target A, so B cannot land on it
+    v = np.fromfile(fout, np.float32).reshape(3, 2)
+    assert np.all(v > 0)
+    assert np.array_equal(v[:, 0], v[:, 1]), v
+    assert v[0, 0] != v[1, 0] and v[1, 0] != v[2, 0], v                  # the three targets are different images to the loss
