@@ -419,17 +419,34 @@ void GaussianTrainerStep::adam(const std::vector<segs_adam_segment>& groups_in, 
 // and the target's tensors must therefore stay unchanged until the next call.
 torch::Tensor GaussianTrainerStep::trainingOnce(const KeyframeView& kf, const torch::Tensor& gt_image) {
   TORCH_CHECK(gt_image.is_contiguous() && gt_image.sizes() == out_color_.sizes() && gt_image.device() == dev_, "gt_image must be a contiguous (3,H,W) tensor on the step's device");
-  if (redo_dropped_steps_ && have_last_ && world() == 1 && resolve_status()) {
-    have_last_ = false;
-    redone_steps_ += 1;
-    iteration_body(last_kf_, last_gt_);   // iteration_ still holds that iteration's number
-  }
+  redo_if_dropped();
   iteration_ += 1;
   last_kf_ = kf;
   last_gt_ = gt_image;
   have_last_ = true;
   return iteration_body(kf, gt_image);
 }
+
+// An iteration the device dropped is run again -- same keyframe, same iteration number (iteration_ still holds it) -- before the
+// next one is queued.  One rank: this rank's own status word.  N > 1: the summed word every rank mirrored to its host after the
+// gradient exchange (KeyframeExchange::mirror_flag), so all ranks redo the same iteration together; the rank that overflowed
+// re-calibrates in its forward (resolve_status), and a redo that another rank's overflow drops again is redone again.
+void GaussianTrainerStep::redo_if_dropped() {
+  if (!redo_dropped_steps_ || !have_last_) return;
+  have_last_ = false;
+  for (int tries = 0;; tries++) {
+    bool dropped;
+    if (world() == 1) dropped = resolve_status();
+    else { dropped = exchange().step_dropped(); resolve_status(); }
+    if (!dropped) return;
+    TORCH_CHECK(tries < 4, "an iteration kept being dropped by the device");
+    redone_steps_ += 1;
+    iteration_body(last_kf_, last_gt_);
+    if (world() == 1) return;   // (a re-calibrating forward cannot overflow)
+  }
+}
+
+void GaussianTrainerStep::finish() { redo_if_dropped(); }
 
 torch::Tensor GaussianTrainerStep::iteration_body(const KeyframeView& kf, const torch::Tensor& gt_image) {
   std::vector<double> lr;
@@ -455,7 +472,8 @@ torch::Tensor GaussianTrainerStep::iteration_body(const KeyframeView& kf, const 
   // a densification may re-size the bucket, so the shard partition the optimizer clips to below is not the one a
   // reduce-scatter would have summed for: every element gets the full sum on those steps
   exchange().reduce_gradients(model_.grads, adjust_now);
-  if (on_gradients) on_gradients(model_.grads);
+  if (exchange().active() && redo_dropped_steps_ && !adjust_now) exchange().mirror_flag();   // (an adjust_anchor iteration has resolved its word above)
+  if (on_gradients_) on_gradients_(model_.grads);
   bool adjusted = false;
   if (in_stat_window) {
     d->training_statis(neural_opacity_, visible_radii_, radii_, dL_dmean2D_, guard, world() > 1, cur_stream(dev_));

@@ -134,21 +134,26 @@ class GaussianTrainerStep {
   void set_frequency_target_cache(size_t max_targets) { freq_.max_targets = max_targets ? max_targets : 1; }
   size_t frequency_targets_cached() const { return freq_.targets.size(); }
 
-  // test support: dL/dimage is multiplied by this (H,W) mask before the raster backward (the parity tests blank the pixels
-  // whose compositing decisions sit on a threshold, on both sides); and a callback that sees the gradient bucket exactly as
-  // the optimizer receives it (after the exchange, before Adam clears it)
-  void set_image_gradient_mask(const torch::Tensor& mask_hw) { dL_mask_ = mask_hw; }
   // SURVEY 8f n3 (default on): once the rasterizer's resident scratch is calibrated, the neural forward runs the per-Gaussian
   // projection (K1) and prefilter_voxel itself (segs_neural_forward_projected) and the rasterizer starts at the binning
   // (segs_rasterize_forward_resident_projected).  Same image, radii and gradients bit for bit; colours and opacities of the
   // candidates are then not materialised as arrays.
   void set_fuse_projection(bool on) { fuse_projection_ = on; }
-  // One rank: run an iteration the device dropped (resident capacity overflow) again before the next one (trainingOnce).
+  // Run an iteration the device dropped (a resident-capacity overflow on ANY rank) again before the next one (trainingOnce; on by
+  // default).  finish(): resolve the LAST iteration's word and redo it if needed -- call once after the last trainingOnce of a run.
   void set_redo_dropped_steps(bool on) { redo_dropped_steps_ = on; }
   int64_t redone_steps() const { return redone_steps_; }
-  // test support: make the next resident forward overflow (capacity = last instance count / divisor; the buffers stay as large as they are)
+  void finish();
+#ifdef SEGS_TESTING
+  // Test support, compiled in only for the drivers under tests/ (trainer_test is built with -DSEGS_TESTING; the class layout does
+  // not depend on the macro).  dL/dimage is multiplied by this (H,W) mask before the raster backward (the parity tests blank the
+  // pixels whose compositing decisions sit on a threshold, on both sides); a callback that sees the gradient bucket exactly as the
+  // optimizer receives it (after the exchange, before Adam clears it); and a way to make the next resident forward overflow
+  // (capacity = last instance count / divisor; the buffers stay as large as they are).
+  void set_image_gradient_mask(const torch::Tensor& mask_hw) { dL_mask_ = mask_hw; }
+  void set_on_gradients(std::function<void(const torch::Tensor&)> fn) { on_gradients_ = std::move(fn); }
   void debug_shrink_capacity(int divisor) { resolve_status(); if (capacity_ > 0) capacity_ = std::max(num_rendered_ / divisor, 1024); }
-  std::function<void(const torch::Tensor&)> on_gradients;
+#endif
 
   torch::Tensor image() { return out_color_; }
   torch::Tensor scaling_reg() { return scaling_reg_; }
@@ -172,6 +177,8 @@ class GaussianTrainerStep {
   const torch::Tensor& anchor_rotations();
   void render(const KeyframeView& kf);
   bool resolve_status();
+  void redo_if_dropped();
+  std::function<void(const torch::Tensor&)> on_gradients_;
   torch::Tensor iteration_body(const KeyframeView& kf, const torch::Tensor& gt_image);
   void forward_backward(const KeyframeView& kf, const torch::Tensor& gt_image);
   void adam(const std::vector<segs_adam_segment>& groups, StepCount& count, const uint32_t* guard);

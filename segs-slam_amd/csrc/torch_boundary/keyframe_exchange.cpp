@@ -3,6 +3,9 @@
 
 #include <algorithm>
 
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime.h>
+
 namespace segs_host {
 namespace {
 constexpr int64_t ALIGN = 4;   // shard boundaries fall on 16-byte boundaries (float4 accesses of the fused Adam)
@@ -66,6 +69,36 @@ torch::Tensor KeyframeExchange::wait_flag() {
   }
   if (flag_work_) { flag_work_->wait(); flag_work_.reset(); }
   return flag_;
+}
+
+KeyframeExchange::~KeyframeExchange() {
+  if (mirror_event_) (void)hipEventDestroy((hipEvent_t)mirror_event_);
+}
+
+void KeyframeExchange::mirror_flag() {
+  torch::Tensor w = wait_flag();
+  if (!dev_.is_cuda()) {
+    mirror_host_ = w.to(torch::kCPU).clone();
+    mirror_pending_ = true;
+    return;
+  }
+  if (!mirror_host_.defined()) {
+    mirror_host_ = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    hipEvent_t e;
+    TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreateWithFlags");
+    mirror_event_ = e;
+  }
+  hipStream_t st = c10::hip::getCurrentHIPStream(dev_.index()).stream();
+  TORCH_CHECK(hipMemcpyAsync(mirror_host_.data_ptr(), w.data_ptr(), 4, hipMemcpyDeviceToHost, st) == hipSuccess, "hipMemcpyAsync");
+  TORCH_CHECK(hipEventRecord((hipEvent_t)mirror_event_, st) == hipSuccess, "hipEventRecord");
+  mirror_pending_ = true;
+}
+
+bool KeyframeExchange::step_dropped() {
+  if (!mirror_pending_) return false;
+  mirror_pending_ = false;
+  if (mirror_event_) TORCH_CHECK(hipEventSynchronize((hipEvent_t)mirror_event_) == hipSuccess, "hipEventSynchronize");
+  return mirror_host_.data_ptr<int32_t>()[0] != 0;
 }
 
 void KeyframeExchange::all_reduce_sum(torch::Tensor t) {

@@ -32,6 +32,9 @@ class KeyframeExchange {
   // rank (exercises the RCCL calls on a one-GPU box).
   KeyframeExchange(int64_t n, torch::Device device, c10::intrusive_ptr<c10d::Backend> pg, bool sharded = true,
                    bool single_rank_collectives = false);
+  ~KeyframeExchange();
+  KeyframeExchange(const KeyframeExchange&) = delete;
+  KeyframeExchange& operator=(const KeyframeExchange&) = delete;
 
   int world() const { return world_; }
   int rank() const { return rank_; }
@@ -49,6 +52,13 @@ class KeyframeExchange {
   void reduce_flag_async(const torch::Tensor& local_flag);
   torch::Tensor wait_flag();
 
+  // The SUMMED word on the host, one step late, so that no iteration is lost with N > 1 ranks either: mirror_flag() queues a
+  // copy of the summed word into pinned host memory (call after wait_flag()); step_dropped() waits for that copy and says
+  // whether some rank's pass was invalid (false when nothing was mirrored since the last call).  Every rank mirrors the same
+  // word, so every rank takes the same decision without another collective.
+  void mirror_flag();
+  bool step_dropped();
+
   void reduce_gradients(torch::Tensor grads, bool dense = false);
   void gather(torch::Tensor bucket);
   // plain sum over ranks (the densification statistics' shadow)
@@ -63,6 +73,9 @@ class KeyframeExchange {
   torch::Tensor flag_, local_, send_, shard_, full_;
   c10::intrusive_ptr<c10d::Work> flag_work_;
   bool local_set_ = false;
+  torch::Tensor mirror_host_;
+  void* mirror_event_ = nullptr;
+  bool mirror_pending_ = false;
 };
 
 }  // namespace segs_host

@@ -170,7 +170,7 @@ static int run_chain(const char* in, const char* out) {
   f.read(reinterpret_cast<char*>(&lam), 4);
   if (lam != 0.f) step.enable_frequency_regularization(lam, {1.0f, 0.5f, 0.25f}, fr[0], fr[1], true);
   std::vector<torch::Tensor> grads, params;
-  step.on_gradients = [&](const torch::Tensor& g) { grads.push_back(g.clone()); };
+  step.set_on_gradients([&](const torch::Tensor& g) { grads.push_back(g.clone()); });
   std::vector<float> scal;
   torch::Tensor first_image, first_radii;
   for (int it = 0; it < n_steps; it++) {
@@ -315,12 +315,18 @@ static int run_mapper(int argc, char** argv) {
   }
   std::vector<float> losses;
   std::vector<int32_t> sizes;
+  // test hook (tests/test_cpp_trainer.py): SEGS_TRAINER_TEST_OVERFLOW_AT=k with SEGS_TRAINER_TEST_OVERFLOW_RANK=r shrinks rank r's
+  // resident capacity in front of loop index k, so that ITS forward overflows and every rank's device drops that pass
+  const int overflow_at = std::getenv("SEGS_TRAINER_TEST_OVERFLOW_AT") ? std::atoi(std::getenv("SEGS_TRAINER_TEST_OVERFLOW_AT")) : -1;
+  const int overflow_rank = std::getenv("SEGS_TRAINER_TEST_OVERFLOW_RANK") ? std::atoi(std::getenv("SEGS_TRAINER_TEST_OVERFLOW_RANK")) : 0;
   for (int it = 0; it < n_steps; it++) {
     const int k = (it * world + rank) % n_kf;
+    if (it == overflow_at && rank == overflow_rank) step.debug_shrink_capacity(3);
     auto loss = step.trainingOnce(kfs[k], gts[k]);
     losses.push_back(loss.item<float>());
     sizes.push_back((int32_t)step.model().A);
   }
+  step.finish();
   torch::cuda::synchronize();
   auto& m = step.model();
   std::ofstream o(out, std::ios::binary);
@@ -331,8 +337,8 @@ static int run_mapper(int argc, char** argv) {
   for (const char* name : {"anchor", "offset", "anchor_feat", "scaling"}) wr(o, m.param(name));
   wr(o, m.mlp_params());
   for (const char* name : {"opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"}) wr(o, dens.stat(name));
-  std::printf("trainer_test --mapper ok rank %d/%d A %d -> %d capacity %d steps %d/%d\n", rank, world, A, (int)m.A, (int)m.capacity,
-              (int)step.steps_taken(), (int)step.anchor_steps_taken());
+  std::printf("trainer_test --mapper ok rank %d/%d A %d -> %d capacity %d steps %d/%d redone %d\n", rank, world, A, (int)m.A, (int)m.capacity,
+              (int)step.steps_taken(), (int)step.anchor_steps_taken(), (int)step.redone_steps());
   return 0;
 }
 

@@ -235,21 +235,46 @@ class TrainerStep:
     def training_once(self, keyframes, gt_images) -> torch.Tensor:
         """Nothing here waits for the device: a pass whose instance count outgrew some rank's resident capacity is dropped by
         every rank on the device (the optimizer is guarded by the all-reduced overflow word and its step count lives there);
-        the rank concerned re-sizes its scratch at its next forward.  With one rank the dropped iteration is then run again
-        before the next one (`redo_dropped_steps`), so no optimizer step of the reference's sequence is lost."""
-        # One rank: an iteration the device dropped is run again -- same keyframe, same iteration number -- as soon as the host
-        # resolves that forward's status word, which is before the next iteration is queued (ScaffoldTrainerStep.training_once).
-        eng = getattr(self, "engine", None)
-        prev = getattr(self, "_last_iteration", None)
-        if (prev is not None and getattr(self, "redo_dropped_steps", True) and self.world == 1 and not getattr(self, "use_graph", False)
-                and eng is not None and eng.resident and not eng.check(raise_on_overflow=False)):
-            self._last_iteration = None
-            self.redone_steps = getattr(self, "redone_steps", 0) + 1
-            self._iteration_body(*prev)
+        the rank concerned re-sizes its scratch at its next forward.  The dropped iteration is then run again by every rank before
+        the next one (`redo_dropped_steps`), so no optimizer step of the reference's sequence is lost
+        (src/gaussian_mapper.cpp:1027-1030 never skips one).  CONTRACT: the keyframe's and the target's tensors of a call must
+        stay unchanged until the next call (or finish()) has returned -- a redo trains on them again."""
+        # An iteration the device dropped is run again -- same keyframe, same iteration number -- as soon as the host resolves that
+        # step's overflow word, which is before the next iteration is queued (ScaffoldTrainerStep.training_once).  One rank: the
+        # engine's own status word.  N > 1: the SUMMED word every rank mirrored to its host after the gradient exchange
+        # (BucketExchange.mirror_flag), so all ranks redo the same iteration together and replicas stay bit-identical.
+        self._redo_if_dropped()
         self.iteration += 1
         k = self.keyframe_for(self.iteration - 1, len(keyframes))
         self._last_iteration = (keyframes[k], gt_images[k], self.iteration)
         return self._iteration_body(keyframes[k], gt_images[k], self.iteration)
+
+    def _redo_if_dropped(self):
+        prev = getattr(self, "_last_iteration", None)
+        if prev is None or not getattr(self, "redo_dropped_steps", True) or getattr(self, "use_graph", False):
+            return
+        eng = getattr(self, "engine", None)
+        for _ in range(4):
+            if self.world == 1:
+                dropped = eng is not None and eng.resident and not eng.check(raise_on_overflow=False)
+            else:
+                dropped = bool(self.exchange.step_dropped())
+                if eng is not None and eng.resident:
+                    eng.check(raise_on_overflow=False)      # the rank that overflowed re-calibrates in its next forward
+            if not dropped:
+                break
+            self.redone_steps = getattr(self, "redone_steps", 0) + 1
+            self._iteration_body(*prev)
+            if self.world == 1:
+                break                                       # (a re-calibrating forward cannot overflow)
+        else:
+            raise RuntimeError("an iteration kept being dropped by the device")
+        self._last_iteration = None
+
+    def finish(self):
+        """Resolve the LAST iteration's status word and run that iteration again if the device dropped it (training_once only
+        learns of a drop at the next call).  Call once after the last training_once of a run."""
+        self._redo_if_dropped()
 
     def _iteration_body(self, keyframe, gt, it: int) -> torch.Tensor:
         lrs = self.learning_rates(it)
@@ -266,6 +291,8 @@ class TrainerStep:
             ex.reduce_flag_async(None)
         flag = ex.wait_flag()
         ex.reduce_gradients(self.grads_flat)  # sum over the keyframes of this step
+        if ex.active and getattr(self, "redo_dropped_steps", True):
+            ex.mirror_flag()
         self.optimizer.step(self.params_flat, self.grads_flat, lrs, self.P, 1.0 / self.world, exchange=ex, guard=flag)
         ex.gather(self.params_flat)
         return loss

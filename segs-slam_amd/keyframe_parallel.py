@@ -88,10 +88,13 @@ class BucketExchange:
 
     # ---- ranges
     def shard_range(self, rank: Optional[int] = None) -> Tuple[int, int]:
-        """[lo, hi) of the bucket this rank updates, in whole-bucket coordinates (the whole bucket, the part in front of the
-        exchanged range included, when not sharded)."""
+        """[lo, hi) of the bucket this rank updates, in whole-bucket coordinates.  Not sharded: the whole bucket with one rank
+        (the part in front of the exchanged range included: the optimizer then keeps that group's moments exactly as the
+        reference's does); with an ACTIVE exchange only the exchanged range -- the frozen segment in front of it holds this rank's
+        own, un-summed gradient, and an optimizer pass over it would let its moments differ from rank to rank (its parameters
+        never move either way: the segment is frozen because its learning rate is 0)."""
         if not self.sharded:
-            return 0, self.offset + self.n
+            return (self.offset if self.active else 0), self.offset + self.n
         r = self.rank if rank is None else rank
         lo = min(r * self.shard_len, self.n)
         return self.offset + lo, self.offset + min(lo + self.shard_len, self.n)
@@ -160,6 +163,34 @@ class BucketExchange:
         w = self.wait_flag()
         return int(w.view(torch.int32).item()) if w.dtype == torch.float32 else int(w.item())
 
+    # ---- the summed word on the host, one step late (so that NO iteration is lost with N > 1 ranks either)
+    def mirror_flag(self):
+        """Queue a copy of the SUMMED overflow word into pinned host memory and an event behind it.  Call when the word is final
+        for work enqueued now: after reduce_gradients() (the word may ride in the gradient all-reduce).  Every rank mirrors the
+        same word, so every rank takes the same decision in step_dropped() -- no further collective."""
+        w = self.wait_flag()
+        if self.device.type != "cuda":
+            self._mirror = ("value", int(w.view(torch.int32).reshape(-1)[0]) if w.dtype == torch.float32 else int(w.reshape(-1)[0]))
+            return
+        if getattr(self, "_mirror_host", None) is None:
+            self._mirror_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._mirror_event = torch.cuda.Event()
+        self._mirror_host.copy_(w.view(torch.int32).reshape(1), non_blocking=True)   # (a float 1.0, 2.0 ... is a non-zero bit pattern)
+        self._mirror_event.record()
+        self._mirror = ("event", None)
+
+    def step_dropped(self):
+        """True / False: the device dropped / took the last mirrored step (waits for that step's exchange, not for its optimizer);
+        None when nothing was mirrored since the last call."""
+        m = getattr(self, "_mirror", None)
+        self._mirror = None
+        if m is None:
+            return None
+        if m[0] == "value":
+            return m[1] != 0
+        self._mirror_event.synchronize()
+        return int(self._mirror_host[0]) != 0
+
     def _timed(self, label: str, nbytes: int, fn):
         if self.timing is None or self.device.type != "cuda":
             return fn()
@@ -180,6 +211,7 @@ class BucketExchange:
         if not self.active:
             return
         if self.offset:
+            grads[:self.offset].zero_()      # nobody reads the frozen segment's gradient (shard_range): it must not pile up
             grads = grads[self.offset:]
         if self._piggy:
             assert grads.data_ptr() == self._ext.data_ptr(), "the exchange was built for another gradient bucket"

@@ -93,7 +93,7 @@ def load_mapper_config(path: str, duplicates: str = "first") -> MapperConfig:
 
 def mapper_config_from_values(raw: Dict[str, Scalar], path: str = "<values>") -> MapperConfig:
     """The typed configuration from a flat key -> value mapping: what read_opencv_yaml returns, or a committed extract of a
-    reference configuration file (tests/golden/mapper_cfgs.json) where the reference tree itself is absent (the GPU box)."""
+    reference configuration file (segs-slam_amd/data/mapper_cfgs.json) where the reference tree itself is absent (the GPU box)."""
     raw = dict(raw)
 
     def num(key, cast):
@@ -133,14 +133,13 @@ def mapper_config_from_values(raw: Dict[str, Scalar], path: str = "<values>") ->
 
 def load_committed_config(rel_path: str) -> MapperConfig:
     """A reference configuration by its path inside the reference tree (e.g. "cfg/gaussian_mapper/RGB-D/Replica/office0.yaml"),
-    from the committed value extract tests/golden/mapper_cfgs.json (made by tests/golden/make_cfg_golden.py)."""
+    from the committed value extract segs-slam_amd/data/mapper_cfgs.json (made by tests/golden/make_cfg_golden.py)."""
     import json
     import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "tests", "golden", "mapper_cfgs.json")) as f:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "mapper_cfgs.json")) as f:
         table = json.load(f)
     if rel_path not in table:
-        raise KeyError(f"{rel_path} is not in tests/golden/mapper_cfgs.json (has: {sorted(table)})")
+        raise KeyError(f"{rel_path} is not in segs-slam_amd/data/mapper_cfgs.json (has: {sorted(table)})")
     return mapper_config_from_values(table[rel_path], rel_path)
 
 

@@ -413,6 +413,9 @@ class ScaffoldTrainerStep:
         self.freq_reg = dict(lambda_high=lambda_high, lambda_low=lambda_low, scales=tuple(scales), start=start, until=until,
                              multi=multi_resolution, fused=bool(fused))
         self._freq_fused = {}
+        # a captured iteration holds the old plan's scratch and target-table addresses, which die with the old object
+        self._graphs.clear()
+        self._graph_stage.clear()
 
     def _freq_active(self):
         """(low term on, high term on) at this iteration: the two conditions of src/gaussian_mapper.cpp:932-944."""
@@ -608,18 +611,19 @@ class ScaffoldTrainerStep:
         step counts live on the device and do not advance -- and the rank that overflowed re-sizes its scratch at its next
         forward.  The loss returned for such an iteration comes from an invalid image.
 
-        With one rank and eager launches (`redo_dropped_steps`, on by default; not under `enable_graph`, whose replay loop polls
-        the status word instead of waiting for it) a dropped iteration is not lost: the host learns of it when it
-        resolves that forward's status word, which is before anything of the next iteration is queued, and runs the same
-        keyframe with the same iteration number again right there -- its forward re-calibrates, so it cannot overflow -- before
-        the next one.  Parameters, moments and step counts are what the dropped pass found, so the optimizer takes every step
-        the reference takes (src/gaussian_mapper.cpp:823-1032 never skips one), in the same order."""
-        prev = self._last_iteration
-        if (prev is not None and self.redo_dropped_steps and self.world == 1 and not self.use_graph and self.engine.resident
-                and not self.engine.check(raise_on_overflow=False)):
-            self._last_iteration = None
-            self.redone_steps += 1
-            self._iteration_body(*prev)
+        With eager launches (`redo_dropped_steps`, on by default; not under `enable_graph`, whose replay loop polls the status
+        word instead of waiting for it) a dropped iteration is not lost: the host learns of it when it resolves that step's
+        overflow word -- one rank: the engine's own status word, i.e. before anything of the next iteration is queued; N > 1
+        ranks: the SUMMED word, which every rank mirrored into pinned host memory right after the gradient exchange
+        (BucketExchange.mirror_flag), so every rank takes the same decision without another collective -- and runs the same
+        keyframe with the same iteration number again right there, on every rank (the forward of the rank that overflowed
+        re-calibrates).  Parameters, moments, statistics and step counts are what the dropped pass found, so the optimizer takes
+        every step the reference takes (src/gaussian_mapper.cpp:823-1032 never skips one), in the same order, and replicas stay
+        bit-identical.
+
+        CONTRACT: the keyframe's and the target's tensors handed to a call must stay unchanged until the next call (or
+        finish()) has returned -- a redo trains on them again (refresh staging buffers only after that)."""
+        self._redo_if_dropped()
         self.iteration += 1
         if self.keyframe_selector is not None:
             # useOneRandomSlidingWindowKeyframe (src/gaussian_mapper.cpp:827): one draw per rank, identical on every rank
@@ -628,6 +632,35 @@ class ScaffoldTrainerStep:
             k = self.keyframe_for(self.iteration - 1, len(keyframes))
         self._last_iteration = (keyframes[k], gt_images[k], self.iteration)
         return self._iteration_body(keyframes[k], gt_images[k], self.iteration)
+
+    def _redo_if_dropped(self):
+        prev = self._last_iteration
+        if prev is None or not self.redo_dropped_steps or self.use_graph or not self.engine.resident:
+            return
+        for _ in range(4):
+            if self.world == 1:
+                dropped = not self.engine.check(raise_on_overflow=False)
+            else:
+                dropped = bool(self._exchange().step_dropped())
+                self.engine.check(raise_on_overflow=False)       # the rank that overflowed re-calibrates in its next forward
+            if not dropped:
+                break
+            self.redone_steps += 1
+            self._iteration_body(*prev)
+            if self.world == 1:
+                break                                            # (a re-calibrating forward cannot overflow)
+        else:
+            raise RuntimeError("an iteration kept being dropped by the device")
+        self._last_iteration = None
+
+    def finish(self):
+        """Resolve the LAST iteration's overflow word and run that iteration again if the device dropped it (training_once only
+        learns of a drop at the next call).  Call once after the last training_once of a run, before reporting."""
+        self._redo_if_dropped()
+
+    def lost_steps(self) -> int:
+        """Iterations the device dropped and nobody ran again (0 with redo_dropped_steps after finish(); synchronises)."""
+        return self.dropped_steps() - self.redone_steps
 
     def _iteration_body(self, kf: Keyframe, gt: torch.Tensor, it: int) -> torch.Tensor:
         """Iteration `it` on keyframe `kf` (training_once; also the re-run of an iteration the device dropped)."""
@@ -658,6 +691,8 @@ class ScaffoldTrainerStep:
         # A densification may re-size the bucket (reserve() moves the MLP block), so the shard partition the optimizer clips
         # to below is not the one a reduce-scatter would have summed for: every element gets the full sum on those steps.
         ex.reduce_gradients(self.model.grads, dense=adjust_now)
+        if ex.active and self.redo_dropped_steps and not adjust_now:
+            ex.mirror_flag()              # (an adjust_anchor iteration has resolved its word above)
         adjusted = False
         if in_stat_window:
             d.training_statis(self.neural, self.visible_radii, self.engine.radii, self.engine.dL_dmean2D, guard,

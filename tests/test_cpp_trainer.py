@@ -229,6 +229,34 @@ def test_two_cpp_ranks_keep_bit_identical_replicas_through_adjust_anchor(tmp_pat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["dense", "sharded"])
+def test_two_cpp_ranks_run_an_iteration_again_when_one_of_them_overflowed(tmp_path, mode):
+    """Rank 1's forward overflows its resident capacity at loop index 5 (rank 0's does not): both devices drop that pass (the
+    summed overflow word guards statistics and optimizer), both hosts read the summed word from their pinned mirror at the top
+    of the next trainingOnce and run iteration 6 again together.  No optimizer step is lost (the reference never skips an
+    iteration, src/gaussian_mapper.cpp:1027-1030) and the replicas stay bit-identical, through the adjust_anchor that follows."""
+    c = _mapper_case(tmp_path)
+    exe = os.path.join(TB, "trainer_test")
+    store = tmp_path / f"store_redo_{mode}"
+    env = dict(os.environ, SEGS_TRAINER_TEST_OVERFLOW_AT="5", SEGS_TRAINER_TEST_OVERFLOW_RANK="1")
+    procs = []
+    for r in range(2):
+        cmd = [exe, "--mapper", str(c["fin"]), str(tmp_path / f"redo_{mode}_{r}.bin"), "--world", "2", "--rank", str(r), "--store", str(store)]
+        if mode == "dense":
+            cmd.append("--dense")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert all(o.strip().endswith("redone 1") for o in outs), outs            # BOTH ranks ran it again, once
+    r0, r1 = (_read_mapper_out(tmp_path / f"redo_{mode}_{r}.bin", c["n_steps"], c["dims"]) for r in range(2))
+    assert r0["steps"] == r1["steps"] == (c["n_steps"], c["n_steps"] - 1)     # every optimizer step of the sequence was taken
+    assert r0["A"] == r1["A"] != c["A"] and list(r0["sizes"]) == list(r1["sizes"])
+    for k in ("anchor", "offset", "anchor_feat", "scaling", "mlp", "opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert 10.0 < r0["anchor_demon"].max() <= 2.0 * (c["n_steps"] - 2)         # the dropped pass left no statistics behind
+
+
+@pytest.mark.gpu
 def test_cpp_exchange_through_a_one_rank_rccl_group(tmp_path):
     """The same loop with a ONE-rank c10d::ProcessGroupNCCL constructed in C++ and every collective forced: the overflow word's
     all-reduce, reduce_scatter -> Adam on the shard -> all_gather (and the dense all-reduce of the adjust_anchor iteration)

@@ -257,3 +257,101 @@ def test_overflow_word_rides_in_the_dense_gradient_all_reduce(tmp_path):
         # second loop value: rank 1 raised its word -> both ranks must have seen the sum 1
         a, b = (float(np.load(tmp_path / f"flag_{r}_{allow}_{1 if r == 1 else 0}.npy")[0]) for r in range(2))
         assert (a, b) == (1.0, 1.0), (allow, a, b)
+
+
+def _redo_worker(rank, world, port, out_dir, sharded, overflow_at):
+    """Three iterations of the two-rank step; at iteration `overflow_at` (1-based; 0 = never) RANK 1 ALONE raises its overflow word
+    on the first attempt.  Both ranks must drop that pass on the device, learn of it from the mirrored SUMMED word at the top of
+    the next call, run the iteration again together, and end with the parameters of the run in which nothing overflowed."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from segs_slam_amd.gaussian_trainer import OptimizationParams, TorchAdam, TrainerStep
+    sc, cams, gts = _make()
+    flat = _params(sc)
+    grads_store = torch.zeros(flat.numel() + 4)          # (a spare element behind the bucket: the dense exchange carries the word there)
+    grads = grads_store[:flat.numel()]
+    opt = OptimizationParams()
+    inner = _oracle_backend(sc, grads, sc.P)
+    attempts = {}
+
+    def backend(params, keyframe, dL_fn, after_forward=None):
+        it = step.iteration
+        attempts[it] = attempts.get(it, 0) + 1
+        raised = rank == 1 and it == overflow_at and attempts[it] == 1
+        after_forward(torch.tensor([1 if raised else 0], dtype=torch.int32))
+        return inner(params, keyframe, dL_fn)
+
+    adam = TorchAdam(flat.numel(), "cpu", opt)
+    step = TrainerStep(flat, sc.P, backend, adam, opt, grads, sharded_optimizer=sharded)
+    for _ in range(3):
+        step.training_once(cams, gts)
+    step.finish()                                         # (a drop of the LAST iteration is only seen here)
+    np.save(os.path.join(out_dir, f"redo_params_{rank}_{overflow_at}.npy"), flat.numpy())
+    np.save(os.path.join(out_dir, f"redo_counts_{rank}_{overflow_at}.npy"),
+            np.array([adam.step_count, getattr(step, "redone_steps", 0), sum(attempts.values())]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded", [False, True], ids=["dense_allreduce", "reduce_scatter_sharded_adam_allgather"])
+def test_iteration_dropped_because_one_rank_overflowed_is_run_again_by_both(tmp_path, sharded):
+    """N > 1 ranks lose no optimizer step either (the reference never skips an iteration, src/gaussian_mapper.cpp:1027-1030): an
+    overflow on ONE rank -- in the middle of the run, and at its very last iteration -- makes both ranks redo that iteration;
+    replicas stay bit-identical and equal the run without any overflow."""
+    base = 29500 + (os.getpid() % 2000) + (31 if sharded else 23)
+    for i, at in enumerate((0, 2, 3)):
+        mp.spawn(_redo_worker, args=(2, base + i, str(tmp_path), sharded, at), nprocs=2, join=True)
+    clean = np.load(tmp_path / "redo_params_0_0.npy")
+    for at in (0, 2, 3):
+        p0, p1 = np.load(tmp_path / f"redo_params_0_{at}.npy"), np.load(tmp_path / f"redo_params_1_{at}.npy")
+        assert np.array_equal(p0, p1), ("replicas diverged", at)
+        assert np.array_equal(p0, clean), ("a step was lost or taken twice", at)
+        for r in range(2):
+            steps, redone, attempts = np.load(tmp_path / f"redo_counts_{r}_{at}.npy")
+            assert steps == 3 and redone == (1 if at else 0) and attempts == (4 if at else 3), (at, r, steps, redone, attempts)
+
+
+def _frozen_worker(rank, world, port, out_dir, sharded):
+    """A frozen segment in front of the exchanged range (anchor positions under position_lr = 0): it never crosses a link, and no
+    rank's optimizer may touch it -- its gradient is this rank's own, so moments formed from it would differ between replicas."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segs_slam_amd.keyframe_parallel import BucketExchange
+    off, n = 12, 1001
+    store = torch.zeros(off + n + 4)
+    grads = store[:off + n]
+    ex = BucketExchange(n, "cpu", None, sharded=sharded, grads=grads, offset=off)
+    assert ex.active and ex.sharded == sharded
+    grads.copy_(torch.arange(off + n, dtype=torch.float32) * (rank + 1) + 1.0)
+    ex.reduce_flag_async(None)
+    ex.wait_flag()
+    ex.reduce_gradients(grads)
+    lo, hi = ex.shard_range()
+    assert lo >= off and hi <= off + n, (lo, hi)
+    clipped = ex.clip_segments([(0, off, 0.0), (off, n, 1e-3)])        # the anchor group and everything else
+    assert all(a >= off for a, _, _ in clipped) and sum(c for _, c, _ in clipped) == hi - lo, clipped
+    assert float(grads[:off].abs().max()) == 0.0                       # un-summed, unread: cleared
+    want = torch.arange(off + n, dtype=torch.float32) * 3.0 + 2.0
+    assert torch.equal(grads[lo:hi], want[lo:hi])
+    np.save(os.path.join(out_dir, f"frozen_{rank}.npy"), np.array([lo, hi]))
+    one = BucketExchange(n, "cpu", None, sharded=False, offset=off)   # (what a single process gets is checked in the parent)
+    assert one.active
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded", [False, True], ids=["dense_allreduce", "reduce_scatter_sharded_adam_allgather"])
+def test_frozen_segment_stays_out_of_exchange_and_optimizer_on_every_rank(tmp_path, sharded):
+    port = 29500 + (os.getpid() % 2000) + (43 if sharded else 41)
+    mp.spawn(_frozen_worker, args=(2, port, str(tmp_path), sharded), nprocs=2, join=True)
+    (lo0, hi0), (lo1, hi1) = np.load(tmp_path / "frozen_0.npy"), np.load(tmp_path / "frozen_1.npy")
+    if sharded:
+        assert lo0 == 12 and hi0 == lo1 and hi1 == 12 + 1001
+    else:
+        assert (lo0, hi0) == (lo1, hi1) == (12, 12 + 1001)
+    # one process, no group: the optimizer covers the whole bucket, frozen group included, like the reference's
+    from segs_slam_amd.keyframe_parallel import BucketExchange
+    assert BucketExchange(1001, "cpu", None, sharded=False, offset=12).shard_range() == (0, 1013)

@@ -180,3 +180,36 @@ def test_two_ranks_grow_and_prune_the_same_map(sharded):
         assert a.shape == b.shape and b.sum() > 0, n
         assert abs(a.sum() - b.sum()) <= 1e-3 * b.sum(), (n, a.sum(), b.sum())
         assert np.corrcoef(a, b)[0, 1] > 0.9999, (n, float(np.corrcoef(a, b)[0, 1]))
+
+
+def _redo_worker(rank, world, port, outdir, sharded):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    kfs, model, step, gts = _setup(dev, sharded)
+    for it in range(6):
+        if it == 3 and rank == 1:
+            assert step.engine.check() and step.engine.capacity > 0
+            step.engine.capacity = max(step.engine.R // 3, 1024)      # rank 1's next forward overflows; rank 0's does not
+        step.training_once([k for _, k in kfs], gts)
+    step.finish()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, f"redo_{rank}.npz"), params=model.params.cpu().numpy(), steps=step._mlp_count.value(),
+             dropped=step.dropped_steps(), redone=step.redone_steps, lost=step.lost_steps())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded", [False, True], ids=["dense_allreduce", "sharded_adam"])
+def test_an_overflow_on_one_rank_makes_both_ranks_run_the_iteration_again(sharded):
+    """With N > 1 ranks a dropped iteration is run again too (the reference never skips an optimizer step,
+    src/gaussian_mapper.cpp:1027-1030): rank 1 overflows its resident capacity at iteration 4, both devices drop the pass, both
+    hosts read the SUMMED word from their pinned mirror and redo iteration 4 together; replicas stay bit-identical and the Adam
+    step count equals the iteration count."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_redo_worker, args=(2, 29577 + int(sharded), d, sharded), nprocs=2, join=True)
+        r0, r1 = (dict(np.load(os.path.join(d, f"redo_{r}.npz"))) for r in range(2))
+    assert np.array_equal(r0["params"], r1["params"]), "replicas diverged"
+    for r in (r0, r1):
+        assert int(r["steps"]) == 6 and int(r["dropped"]) == 1 and int(r["redone"]) == 1 and int(r["lost"]) == 0, {k: r[k] for k in ("steps", "dropped", "redone", "lost")}
