@@ -83,6 +83,7 @@ class Config3Run:
                 if log:
                     log(f"it {it:5d} anchors {last_A:7d} -> {m.A:7d} capacity {m.capacity:7d} loss {float(loss):.4f}")
                 last_A = m.A
+        st.finish()        # a drop of the LAST iteration is only seen here (training_once resolves the previous call's word)
         torch.cuda.synchronize(self.device)
         wall = time.perf_counter() - t0
         return {"iterations": it, "seconds": wall, "iters_per_s": it / wall if wall > 0 else 0.0, "anchors_start": self.anchors_start,

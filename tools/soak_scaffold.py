@@ -53,5 +53,6 @@ for it in range(1, iters + 1):
         t_last = time.perf_counter()
         if stop_at and model.A >= stop_at:
             break
+step.finish()      # (a drop of the last iteration is only seen by the next call)
 assert torch.isfinite(model.params).all()
-print(f"soak ok (dropped {step.dropped_steps()} redone {step.redone_steps})")
+print(f"soak ok (dropped {step.dropped_steps()} redone {step.redone_steps} lost {step.lost_steps()})")
