@@ -683,15 +683,15 @@ def replica_step_block(dev, anchors: int = 50_000, steps: int = 50, warmup: int 
         tstep.keyframe_for = lambda step, n: 0
         # between two adjust_anchor iterations of the cfg's schedule (every 100 from 1 500): the timed steps hold none
         tstep.iteration = iteration
-        assert (iteration + warmup + steps) // cfg.densify.update_interval == iteration // cfg.densify.update_interval
+        # ONE state: the statistics run every iteration as the cfg says, but adjust_anchor (every 100 from 1 500) is held off for the
+        # whole block -- on the block's random target it would grow the map threefold during the plateau warm-up, and the figure
+        # would no longer be "the Replica step at `anchors` anchors"
+        if tstep.densifier is not None:
+            tstep.densifier.p.update_from = 10 ** 9
         for _ in range(warmup):
             tstep.training_once([kf], [gt])
         e_ips, e_ms, e_pc = _timed_steps(tstep, [kf], [gt], steps)          # rounds 3-4's window: a moving state
         plateau_iters, trail = _warm_to_plateau(tstep, [kf], [gt], max_iters=200)
-        # the plateau warm-up may have crossed adjust_anchor iterations of the cfg's schedule (every 100): the TIMED steps hold none
-        while (tstep.iteration + steps + 21) // cfg.densify.update_interval != tstep.iteration // cfg.densify.update_interval:
-            tstep.training_once([kf], [gt])
-            plateau_iters += 1
         ips, ms, pc = _timed_steps(tstep, [kf], [gt], steps)
         wall = steps / ips
         low_on, high_on = tstep._freq_active()

@@ -30,10 +30,13 @@
 #include <dlfcn.h>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <initializer_list>
+#include <vector>
 #include "../../include/segs_raster.h"
 #include "kernels.h"
 #include "../../include/segs_train.h"
+#include "real_fft.h"
 
 namespace {
 constexpr int MAXL = SEGS_FREQ_MAX_LEVELS;
@@ -199,9 +202,12 @@ __device__ __forceinline__ float2 rot90(float2 e, int q) {   // e * i^q
 }
 // index of full-spectrum entry (ky, kx) of an h x w transform in its stored half (columns 0 .. w/2); `mirrored` tells the
 // caller to conjugate (|.| tables ignore it)
-__device__ __forceinline__ size_t half_index(int c, int ky, int kx, int h, int w, bool& mirrored) {
+// `tiled` (the plan's own transforms, real_fft.h): the half spectrum is stored in tiles of rfft::TILE_COLS adjacent columns, each
+// tile one contiguous (h x TILE_COLS) block, so that the column pass streams whole tiles: [c][kx / T][ky][kx mod T]
+__device__ __forceinline__ size_t half_index(int c, int ky, int kx, int h, int w, bool& mirrored, bool tiled) {
   mirrored = kx > w / 2;
   if (mirrored) { ky = ky ? h - ky : 0; kx = w - kx; }
+  if (tiled) return rfft::tiled_index(c, ky, kx, h, w / 2 + 1);
   return ((size_t)c * h + ky) * (w / 2 + 1) + kx;
 }
 // Q = wl * sign(|y| - t) * y / |y|, and the loss term wl * | |y| - t |
@@ -221,13 +227,29 @@ __device__ __forceinline__ float2 coeff(float2 y, float t, float wl, float& term
 template <bool TARGET>
 __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const float2* __restrict__ X, float2* __restrict__ D,
                                                          float* __restrict__ T0, float* __restrict__ T1, float* __restrict__ T2,
-                                                         float w0, float w1, float w2, float* __restrict__ partial) {
+                                                         float w0, float w1, float w2, float* __restrict__ partial, bool tiled) {
   __shared__ float red[4];
   const int H4 = H / 4, W4 = W / 4;
   const unsigned idx = blockIdx.x * 256u + threadIdx.x;
   float term = 0.f;
-  if (idx < 3u * H4 * W4) {
-    const int kx2 = idx % W4, ky2 = (idx / W4) % H4, c = idx / ((unsigned)W4 * H4);
+  // Which quarter-size frequency this thread owns.  Row-major spectra: consecutive threads take consecutive kx2.  Tiled spectra
+  // (real_fft.h): a wave takes an 8 x 8 patch (kx2 low bits = lane & 7, ky2 low bits = lane >> 3), so that each of its accesses to
+  // X, T0 and D covers eight adjacent rows of one or two column tiles -- 512 contiguous bytes -- instead of eight 64-byte pieces
+  // 43 KB apart (21 us against 15 at 1200x680).
+  int kx2, ky2, c;
+  bool valid;
+  if (tiled) {
+    const unsigned nkx = ((unsigned)W4 + 7u) / 8u, nky = ((unsigned)H4 + 7u) / 8u;
+    const unsigned patch = idx >> 6, within = idx & 63u;
+    kx2 = (int)((patch % nkx) * 8u + (within & 7u));
+    ky2 = (int)(((patch / nkx) % nky) * 8u + (within >> 3));
+    c = (int)(patch / (nkx * nky));
+    valid = c < 3 && kx2 < W4 && ky2 < H4;
+  } else {
+    kx2 = idx % W4; ky2 = (idx / W4) % H4; c = idx / ((unsigned)W4 * H4);
+    valid = idx < 3u * H4 * W4;
+  }
+  if (valid) {
     // e^{2 pi i k/N} of the first alias per axis; the others differ by powers of i
     float2 ey, ex;
     sincospif(2.f * (float)ky2 / (float)H, &ey.y, &ey.x);
@@ -248,7 +270,7 @@ __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const floa
 #pragma unroll
       for (int b = 0; b < 4; b++) {
         bool mir;
-        const size_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir);
+        const size_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
         const float2 v = X[o];
         x[a][b] = mir ? make_float2(v.x, -v.y) : v;
       }
@@ -275,7 +297,7 @@ __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const floa
 #pragma unroll
         for (int b = 0; b < 3; b++)
           if (b < 2 || kx2 == 0) {
-            const size_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir);
+            const size_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
             T0[o] = sqrtf(x[a][b].x * x[a][b].x + x[a][b].y * x[a][b].y);
           }
 #pragma unroll
@@ -296,7 +318,7 @@ __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const floa
       for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-          const size_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir);
+          const size_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
           float2 d = coeff(x[a][b], T0[o], w0, term);
           if (b < 2 || (b == 2 && kx2 == 0)) {      // the stored half: columns 0 .. W/2
             const float2 t1 = cmulc(q1[a & 1][b & 1], cmul(cy2[a], cx2[b]));
@@ -370,6 +392,11 @@ struct segs_freq_plan {
   float* grad[MAXL] = {};              // inverse transforms
   float* partial = nullptr;
   char* arena = nullptr;
+  // folded plans whose sizes factor into {2, 3, 5, 17}: both full-size transforms by this library's own kernels (real_fft.h)
+  bool own_fft = false;
+  rfft::Stages st_rows{}, st_cols{};
+  float2* root_w = nullptr;            // e^{-2 pi i n / W}, n < W
+  float2* root_h = nullptr;            // e^{-2 pi i n / H}, n < H
 };
 
 extern "C" {
@@ -473,7 +500,6 @@ int segs_freq_plan_create(int H, int W, int nscales, const float* scales, float 
   if (!out || H <= 0 || W <= 0 || nscales <= 0 || nscales > MAXL || !scales) return bad("segs_freq_plan_create: invalid argument");
   *out = nullptr;
   const HipFft& f = hipfft();
-  if (!f.ok) return segs::set_error(SEGS_ERR_UNSUPPORTED, "segs_freq_plan_create: libhipfft.so.0 could not be loaded (no FFT library in this process)");
   segs_freq_plan* p = new segs_freq_plan();
   p->H = H; p->W = W; p->n = nscales;
   size_t toff = 0;
@@ -485,9 +511,19 @@ int segs_freq_plan_create(int H, int W, int nscales, const float* scales, float 
     p->weight[l] = lambda_high * scales[l] / (3.f * (float)p->h[l] * (float)p->w[l]);   // loss_utils.h:235: scale * mean(...)
   }
   p->folded = nscales == 3 && scales[0] == 1.f && scales[1] == 0.5f && scales[2] == 0.25f && H % 4 == 0 && W % 4 == 0;
+  // SEGS_FREQ_HIPFFT=1: keep the library transforms (A/B measurements, and the fallback's tests)
+  static const bool force_library = [] { const char* e = getenv("SEGS_FREQ_HIPFFT"); return e && e[0] == '1'; }();
+  p->own_fft = p->folded && !force_library && rfft::factorize(W / 2, p->st_rows) && rfft::factorize(H, p->st_cols) &&
+               rfft::rows_lds_bytes(W) <= 160 * 1024 && rfft::cols_lds_bytes(H) <= 160 * 1024;
+  if (!p->own_fft && !f.ok) {
+    delete p;
+    return segs::set_error(SEGS_ERR_UNSUPPORTED, "segs_freq_plan_create: libhipfft.so.0 could not be loaded (no FFT library in this process)");
+  }
+  // columns STORED per row of the full-size half spectrum: W/2 + 1, rounded up to whole tiles under the plan's own transforms
+  const size_t wc0 = p->own_fft ? (size_t)rfft::tiles_of(W / 2 + 1) * rfft::TILE_COLS : (size_t)(W / 2 + 1);
   for (int l = 0; l < nscales; l++) {     // target tables: half spectra; a folded plan keeps levels 1, 2 as full spectra
     p->toff[l] = toff;
-    toff += (size_t)3 * p->h[l] * ((p->folded && l > 0) ? p->w[l] : p->w[l] / 2 + 1);
+    toff += (size_t)3 * p->h[l] * ((p->folded && l > 0) ? (size_t)p->w[l] : (l == 0 ? wc0 : (size_t)(p->w[l] / 2 + 1)));
   }
   p->toff[nscales] = toff;
   // scratch: one arena (256-byte aligned pieces)
@@ -495,7 +531,8 @@ int segs_freq_plan_create(int H, int W, int nscales, const float* scales, float 
   size_t bytes = 0, off_level[MAXL] = {}, off_spec[MAXL] = {}, off_grad[MAXL] = {};
   const int nfft = p->folded ? 1 : nscales;
   for (int l = 0; l < nscales; l++) {
-    const size_t real = al((size_t)3 * p->h[l] * p->w[l] * sizeof(float)), cplx = al((size_t)3 * p->h[l] * (p->w[l] / 2 + 1) * sizeof(float2));
+    const size_t real = al((size_t)3 * p->h[l] * p->w[l] * sizeof(float)),
+                 cplx = al((size_t)3 * p->h[l] * (l == 0 ? wc0 : (size_t)(p->w[l] / 2 + 1)) * sizeof(float2));
     if (p->folded) {
       if (l == 0) { off_spec[0] = bytes; bytes += cplx; off_spec[1] = bytes; bytes += cplx; off_grad[0] = bytes; bytes += real; }
     } else {
@@ -506,8 +543,28 @@ int segs_freq_plan_create(int H, int W, int nscales, const float* scales, float 
   }
   const size_t off_partial = bytes;
   bytes += al((toff / 256 + 2) * sizeof(float));
+  const size_t off_root_w = bytes;
+  bytes += al((size_t)W * sizeof(float2));
+  const size_t off_root_h = bytes;
+  bytes += al((size_t)H * sizeof(float2));
   if (hipMalloc(&p->arena, bytes) != hipSuccess) { delete p; return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "segs_freq_plan_create: out of device memory"); }
   p->partial = reinterpret_cast<float*>(p->arena + off_partial);
+  if (p->own_fft) {
+    p->root_w = reinterpret_cast<float2*>(p->arena + off_root_w);
+    p->root_h = reinterpret_cast<float2*>(p->arena + off_root_h);
+    std::vector<float2> tw((size_t)W), th((size_t)H);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int n = 0; n < W; n++) tw[n] = make_float2((float)std::cos(two_pi * n / W), (float)-std::sin(two_pi * n / W));
+    for (int n = 0; n < H; n++) th[n] = make_float2((float)std::cos(two_pi * n / H), (float)-std::sin(two_pi * n / H));
+    if (hipMemcpy(p->root_w, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->root_h, th.data(), th.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(rfft::rows_r2c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rfft::rows_lds_bytes(W)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(rfft::rows_c2r_add_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rfft::rows_lds_bytes(W)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(rfft::cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rfft::cols_lds_bytes(H)) != hipSuccess) {
+      segs_freq_plan_destroy(p);
+      return segs::set_error(SEGS_ERR_INVALID_ARGUMENT, "segs_freq_plan_create: could not set up the transform kernels");
+    }
+  }
   for (int l = 0; l < nscales; l++) {
     if (p->folded) {
       if (l < 2) p->spec[l] = reinterpret_cast<float*>(p->arena + off_spec[l]);
@@ -518,7 +575,7 @@ int segs_freq_plan_create(int H, int W, int nscales, const float* scales, float 
       p->grad[l] = reinterpret_cast<float*>(p->arena + off_grad[l]);
     }
   }
-  for (int l = 0; l < nfft; l++) {
+  for (int l = 0; l < (p->own_fft ? 0 : nfft); l++) {
     int n[2] = {p->h[l], p->w[l]};
     if (f.PlanMany(&p->r2c[l], 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_R2C, 3) != HIPFFT_SUCCESS ||
         f.PlanMany(&p->c2r[l], 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_C2R, 3) != HIPFFT_SUCCESS) {
@@ -541,6 +598,23 @@ int segs_freq_plan_levels(const segs_freq_plan* p, int* level_h, int* level_w, i
 size_t segs_freq_target_floats(const segs_freq_plan* p) { return p ? p->toff[p->n] : 0; }
 
 static int fft_fail(const char* what) { return segs::set_error(SEGS_ERR_UNSUPPORTED, what); }
+// threads of freq_fold_kernel: one per quarter-size frequency, in 8 x 8 patches (some of them partly empty) over tiled spectra
+static unsigned fold_threads(const segs_freq_plan* p) {
+  const unsigned h4 = p->H / 4, w4 = p->W / 4;
+  return p->own_fft ? 3u * ((w4 + 7u) / 8u) * ((h4 + 7u) / 8u) * 64u : 3u * h4 * w4;
+}
+
+// own transforms of a folded plan (real_fft.h): image (3,H,W) -> half spectrum (3,H,W/2+1), and the way back, added into dL
+static void own_forward(const segs_freq_plan* p, const float* image, float2* spec, hipStream_t st) {
+  const int rows = 3 * p->H, wc = p->W / 2 + 1;
+  rfft::rows_r2c_kernel<<<(rows + rfft::ROWS_PER_WG - 1) / rfft::ROWS_PER_WG, rfft::ROW_THREADS, rfft::rows_lds_bytes(p->W), st>>>(image, spec, rows, p->H, p->W, p->st_rows, p->root_w);
+  rfft::cols_kernel<<<dim3(rfft::tiles_of(wc), 3), rfft::COL_THREADS, rfft::cols_lds_bytes(p->H), st>>>(spec, p->H, wc, p->st_cols, p->root_h, -1.f, nullptr, 0, nullptr, nullptr);
+}
+static void own_inverse_add(const segs_freq_plan* p, float2* spec, float* dL, hipStream_t st, int npartial, float* freq_loss_out, float* loss_inout) {
+  const int rows = 3 * p->H, wc = p->W / 2 + 1;
+  rfft::cols_kernel<<<dim3(rfft::tiles_of(wc), 3), rfft::COL_THREADS, rfft::cols_lds_bytes(p->H), st>>>(spec, p->H, wc, p->st_cols, p->root_h, +1.f, p->partial, npartial, freq_loss_out, loss_inout);
+  rfft::rows_c2r_add_kernel<<<(rows + rfft::ROWS_PER_WG - 1) / rfft::ROWS_PER_WG, rfft::ROW_THREADS, rfft::rows_lds_bytes(p->W), st>>>(spec, dL, rows, p->H, p->W, p->st_rows, p->root_w);
+}
 
 // down-scaled copies of `image` for the generic path; returns the per-level source pointers in src[]
 static int plan_pyramid(segs_freq_plan* p, const float* image, const float* src[MAXL], hipStream_t st) {
@@ -554,13 +628,14 @@ int segs_freq_target(segs_freq_plan* p, const float* gt, float* target_out, void
   const HipFft& f = hipfft();
   hipStream_t st = (hipStream_t)stream;
   if (p->folded) {
-    if (f.SetStream(p->r2c[0], st) != HIPFFT_SUCCESS ||
+    if (p->own_fft) own_forward(p, gt, reinterpret_cast<float2*>(p->spec[0]), st);
+    else if (f.SetStream(p->r2c[0], st) != HIPFFT_SUCCESS ||
         f.ExecR2C(p->r2c[0], const_cast<float*>(gt), reinterpret_cast<hipfftComplex*>(p->spec[0])) != HIPFFT_SUCCESS)
       return fft_fail("segs_freq_target: hipfftExecR2C failed");
-    const unsigned nthr = 3u * (p->H / 4) * (p->W / 4);
+    const unsigned nthr = fold_threads(p);
     freq_fold_kernel<true><<<(nthr + 255) / 256, 256, 0, st>>>(p->H, p->W, reinterpret_cast<const float2*>(p->spec[0]), nullptr,
                                                                target_out + p->toff[0], target_out + p->toff[1], target_out + p->toff[2],
-                                                               0.f, 0.f, 0.f, nullptr);
+                                                               0.f, 0.f, 0.f, nullptr, p->own_fft);
   } else {
     const float* src[MAXL];
     if (int rc = plan_pyramid(p, gt, src, st)) return rc;
@@ -582,17 +657,25 @@ int segs_freq_loss(segs_freq_plan* p, const float* image, const float* target, f
   hipStream_t st = (hipStream_t)stream;
   const size_t npix = (size_t)3 * p->H * p->W;
   if (p->folded) {
+    if (p->own_fft) own_forward(p, image, reinterpret_cast<float2*>(p->spec[0]), st);
+    else {
     if (f.SetStream(p->r2c[0], st) != HIPFFT_SUCCESS || f.SetStream(p->c2r[0], st) != HIPFFT_SUCCESS) return fft_fail("segs_freq_loss: hipfftSetStream failed");
     if (f.ExecR2C(p->r2c[0], const_cast<float*>(image), reinterpret_cast<hipfftComplex*>(p->spec[0])) != HIPFFT_SUCCESS)
       return fft_fail("segs_freq_loss: hipfftExecR2C failed");
-    const unsigned nthr = 3u * (p->H / 4) * (p->W / 4), nblk = (nthr + 255) / 256;
+    }
+    const unsigned nthr = fold_threads(p), nblk = (nthr + 255) / 256;
     freq_fold_kernel<false><<<nblk, 256, 0, st>>>(p->H, p->W, reinterpret_cast<const float2*>(p->spec[0]), reinterpret_cast<float2*>(p->spec[1]),
                                                   const_cast<float*>(target + p->toff[0]), const_cast<float*>(target + p->toff[1]),
-                                                  const_cast<float*>(target + p->toff[2]), p->weight[0], p->weight[1], p->weight[2], p->partial);
-    freq_finish_kernel<<<1, 1024, 0, st>>>(p->partial, (int)nblk, freq_loss_out, loss_inout);
-    if (f.ExecC2R(p->c2r[0], reinterpret_cast<hipfftComplex*>(p->spec[1]), p->grad[0]) != HIPFFT_SUCCESS)
-      return fft_fail("segs_freq_loss: hipfftExecC2R failed");
-    add_kernel<<<(unsigned)((npix + 255) / 256), 256, 0, st>>>(dL_inout, p->grad[0], npix);
+                                                  const_cast<float*>(target + p->toff[2]), p->weight[0], p->weight[1], p->weight[2], p->partial, p->own_fft);
+    if (p->own_fft) {
+      // (the column pass folds the loss partials on its way, the row pass adds into dL/dimage itself)
+      own_inverse_add(p, reinterpret_cast<float2*>(p->spec[1]), dL_inout, st, (int)nblk, freq_loss_out, loss_inout);
+    } else {
+      freq_finish_kernel<<<1, 1024, 0, st>>>(p->partial, (int)nblk, freq_loss_out, loss_inout);
+      if (f.ExecC2R(p->c2r[0], reinterpret_cast<hipfftComplex*>(p->spec[1]), p->grad[0]) != HIPFFT_SUCCESS)
+        return fft_fail("segs_freq_loss: hipfftExecC2R failed");
+      add_kernel<<<(unsigned)((npix + 255) / 256), 256, 0, st>>>(dL_inout, p->grad[0], npix);
+    }
   } else {
     const float* src[MAXL];
     if (int rc = plan_pyramid(p, image, src, st)) return rc;
