@@ -204,11 +204,13 @@ __device__ __forceinline__ float2 rot90(float2 e, int q) {   // e * i^q
 // caller to conjugate (|.| tables ignore it)
 // `tiled` (the plan's own transforms, real_fft.h): the half spectrum is stored in tiles of rfft::TILE_COLS adjacent columns, each
 // tile one contiguous (h x TILE_COLS) block, so that the column pass streams whole tiles: [c][kx / T][ky][kx mod T]
-__device__ __forceinline__ size_t half_index(int c, int ky, int kx, int h, int w, bool& mirrored, bool tiled) {
+// (32-bit element offsets: one address register per access instead of two -- the fold kernel has sixteen of them in flight; a
+// plan's spectra stay far below 2^32 elements)
+__device__ __forceinline__ uint32_t half_index(int c, int ky, int kx, int h, int w, bool& mirrored, bool tiled) {
   mirrored = kx > w / 2;
   if (mirrored) { ky = ky ? h - ky : 0; kx = w - kx; }
-  if (tiled) return rfft::tiled_index(c, ky, kx, h, w / 2 + 1);
-  return ((size_t)c * h + ky) * (w / 2 + 1) + kx;
+  if (tiled) return (uint32_t)rfft::tiled_index(c, ky, kx, h, w / 2 + 1);
+  return ((uint32_t)c * h + ky) * (w / 2 + 1) + kx;
 }
 // Q = wl * sign(|y| - t) * y / |y|, and the loss term wl * | |y| - t |
 __device__ __forceinline__ float2 coeff(float2 y, float t, float wl, float& term) {
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const floa
 #pragma unroll
       for (int b = 0; b < 4; b++) {
         bool mir;
-        const size_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
+        const uint32_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
         const float2 v = X[o];
         x[a][b] = mir ? make_float2(v.x, -v.y) : v;
       }
@@ -297,7 +299,7 @@ __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const floa
 #pragma unroll
         for (int b = 0; b < 3; b++)
           if (b < 2 || kx2 == 0) {
-            const size_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
+            const uint32_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
             T0[o] = sqrtf(x[a][b].x * x[a][b].x + x[a][b].y * x[a][b].y);
           }
 #pragma unroll
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const floa
       for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-          const size_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
+          const uint32_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
           float2 d = coeff(x[a][b], T0[o], w0, term);
           if (b < 2 || (b == 2 && kx2 == 0)) {      // the stored half: columns 0 .. W/2
             const float2 t1 = cmulc(q1[a & 1][b & 1], cmul(cy2[a], cx2[b]));

@@ -39,7 +39,7 @@ __device__ __forceinline__ float2 muli(float2 a, float sgn) { return make_float2
 // 17 of its 21 us at 1200x680 with the transform compiled out); the row passes write / read 64-byte pieces instead.
 __host__ __device__ __forceinline__ int tiles_of(int Wc) { return (Wc + TILE_COLS - 1) / TILE_COLS; }
 __host__ __device__ __forceinline__ size_t tiled_index(int c, int ky, int kx, int H, int Wc) {
-  return (((size_t)c * tiles_of(Wc) + (kx / TILE_COLS)) * H + ky) * TILE_COLS + (kx % TILE_COLS);
+  return (size_t)(((uint32_t)c * tiles_of(Wc) + (uint32_t)(kx / TILE_COLS)) * H + ky) * TILE_COLS + (uint32_t)(kx % TILE_COLS);
 }
 
 template <int R> struct Roots;
@@ -183,7 +183,11 @@ __global__ void __launch_bounds__(ROW_THREADS) rows_r2c_kernel(const float* __re
     a[(size_t)r * pitch + n] = reinterpret_cast<const float2*>(img + (size_t)(row0 + r) * W)[n];
   }
   __syncthreads();
+#if defined(SEGS_MEASURE) && defined(RFFT_ABLATE_NO_ROW_TRANSFORM)   // measurement only
+  const float2* Z = a;
+#else
   const float2* Z = transform(a, b, M, st, nrows, pitch, rootM, -1.f);
+#endif
   // X[k] = E + e^{-2 pi i k / W} O,  E = (Z[k] + conj Z[M-k]) / 2,  O = (Z[k] - conj Z[M-k]) / (2 i),  k = 0 .. M  (Z[M] = Z[0])
   for (int i = threadIdx.x; i < nrows * (M + 1); i += ROW_THREADS) {
     const int r = fdiv(i, inv_M1), k = i - r * (M + 1);
@@ -229,7 +233,11 @@ __global__ void __launch_bounds__(ROW_THREADS) rows_c2r_add_kernel(const float2*
     a[(size_t)r * pitch + k] = make_float2(e.x - o.y, e.y + o.x);
   }
   __syncthreads();
+#if defined(SEGS_MEASURE) && defined(RFFT_ABLATE_NO_ROW_TRANSFORM)
+  const float2* z = a;
+#else
   const float2* z = transform(a, b, M, st, nrows, pitch, rootM, +1.f);
+#endif
   for (int i = threadIdx.x; i < nrows * M; i += ROW_THREADS) {
     const int r = fdiv(i, inv_M), n = i - r * M;
     float2* out = reinterpret_cast<float2*>(dst_img + (size_t)(row0 + r) * W) + n;

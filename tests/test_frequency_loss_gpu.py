@@ -192,3 +192,50 @@ def test_replica_mapper_step_with_fused_frequency_regulariser_matches_the_mirror
         # and the regulariser is really in there: without it the loss is smaller
         step, kf, gt = _step_pair(True, 3_000, dev)
         assert float(step._forward_backward(kf, gt)) < la - 1e-4
+
+
+_LIBRARY_ARM = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from segs_slam_amd.frequency_loss import FusedFrequencyLoss
+from tests.test_frequency_loss_gpu import _images
+H, W = int(sys.argv[2]), int(sys.argv[3])
+dev = torch.device("cuda:0")
+img, gt = _images(H, W, dev, 5)
+fl = FusedFrequencyLoss(H, W, dev, lambda_high=0.01)
+assert fl.folded
+dL = torch.zeros_like(img)
+val = float(fl(img, gt, dL))
+torch.cuda.synchronize()
+np.savez(sys.argv[4], val=val, dL=dL.cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("size", [(680, 1200), (480, 640)])
+def test_own_transforms_and_the_vendor_library_fallback_agree(size, tmp_path):
+    """The plan's own real transforms (csrc/real_fft.h; the default for sizes whose factors are in {2, 3, 5, 17}) against the same
+    plan on the vendor FFT library (SEGS_FREQ_HIPFFT=1, read once per process: a child process): two float32 routes to the same
+    numbers, held to the rule of test_folded_and_per_scale_plans_agree -- value 2e-6 relative, gradient within the sign flips'
+    budget (L2 distance 5e-3)."""
+    import os
+    import subprocess
+    import sys
+    from segs_slam_amd.frequency_loss import FusedFrequencyLoss
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    H, W = size
+    out = tmp_path / "library.npz"
+    env = dict(os.environ, SEGS_FREQ_HIPFFT="1")
+    subprocess.check_call([sys.executable, "-c", _LIBRARY_ARM, root, str(H), str(W), str(out)], env=env)
+    lib = np.load(out)
+    dev = torch.device("cuda:0")
+    img, gt = _images(H, W, dev, 5)
+    fl = FusedFrequencyLoss(H, W, dev, lambda_high=0.01)
+    da = torch.zeros_like(img)
+    va = float(fl(img, gt, da))
+    assert abs(va - float(lib["val"])) <= 2e-6 * float(lib["val"])
+    db = torch.from_numpy(lib["dL"]).to(dev)
+    rel = float((da - db).norm() / db.norm())
+    assert rel < 5e-3, rel
+    # the plan adds into dL/dimage: a second call on the same buffer doubles it (the inverse row pass accumulates)
+    fl(img, gt, da)
+    assert float((da - 2 * db).norm() / db.norm()) < 1e-2
