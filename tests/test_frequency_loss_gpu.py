@@ -239,3 +239,32 @@ def test_own_transforms_and_the_vendor_library_fallback_agree(size, tmp_path):
     # the plan adds into dL/dimage: a second call on the same buffer doubles it (the inverse row pass accumulates)
     fl(img, gt, da)
     assert float((da - 2 * db).norm() / db.norm()) < 1e-2
+
+
+@pytest.mark.parametrize("size", [(680, 1200), (480, 640), (1080, 1920), (240, 320), (136, 272)])
+def test_own_forward_transform_against_a_float64_fft(size):
+    """csrc/real_fft.h's forward pass alone (row pass: W reals as W/2 complex + split; column pass over tile-major storage), read
+    back through the plan's target table |X| (segs_freq_target: the first table of the block, stored like the spectrum in tiles of 8
+    columns, [c][kx // 8][ky][kx % 8]) against |torch.fft.rfft2| in float64.  Sizes: the three shipped ones, a small one, and one
+    whose height has the radix-17 factor twice over (136 = 8.17, 272 / 2 = 8.17).
+    Bar: a float32 Cooley-Tukey transform of N points errs by about eps log2(N) ||x||_2 per coefficient when no coefficient
+    dominates (||x||_2 is the size of a typical coefficient, Parseval) -- 1.2e-6 ||x||_2 at these N; the input is zero-mean noise
+    (an image's DC term, hundreds of times ||x||_2, would leave its own rounding, eps |DC|, on the coefficients that share its
+    butterflies) and every coefficient must be inside 1e-5 ||x||_2 + 1e-5 |X|."""
+    from segs_slam_amd.frequency_loss import FusedFrequencyLoss
+    dev = torch.device("cuda:0")
+    H, W = size
+    g = torch.Generator().manual_seed(H * 7 + W)
+    gt = (torch.rand(3, H, W, generator=g) - 0.5).to(dev).contiguous()
+    fl = FusedFrequencyLoss(H, W, dev, lambda_high=0.01)
+    assert fl.folded
+    block = fl.target_block(gt)
+    torch.cuda.synchronize()
+    wc = W // 2 + 1
+    ntiles = (wc + 7) // 8
+    t0 = block[:3 * ntiles * H * 8].view(3, ntiles, H, 8).permute(0, 2, 1, 3).reshape(3, H, ntiles * 8)[:, :, :wc].double()
+    ref = torch.fft.rfft2(gt.double()).abs()
+    norm = float(gt.double().norm() / 3 ** 0.5)          # per channel, on average
+    err = (t0 - ref).abs()
+    assert bool((err <= 1e-5 * norm + 1e-5 * ref).all()), (float(err.max()), norm)
+    assert float(err.max()) > 0                            # (it IS a float32 transform, not the reference looked up)
