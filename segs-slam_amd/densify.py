@@ -133,6 +133,8 @@ class AnchorDensifier:
         self._append(anchor, torch.zeros((n_new, m.dims.feat_dim), dtype=torch.float32, device=m.device), 0.0, scaling)
         self._stats["offset_denom"][A0 * no:m.A * no] = 0
         self._stats["offset_gradient_accum"][A0 * no:m.A * no] = 0
+        if getattr(m, "coarse", None) is not None:        # :517-518: increasePcd -> increasePcdCoarse on the same points
+            m.coarse.increase_pcd(points)
         return n_new
 
     def anchor_growing(self, grads: torch.Tensor, threshold: float, offset_mask: torch.Tensor, rands: List[torch.Tensor]):

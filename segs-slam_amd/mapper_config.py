@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import re
 from dataclasses import dataclass, field, fields
-from typing import Dict, Tuple, Union
+from typing import Dict, Optional, Tuple, Union
 
 from .densify import DensifyParams
 from .neural_gaussians import ModelDims, ScaffoldOptimizationParams
@@ -79,6 +79,7 @@ class MapperConfig:
     lambda_frequency_high: float = 0.0
     lambda_frequency_low: float = 0.0
     use_coarse_anchor: bool = False
+    coarse: Optional["CoarseParams"] = None          # Model.*_coarse / Optimization.*_coarse when use_coarse_anchor (coarse_anchors.py)
     raw: Dict[str, Scalar] = field(default_factory=dict)
 
     @property
@@ -121,7 +122,14 @@ def mapper_config_from_values(raw: Dict[str, Scalar], path: str = "<values>") ->
                          update_interval=I("Optimization.update_interval"), update_until=I("Optimization.update_until"),
                          min_opacity=F("Optimization.min_opacity"), success_threshold=F("Optimization.success_threshold"),
                          densify_grad_threshold=F("Optimization.densify_grad_threshold"))
-    return MapperConfig(model=model, opt=opt, densify=dens, white_background=B("Model.white_background"),
+    coarse = None
+    if B("Model.use_coarse_anchor"):                  # src/gaussian_mapper.cpp:433-491
+        from .coarse_anchors import CoarseParams
+        coarse = CoarseParams()
+        for f_ in fields(CoarseParams):
+            key = ("Model." if f_.name in ("feat_dim_coarse", "n_offsets_coarse", "coarse_voxel_size", "appearance_dim_coarse") else "Optimization.") + f_.name
+            setattr(coarse, f_.name, I(key) if f_.type in (int, "int") else F(key))
+    return MapperConfig(model=model, opt=opt, densify=dens, coarse=coarse, white_background=B("Model.white_background"),
                         z_near=F("Camera.z_near"), z_far=F("Camera.z_far"), max_num_iterations=I("Optimization.max_num_iterations"),
                         use_frequency_regularization=B("Mapper.use_frequency_regularization"),
                         use_multi_resolution=B("Mapper.use_multi_resolution"), scale_num=I("Mapper.scale_num"),
@@ -150,8 +158,9 @@ def make_mapper_step(cfg: MapperConfig, model, width: int, height: int, spatial_
     densification schedule :961-968, background :61-67."""
     from .densify import AnchorDensifier
     from .neural_gaussians import ScaffoldTrainerStep
-    if cfg.use_coarse_anchor:
-        raise NotImplementedError("Model.use_coarse_anchor = 1 (the coarse-anchor variant) is not built")
+    if cfg.use_coarse_anchor and getattr(model, "coarse", None) is None:
+        # the coarse set is made from the point cloud together with the fine one (src/gaussian_model.cpp:379-380)
+        raise ValueError("Model.use_coarse_anchor = 1: build the model with neural_gaussians.create_from_pcd(..., coarse=cfg.coarse)")
     step = ScaffoldTrainerStep(model, width, height, cfg.opt, spatial_lr_scale, process_group, scaling_reg_weight=0.01)
     step.row_mask = True
     step.set_background(cfg.white_background)

@@ -935,22 +935,24 @@ def init_mlps(dims: ModelDims, generator: torch.Generator) -> Dict[str, torch.Te
     return mlp
 
 
-def anchors_from_points(points: torch.Tensor, voxel_size: float) -> Tuple[torch.Tensor, torch.Tensor]:
+def anchors_from_points(points: torch.Tensor, voxel_size: float, place_size: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Shared head of createFromPcd / increasePcd (src/gaussian_model.cpp:343-361, 455-470): voxel centres
     unique_dim(round(points / voxel_size)) * voxel_size in lexicographic order, and log(sqrt(clamp_min(distCUDA2, 1e-7)))
-    repeated over the 6 scaling columns.  `points` (N,3) float32 on the GPU."""
+    repeated over the 6 scaling columns.  `points` (N,3) float32 on the GPU.  `place_size`: the size the unique voxel indices
+    are multiplied by when it is not the size they were rounded at (createCoarseAnchorFromPcd, :290-291)."""
     from .points import distCUDA2
-    fused = (torch.unique(torch.round(points / voxel_size), dim=0, sorted=True) * voxel_size).to(torch.float32).contiguous()
+    fused = (torch.unique(torch.round(points / voxel_size), dim=0, sorted=True) * (voxel_size if place_size is None else place_size)).to(torch.float32).contiguous()
     dist2 = torch.clamp_min(distCUDA2(fused), 0.0000001)
     scaling = torch.log(torch.sqrt(dist2)).unsqueeze(1).repeat(1, 6)
     return fused, scaling
 
 
 def create_from_pcd(points: torch.Tensor, dims: ModelDims, voxel_size: float, device, capacity: Optional[int] = None,
-                    mlp_seed: int = 0) -> ScaffoldModel:
+                    mlp_seed: int = 0, coarse=None) -> ScaffoldModel:
     """GaussianModel::createFromPcd (src/gaussian_model.cpp:327-381): anchors at the occupied voxels of the point cloud,
     zero offsets and features, isotropic log-scales from simple-knn, identity rotations, opacity inverse_sigmoid(0.1),
-    freshly initialised MLPs."""
+    freshly initialised MLPs.  `coarse` (coarse_anchors.CoarseParams; Model.use_coarse_anchor = 1): the coarse anchor set is
+    created from the same points and attached as `model.coarse` (:379-380)."""
     points = points.to(device, torch.float32)
     anchor, scaling = anchors_from_points(points, voxel_size)
     A = anchor.shape[0]
@@ -960,6 +962,9 @@ def create_from_pcd(points: torch.Tensor, dims: ModelDims, voxel_size: float, de
                init_mlps(dims, torch.Generator().manual_seed(0x5E65 + mlp_seed)))
     x = 0.1 * torch.ones((A, 1), dtype=torch.float32, device=device)
     model.opacity[:A] = torch.log(x / (1 - x))          # general_utils::inverse_sigmoid
+    if coarse is not None:
+        from .coarse_anchors import CoarseAnchors
+        model.coarse = CoarseAnchors.create_from_pcd(points, coarse, voxel_size, dims, device, mlp_seed)
     return model
 
 

@@ -16,7 +16,8 @@ from segs_slam_amd import mapper_config as mc  # noqa: E402
 REF = "/root/reference"
 FILES = ["cfg/gaussian_mapper/RGB-D/Replica/office0.yaml",
          "cfg/gaussian_mapper/RGB-D/TUM/tum_freiburg3_long_office_household.yaml",
-         "cfg/gaussian_mapper/RGB-D/ScanNet/scannet_rgbd.yaml"]
+         "cfg/gaussian_mapper/RGB-D/ScanNet/scannet_rgbd.yaml",
+         "cfg/colmap/gaussian_splatting.yaml"]        # (the offline configuration: Model.use_coarse_anchor = 1)
 out = {rel: mc.read_opencv_yaml(os.path.join(REF, rel)) for rel in FILES}
 with open(os.path.join(ROOT, "segs-slam_amd", "data", "mapper_cfgs.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)

@@ -224,3 +224,64 @@ def test_create_from_pcd_and_increase_pcd_match_restatement():
     gt = torch.full((3, cam.height, cam.width), 0.5, device=dev)
     losses = [float(step.training_once([kf], [gt])) for _ in range(30)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_coarse_anchor_set_is_created_and_grown_like_the_reference():
+    """Model.use_coarse_anchor = 1: createCoarseAnchorFromPcd / increasePcdCoarse (src/gaussian_model.cpp:288-325, 383-441)
+    restated with torch.unique and the oracle's simple-knn, quirks included -- the coarse set is rounded at coarse_voxel_size but
+    PLACED at unique * voxel_size (:290-291), and grown at the fine voxel size (:385-386); offsets and features take the FINE
+    n_offsets / feat_dim.  The set is an inert payload: the step trains exactly as without it and never touches it."""
+    from oracle import gs_oracle
+    from segs_slam_amd import coarse_anchors as ca, densify, mapper_config as mc, neural_gaussians as ng, scenes
+    dev = torch.device("cuda:0")
+    cfg = mc.load_committed_config("cfg/colmap/gaussian_splatting.yaml")
+    g = torch.Generator().manual_seed(21)
+    vs, cvs = 0.05, cfg.coarse.coarse_voxel_size
+    pts = torch.rand(8000, 3, generator=g) * torch.tensor([2.0, 1.5, 1.0]) + torch.tensor([-1.0, -0.75, 2.0])
+
+    def restate(p, round_size, place_size):
+        u = (torch.unique(torch.round(p / round_size), dim=0, sorted=True) * place_size).to(torch.float32)
+        d2 = torch.from_numpy(gs_oracle.knn_mean_dist2(u.numpy())).clamp_min(0.0000001)
+        return u, torch.log(torch.sqrt(d2)).unsqueeze(1).repeat(1, 6)
+
+    model = ng.create_from_pcd(pts, cfg.model, vs, dev, coarse=cfg.coarse)
+    plain = ng.create_from_pcd(pts, cfg.model, vs, dev)
+    c = model.coarse
+    u, sc = restate(pts, cvs, vs)
+    assert isinstance(c, ca.CoarseAnchors) and c.n == u.shape[0] and 0 < c.n < model.A          # 0.2-m voxels: far fewer than the fine set
+    assert torch.equal(c.anchor.cpu(), u) and torch.allclose(c.scaling.cpu(), sc, rtol=1e-6, atol=1e-6)
+    assert c.offset.shape == (c.n, cfg.model.n_offsets, 3) and c.anchor_feat.shape == (c.n, cfg.model.feat_dim)
+    assert float(c.offset.abs().max()) == 0.0 and float(c.anchor_feat.abs().max()) == 0.0
+    assert torch.equal(c.rotation.cpu(), torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(c.n, 1))
+    assert torch.allclose(c.opacity.cpu(), torch.full((c.n, 1), float(np.log(0.1 / 0.9))), atol=1e-6)
+    for name, shape in ca.coarse_mlp_shapes(cfg.model, cfg.coarse).items():
+        assert tuple(c.mlp[name].shape) == shape and float(c.mlp[name].abs().max()) > 0
+    names = [n for n, _, _ in c.optimizer_groups(0)]
+    assert names == ["anchor_c", "offset_c", "anchor_feat_c", "opacity_c", "scaling_c", "rotation_c", "mlp_opacity_c", "mlp_cov_c",
+                     "mlp_color_c", "mlp_apperance_c"]                                           # :730-758 (appearance, no feature bank)
+    lr = {n: v for n, _, v in c.optimizer_groups(15000)}
+    assert lr["anchor_c"] == 0.0 and lr["offset_c"] == pytest.approx(0.001) and lr["mlp_cov_c"] == pytest.approx(0.004)
+    # the fine set is what it is without the coarse one
+    assert torch.equal(model.params, plain.params)
+
+    # increasePcd -> increasePcdCoarse: the same new points, rounded and placed at the FINE voxel size, appended
+    dens = densify.AnchorDensifier(model, densify.DensifyParams(voxel_size=vs))
+    new = torch.rand(700, 3, generator=g) * torch.tensor([1.0, 1.0, 0.5]) + torch.tensor([1.2, -0.5, 2.2])
+    n0 = c.n
+    n_new = dens.increase_pcd(new.to(dev))
+    u2, sc2 = restate(new, vs, vs)
+    assert n_new == u2.shape[0] and c.n == n0 + u2.shape[0]
+    assert torch.equal(c.anchor[n0:].cpu(), u2) and torch.equal(c.anchor[:n0].cpu(), u)
+    assert torch.allclose(c.scaling[n0:].cpu(), sc2, rtol=1e-6, atol=1e-6) and c.max_radii2D.shape == (c.n,)
+
+    # a mapper step of this configuration takes the model; training leaves the coarse set bit for bit alone
+    cam = scenes.make_camera(160, 120, 150.0, 150.0, np.eye(3, dtype=np.float32), np.zeros(3, dtype=np.float32))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    kf = ng.Keyframe(t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center),
+                     torch.tensor([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=dev), cam.tanfovx, cam.tanfovy)
+    step = mc.make_mapper_step(cfg, model, cam.width, cam.height)
+    before = {k: v.clone() for k, v in (("anchor", c.anchor), ("scaling", c.scaling), ("w", c.mlp["mlp_cov_c.0.weight"]))}
+    gt = torch.full((3, cam.height, cam.width), 0.5, device=dev)
+    losses = [float(step.training_once([kf], [gt])) for _ in range(10)]
+    assert np.isfinite(losses).all()
+    assert torch.equal(before["anchor"], c.anchor) and torch.equal(before["scaling"], c.scaling) and torch.equal(before["w"], c.mlp["mlp_cov_c.0.weight"])

@@ -145,3 +145,27 @@ def test_mapper_step_from_configuration_applies_the_row_mask(tmp_path):
         assert float(dL[:, :6, :].abs().max()) == 0.0 and float(dL[1, 40, :].abs().max()) == 0.0
         assert float(dL[0, 40, :].abs().max()) > 0.0 and float(dL[:, 6:, :].abs().max()) > 0.0
     assert len(step._row_mask_cache) == 1
+
+
+def test_coarse_anchor_configuration_is_parsed_and_priced():
+    """Model.use_coarse_anchor = 1 (cfg/colmap/gaussian_splatting.yaml:141-185): the `_coarse` keys, the shapes of the five coarse
+    Sequentials (src/gaussian_model.cpp:112-148) and the learning rates of their optimizer groups (:686-787, 917-982)."""
+    from segs_slam_amd import coarse_anchors as ca, mapper_config as mc
+    cfg = mc.load_committed_config("cfg/colmap/gaussian_splatting.yaml")
+    assert cfg.use_coarse_anchor and cfg.coarse is not None
+    cp = cfg.coarse
+    assert (cp.feat_dim_coarse, cp.n_offsets_coarse, cp.appearance_dim_coarse) == (32, 10, 32) and abs(cp.coarse_voxel_size - 0.2) < 1e-12
+    assert cp.offset_lr_init_coarse == 0.01 and cp.mlp_color_lr_final_coarse == 0.00005 and cp.appearance_lr_max_steps_coarse == 30000
+    shapes = ca.coarse_mlp_shapes(cfg.model, cp)
+    assert shapes["mlp_opacity_c.0.weight"] == (32, 35) and shapes["mlp_opacity_c.2.weight"] == (10, 32)
+    assert shapes["mlp_cov_c.2.weight"] == (70, 32) and shapes["mlp_color_c.0.weight"] == (32, 35 + 32) and shapes["mlp_color_c.2.bias"] == (30,)
+    assert shapes["mlp_apperance_c.0.weight"] == (32, 7) and not any(k.startswith("mlp_feature_bank_c") for k in shapes)
+    assert ca.expon_lr(0, 0.01, 0.0001, 0.01, 30000) == pytest.approx(0.01) and ca.expon_lr(30000, 0.01, 0.0001, 0.01, 30000) == pytest.approx(0.0001)
+    assert ca.expon_lr(15000, 0.01, 0.0001, 0.01, 30000) == pytest.approx(0.001) and ca.expon_lr(100, 0.0, 0.0, 0.01, 30000) == 0.0
+    # the RGB-D configurations leave it off, and a step for a configuration with it on wants the coarse set made with the model
+    assert mc.load_committed_config("cfg/gaussian_mapper/RGB-D/Replica/office0.yaml").coarse is None
+
+    class _NoCoarse:
+        coarse = None
+    with pytest.raises(ValueError, match="use_coarse_anchor"):
+        mc.make_mapper_step(cfg, _NoCoarse(), 64, 48)
