@@ -5,16 +5,17 @@
 // which runs each as FOUR launches: row pass on the even/odd-packed real data, post-process + transpose, column pass,
 // transpose back (35 + 39 us at 1200x680, two thirds of the regulariser).  Here each direction is TWO launches and no
 // transpose:
-//   rows     one wave per image row: the W reals as W/2 complex numbers, a mixed-radix Stockham FFT of length W/2 in LDS
-//            (ping-pong, radices 8 / 4 / 2 / 3 / 5 / 17 -- 1200 = 2 x 8.3.5.5, 640 = 2 x 8.8.5, 1920 = 2 x 8.8.5.3), then the
-//            split into the W/2 + 1 non-redundant coefficients; the inverse direction runs the same steps backwards and ADDS
-//            its result into dL/dimage (the separate add launch is gone);
-//   columns  one workgroup per 8 adjacent half-spectrum columns of one channel: the tile is read as 64-byte row segments,
-//            stands in LDS one column after the other (680 = 8.5.17, 480 = 8.4.3.5, 1080 = 8.5.3.3.3), two columns per wave,
-//            and goes back the way it came.
-// Twiddle factors come from tables of N-th roots of unity made once per plan in double precision.  No wave ever waits for
-// another except at the two barriers of the column kernel (tile in, tile out).
-// Sizes whose factors are not all in {2, 3, 5, 17}, or whose tile does not fit the LDS, keep the library transforms.
+//   rows     a workgroup of 512 threads takes four image rows: the W reals are W/2 complex numbers, a mixed-radix Stockham FFT
+//            of length W/2 runs in LDS (ping-pong buffers, radices 8 / 4 / 2 / 3 / 5 / 17 -- 600 = 8.3.5.5, 320 = 8.8.5,
+//            960 = 8.8.3.5 -- one barrier per stage, the butterflies of all four rows dealt over the threads), then the split into
+//            the W/2 + 1 non-redundant coefficients; the inverse direction runs the same steps backwards and ADDS its result into
+//            dL/dimage (the separate add launch is gone);
+//   columns  a workgroup of 512 threads takes 8 adjacent half-spectrum columns of one channel -- ONE contiguous block of the
+//            tile-major storage (tiled_index below) -- transposes it into LDS, runs the eight length-H transforms (680 = 8.5.17,
+//            480 = 8.4.3.5, 1080 = 8.3.3.3.5) stage by stage and writes the block back; the inverse pass also folds the loss
+//            partials of the kernel in front of it (the separate finish launch is gone).
+// Twiddle factors come from tables of N-th roots of unity made once per plan in double precision.
+// Sizes whose factors are not all in {2, 3, 5, 17}, or whose tiles do not fit the LDS, keep the library transforms.
 #pragma once
 #include <hip/hip_runtime.h>
 
