@@ -256,17 +256,12 @@ __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const floa
     float2 ey, ex;
     sincospif(2.f * (float)ky2 / (float)H, &ey.y, &ey.x);
     sincospif(2.f * (float)kx2 / (float)W, &ex.y, &ex.x);
-    float2 cy2[4], cy4[4], cx2[4], cx4[4];
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-      const float2 e = rot90(ey, a), e2 = cmul(e, e);
-      cy2[a] = make_float2(0.5f * (1.f + e.x), 0.5f * e.y);
-      cy4[a] = make_float2(0.5f * (e.x + e2.x), 0.5f * (e.y + e2.y));
-      const float2 f = rot90(ex, a), f2 = cmul(f, f);
-      cx2[a] = make_float2(0.5f * (1.f + f.x), 0.5f * f.y);
-      cx4[a] = make_float2(0.5f * (f.x + f2.x), 0.5f * (f.y + f2.y));
-    }
-    float2 x[4][4];
+    // The fold factors C_2, C_4 of alias q along an axis are functions of e i^q (e = the axis' first-alias phase): formed where
+    // they are used instead of kept as four tables of four -- with the sixteen aliases re-read in the second loop (below) this
+    // kernel needs 60 registers less, i.e. four waves per SIMD instead of two (its 2 500 waves fit the chip in one round).
+    auto c2 = [](float2 e0, int q) { const float2 e = rot90(e0, q); return make_float2(0.5f * (1.f + e.x), 0.5f * e.y); };
+    auto c4 = [](float2 e0, int q) { const float2 e = rot90(e0, q), e2 = cmul(e, e); return make_float2(0.5f * (e.x + e2.x), 0.5f * (e.y + e2.y)); };
+    float2 y1[2][2] = {}, y2 = make_float2(0.f, 0.f);
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -274,15 +269,9 @@ __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const floa
         bool mir;
         const uint32_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
         const float2 v = X[o];
-        x[a][b] = mir ? make_float2(v.x, -v.y) : v;
-      }
-    float2 y1[2][2] = {}, y2 = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const float2 z1 = cmul(x[a][b], cmul(cy2[a], cx2[b]));
-        const float2 z2 = cmul(x[a][b], cmul(cy4[a], cx4[b]));
+        const float2 xab = mir ? make_float2(v.x, -v.y) : v;
+        const float2 z1 = cmul(xab, cmul(c2(ey, a), c2(ex, b)));
+        const float2 z2 = cmul(xab, cmul(c4(ey, a), c4(ex, b)));
         y1[a & 1][b & 1].x += z1.x; y1[a & 1][b & 1].y += z1.y;
         y2.x += z2.x; y2.y += z2.y;
       }
@@ -300,7 +289,8 @@ __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const floa
         for (int b = 0; b < 3; b++)
           if (b < 2 || kx2 == 0) {
             const uint32_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
-            T0[o] = sqrtf(x[a][b].x * x[a][b].x + x[a][b].y * x[a][b].y);
+            const float2 xv = X[o];                 // (|.| of the stored entry; a mirrored one has the same magnitude)
+            T0[o] = sqrtf(xv.x * xv.x + xv.y * xv.y);
           }
 #pragma unroll
       for (int a = 0; a < 2; a++)
@@ -320,11 +310,14 @@ __global__ void __launch_bounds__(256) freq_fold_kernel(int H, int W, const floa
       for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-          const uint32_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
-          float2 d = coeff(x[a][b], T0[o], w0, term);
+          uint32_t o = half_index(c, ky2 + a * H4, kx2 + b * W4, H, W, mir, tiled);
+          asm volatile("" : "+v"(o));              // (keeps the compiler from holding the first loop's sixteen loads instead)
+          const float2 xv = X[o];
+          const float2 xab = mir ? make_float2(xv.x, -xv.y) : xv;
+          float2 d = coeff(xab, T0[o], w0, term);
           if (b < 2 || (b == 2 && kx2 == 0)) {      // the stored half: columns 0 .. W/2
-            const float2 t1 = cmulc(q1[a & 1][b & 1], cmul(cy2[a], cx2[b]));
-            const float2 t2 = cmulc(q2, cmul(cy4[a], cx4[b]));
+            const float2 t1 = cmulc(q1[a & 1][b & 1], cmul(c2(ey, a), c2(ex, b)));
+            const float2 t2 = cmulc(q2, cmul(c4(ey, a), c4(ex, b)));
             d.x += 0.25f * t1.x + 0.0625f * t2.x;
             d.y += 0.25f * t1.y + 0.0625f * t2.y;
             D[o] = d;

@@ -168,7 +168,8 @@ __device__ __forceinline__ float2* transform(float2* a, float2* b, int N, const 
 // ---- rows, forward: (rows, W) real -> (rows, W/2 + 1) complex ------------------------------------------------------------
 // A workgroup of ROW_THREADS threads takes ROWS_PER_WG consecutive rows.  LDS (float2): rootM[M] | a[ROWS][M + 1] | b[ROWS][M + 1],
 // M = W/2;  rootW[n] = e^{-2 pi i n / W} (global), rootM[n] = rootW[2 n].
-constexpr int ROWS_PER_WG = 4, ROW_THREADS = 512;
+constexpr int ROWS_PER_WG = 4, ROW_THREADS = 512;   // (ROWS_PER_WG and TILE_COLS are powers of two: index masks below)
+static_assert((ROWS_PER_WG & (ROWS_PER_WG - 1)) == 0 && (TILE_COLS & (TILE_COLS - 1)) == 0, "index masks");
 __global__ void __launch_bounds__(ROW_THREADS) rows_r2c_kernel(const float* __restrict__ img, float2* __restrict__ X, int rows, int H, int W, Stages st,
                                                                const float2* __restrict__ rootW) {
   extern __shared__ __align__(16) float2 lds2[];
@@ -190,15 +191,20 @@ __global__ void __launch_bounds__(ROW_THREADS) rows_r2c_kernel(const float* __re
   const float2* Z = transform(a, b, M, st, nrows, pitch, rootM, -1.f);
 #endif
   // X[k] = E + e^{-2 pi i k / W} O,  E = (Z[k] + conj Z[M-k]) / 2,  O = (Z[k] - conj Z[M-k]) / (2 i),  k = 0 .. M  (Z[M] = Z[0])
-  for (int i = threadIdx.x; i < nrows * (M + 1); i += ROW_THREADS) {
-    const int r = fdiv(i, inv_M1), k = i - r * (M + 1);
+  // Store order: the workgroup's four rows of one column tile are ONE contiguous 256-byte run of the tile-major spectrum, so
+  // consecutive lanes take (row, column within the tile) of one tile rather than consecutive columns of one row.
+  const int c = row0 / H, y0 = row0 - c * H, ntl = tiles_of(M + 1);
+  (void)inv_M1;
+  for (int i = threadIdx.x; i < ntl * ROWS_PER_WG * TILE_COLS; i += ROW_THREADS) {
+    const int kk = i & (TILE_COLS - 1), r = (i / TILE_COLS) & (ROWS_PER_WG - 1), tl = i / (TILE_COLS * ROWS_PER_WG);
+    const int k = tl * TILE_COLS + kk;
+    if (r >= nrows || k > M) continue;
     const float2* z = Z + (size_t)r * pitch;
     const float2 zk = z[k == M ? 0 : k], zm = z[k == 0 ? 0 : M - k];
     const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
     const float2 d = make_float2(zk.x - zm.x, zk.y + zm.y);                    // Z[k] - conj Z[M-k]
     const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);                     // / (2 i)
-    const int row = row0 + r, c = row / H, y = row - c * H;
-    X[tiled_index(c, y, k, H, M + 1)] = cadd(e, cmul(rootW[k], o));
+    X[tiled_index(c, y0 + r, k, H, M + 1)] = cadd(e, cmul(rootW[k], o));
   }
 }
 
@@ -212,13 +218,17 @@ __global__ void __launch_bounds__(ROW_THREADS) rows_c2r_add_kernel(const float2*
   float2* b = a + (size_t)ROWS_PER_WG * pitch;
   const int row0 = blockIdx.x * ROWS_PER_WG, nrows = min(ROWS_PER_WG, rows - row0);
   for (int n = threadIdx.x; n < M; n += ROW_THREADS) rootM[n] = rootW[2 * n];
-  const float inv_M = 1.0f / (float)M, inv_M1 = 1.0f / (float)(M + 1);
-  for (int i = threadIdx.x; i < nrows * (M + 1); i += ROW_THREADS) {
-    const int r = fdiv(i, inv_M1), k = i - r * (M + 1);
-    const int row = row0 + r, c = row / H, y = row - c * H;
-    float2 v = D[tiled_index(c, y, k, H, M + 1)];
-    if (k == 0 || k == M) v.y = 0.f;          // a real signal's DC and Nyquist coefficients are real (what a C2R transform assumes)
-    b[(size_t)r * pitch + k] = v;
+  const float inv_M = 1.0f / (float)M;
+  {
+    const int c = row0 / H, y0 = row0 - c * H, ntl = tiles_of(M + 1);     // (load order: as the forward pass stores, 256-byte runs)
+    for (int i = threadIdx.x; i < ntl * ROWS_PER_WG * TILE_COLS; i += ROW_THREADS) {
+      const int kk = i & (TILE_COLS - 1), r = (i / TILE_COLS) & (ROWS_PER_WG - 1), tl = i / (TILE_COLS * ROWS_PER_WG);
+      const int k = tl * TILE_COLS + kk;
+      if (r >= nrows || k > M) continue;
+      float2 v = D[tiled_index(c, y0 + r, k, H, M + 1)];
+      if (k == 0 || k == M) v.y = 0.f;        // a real signal's DC and Nyquist coefficients are real (what a C2R transform assumes)
+      b[(size_t)r * pitch + k] = v;
+    }
   }
   __syncthreads();
   // Zin[k] = E + i O,  E = D[k] + conj D[M-k],  O = (D[k] - conj D[M-k]) e^{+2 pi i k / W},  k = 0 .. M-1
