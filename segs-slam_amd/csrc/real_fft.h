@@ -168,6 +168,7 @@ __device__ __forceinline__ float2* transform(float2* a, float2* b, int N, const 
 // ---- rows, forward: (rows, W) real -> (rows, W/2 + 1) complex ------------------------------------------------------------
 // A workgroup of ROW_THREADS threads takes ROWS_PER_WG consecutive rows.  LDS (float2): rootM[M] | a[ROWS][M + 1] | b[ROWS][M + 1],
 // M = W/2;  rootW[n] = e^{-2 pi i n / W} (global), rootM[n] = rootW[2 n].
+constexpr int GU = 5;   // global loads of a thread in flight together (row and column passes)
 constexpr int ROWS_PER_WG = 4, ROW_THREADS = 512;   // (ROWS_PER_WG and TILE_COLS are powers of two: index masks below)
 static_assert((ROWS_PER_WG & (ROWS_PER_WG - 1)) == 0 && (TILE_COLS & (TILE_COLS - 1)) == 0, "index masks");
 __global__ void __launch_bounds__(ROW_THREADS) rows_r2c_kernel(const float* __restrict__ img, float2* __restrict__ X, int rows, int H, int W, Stages st,
@@ -180,9 +181,22 @@ __global__ void __launch_bounds__(ROW_THREADS) rows_r2c_kernel(const float* __re
   const int row0 = blockIdx.x * ROWS_PER_WG, nrows = min(ROWS_PER_WG, rows - row0);
   for (int n = threadIdx.x; n < M; n += ROW_THREADS) rootM[n] = rootW[2 * n];
   const float inv_M = 1.0f / (float)M, inv_M1 = 1.0f / (float)(M + 1);
-  for (int i = threadIdx.x; i < nrows * M; i += ROW_THREADS) {       // z[n] = x[2n] + i x[2n+1]
-    const int r = fdiv(i, inv_M), n = i - r * M;
-    a[(size_t)r * pitch + n] = reinterpret_cast<const float2*>(img + (size_t)(row0 + r) * W)[n];
+  // z[n] = x[2n] + i x[2n+1].  Global loads in groups of GU, all of a group in flight before the first is used: as a plain loop
+  // every iteration waited for its own load (five dependent round trips per pass at 1200 columns).
+  for (int base = 0; base < nrows * M; base += GU * ROW_THREADS) {
+    float2 v[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = base + u * ROW_THREADS + (int)threadIdx.x;
+      const int r = fdiv(i, inv_M), n = i - r * M;
+      v[u] = i < nrows * M ? reinterpret_cast<const float2*>(img + (size_t)(row0 + r) * W)[n] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = base + u * ROW_THREADS + (int)threadIdx.x;
+      const int r = fdiv(i, inv_M), n = i - r * M;
+      if (i < nrows * M) a[(size_t)r * pitch + n] = v[u];
+    }
   }
   __syncthreads();
 #if defined(SEGS_MEASURE) && defined(RFFT_ABLATE_NO_ROW_TRANSFORM)   // measurement only
@@ -221,13 +235,27 @@ __global__ void __launch_bounds__(ROW_THREADS) rows_c2r_add_kernel(const float2*
   const float inv_M = 1.0f / (float)M;
   {
     const int c = row0 / H, y0 = row0 - c * H, ntl = tiles_of(M + 1);     // (load order: as the forward pass stores, 256-byte runs)
-    for (int i = threadIdx.x; i < ntl * ROWS_PER_WG * TILE_COLS; i += ROW_THREADS) {
-      const int kk = i & (TILE_COLS - 1), r = (i / TILE_COLS) & (ROWS_PER_WG - 1), tl = i / (TILE_COLS * ROWS_PER_WG);
-      const int k = tl * TILE_COLS + kk;
-      if (r >= nrows || k > M) continue;
-      float2 v = D[tiled_index(c, y0 + r, k, H, M + 1)];
-      if (k == 0 || k == M) v.y = 0.f;        // a real signal's DC and Nyquist coefficients are real (what a C2R transform assumes)
-      b[(size_t)r * pitch + k] = v;
+    const int total = ntl * ROWS_PER_WG * TILE_COLS;
+    for (int base = 0; base < total; base += GU * ROW_THREADS) {
+      float2 v[GU];
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const int i = base + u * ROW_THREADS + (int)threadIdx.x;
+        const int kk = i & (TILE_COLS - 1), r = (i / TILE_COLS) & (ROWS_PER_WG - 1), tl = i / (TILE_COLS * ROWS_PER_WG);
+        const int k = tl * TILE_COLS + kk;
+        v[u] = (i < total && r < nrows && k <= M) ? D[tiled_index(c, y0 + r, k, H, M + 1)] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+        const int i = base + u * ROW_THREADS + (int)threadIdx.x;
+        const int kk = i & (TILE_COLS - 1), r = (i / TILE_COLS) & (ROWS_PER_WG - 1), tl = i / (TILE_COLS * ROWS_PER_WG);
+        const int k = tl * TILE_COLS + kk;
+        if (i < total && r < nrows && k <= M) {
+          float2 w = v[u];
+          if (k == 0 || k == M) w.y = 0.f;      // a real signal's DC and Nyquist coefficients are real (what a C2R transform assumes)
+          b[(size_t)r * pitch + k] = w;
+        }
+      }
     }
   }
   __syncthreads();
@@ -249,13 +277,23 @@ __global__ void __launch_bounds__(ROW_THREADS) rows_c2r_add_kernel(const float2*
 #else
   const float2* z = transform(a, b, M, st, nrows, pitch, rootM, +1.f);
 #endif
-  for (int i = threadIdx.x; i < nrows * M; i += ROW_THREADS) {
-    const int r = fdiv(i, inv_M), n = i - r * M;
-    float2* out = reinterpret_cast<float2*>(dst_img + (size_t)(row0 + r) * W) + n;
-    const float2 zz = z[(size_t)r * pitch + n];
-    float2 v = *out;
-    v.x += zz.x; v.y += zz.y;
-    *out = v;
+  for (int base = 0; base < nrows * M; base += GU * ROW_THREADS) {
+    float2 v[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = base + u * ROW_THREADS + (int)threadIdx.x;
+      const int r = fdiv(i, inv_M), n = i - r * M;
+      v[u] = i < nrows * M ? reinterpret_cast<const float2*>(dst_img + (size_t)(row0 + r) * W)[n] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = base + u * ROW_THREADS + (int)threadIdx.x;
+      const int r = fdiv(i, inv_M), n = i - r * M;
+      if (i < nrows * M) {
+        const float2 zz = z[(size_t)r * pitch + n];
+        reinterpret_cast<float2*>(dst_img + (size_t)(row0 + r) * W)[n] = make_float2(v[u].x + zz.x, v[u].y + zz.y);
+      }
+    }
   }
 }
 
@@ -276,9 +314,19 @@ __global__ void __launch_bounds__(COL_THREADS) cols_kernel(float2* __restrict__ 
   const int ncols = min(TILE_COLS, Wc - kx0);
   float2* tile = X + ((size_t)c * tiles_of(Wc) + blockIdx.x) * H * TILE_COLS;     // [y][t], contiguous
   for (int n = threadIdx.x; n < H; n += COL_THREADS) rootH[n] = rootH_g[n];
-  for (int i = threadIdx.x; i < H * TILE_COLS; i += COL_THREADS) {
-    const int y = i / TILE_COLS, t = i - y * TILE_COLS;
-    A[(size_t)t * H + y] = tile[i];           // (columns beyond Wc hold whatever the buffer holds: transformed nowhere, written back as read)
+  for (int base = 0; base < H * TILE_COLS; base += GU * COL_THREADS) {     // (GU loads in flight per thread, as in the row passes)
+    float2 v[GU];
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = base + u * COL_THREADS + (int)threadIdx.x;
+      v[u] = i < H * TILE_COLS ? tile[i] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < GU; u++) {
+      const int i = base + u * COL_THREADS + (int)threadIdx.x;
+      const int y = i / TILE_COLS, t = i - y * TILE_COLS;
+      if (i < H * TILE_COLS) A[(size_t)t * H + y] = v[u];     // (columns beyond Wc hold whatever the buffer holds: transformed nowhere)
+    }
   }
   __syncthreads();
 #if defined(SEGS_MEASURE) && defined(RFFT_ABLATE_NO_TRANSFORM)   // measurement only (tools/ab_fft_variant.sh): tile in, tile out
