@@ -291,8 +291,12 @@ def main():
             dist_extra = dist_blocks(world, rank, dev, sharded_opt, args.force_dist)
         except Exception as e:  # noqa: BLE001  (every rank takes the same path: a failure is one of construction, not of one rank)
             dist_extra = {"error": f"{type(e).__name__}: {e}"}
+    if args.mode != "raster" and tstep is not None:
+        # a training step whose forward outgrew the resident capacity is dropped on the device and run again at the top of the NEXT
+        # call (by every rank together): resolve the last one here, on every rank, before anything is reported
+        tstep.finish()
     if rank == 0:
-        eng.check()
+        eng.check(raise_on_overflow=args.mode == "raster")     # (the static raster workload can never outgrow its calibration)
         # The reference's num_rendered R (bounding-square duplication, from the calibrating reference-shaped forward) prices
         # the reference's work; the resident forward bins fewer instances (tight rectangles) and drops the dead ones in the
         # first tile-id pass, so its tile kernels walk `instances_live`: the dominant kernel's roofline is priced on THOSE.
