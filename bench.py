@@ -524,6 +524,7 @@ def dist_blocks(world, rank, dev, sharded_opt, force, steps: int = 40, warmup: i
     gt = torch.rand(3, cam.height, cam.width, device=dev)
     tstep.keyframe_for = lambda step, n: 0
     wall, per, ex_ms = _timed_dist_steps(lambda: tstep.training_once([kf], [gt]), tstep._exchange, world, dev, steps, warmup)
+    tstep.finish()                     # (a drop of the last iteration is run again here, by every rank)
     ex = tstep._exchange()
     out["mapper_step_c5"] = {"workload": f"anchor-level mapper step, {model.A} anchors x 10 offsets, {cam.width}x{cam.height}, appearance_dim 16, "
                                          "no feature bank, one keyframe per rank",
@@ -531,7 +532,7 @@ def dist_blocks(world, rank, dev, sharded_opt, force, steps: int = 40, warmup: i
                              "exchange": "reduce-scatter -> sharded Adam -> all-gather" if ex.sharded else "dense all-reduce",
                              "exchanged_MB": ex.n * 4 / 1e6, "bucket_MB": (ex.offset + ex.n) * 4 / 1e6,
                              "frozen_anchor_segment_left_out": ex.offset > 0, "exchange_ms_per_step": ex_ms, "collectives": per,
-                             "dropped_steps": tstep.dropped_steps()}
+                             "dropped_steps": tstep.dropped_steps(), "redone_steps": tstep.redone_steps, "lost_steps": tstep.lost_steps()}
     del tstep, model
     torch.cuda.empty_cache()
     # ---- config 4
@@ -540,6 +541,7 @@ def dist_blocks(world, rank, dev, sharded_opt, force, steps: int = 40, warmup: i
     kfs, gts = [keyframe_tensors(sc.camera, dev)], [torch.rand(3, sc.camera.height, sc.camera.width, device=dev)]
     ts4.keyframe_for = lambda step, n: 0
     wall, per, ex_ms = _timed_dist_steps(lambda: ts4.training_once(kfs, gts), lambda: ts4.exchange, world, dev, steps, warmup)
+    ts4.finish()
     out["trainer_step_c4"] = {"workload": f"trainer step (raster + L1/SSIM + fused Adam), {sc.P} Gaussians, {sc.camera.width}x{sc.camera.height}, one keyframe per rank",
                               "iters_per_s": world * steps / wall, "ms_per_step": wall / steps * 1e3, "steps": steps, "warmup": warmup,
                               "exchange": "reduce-scatter -> sharded Adam -> all-gather" if ts4.exchange.sharded else "dense all-reduce",
